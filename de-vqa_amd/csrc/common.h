@@ -1,0 +1,56 @@
+// Shared device/host helpers for libdevqa_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/devqa.h"
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short short8_t;   // 8 bf16 = one MFMA A/B fragment
+typedef __attribute__((ext_vector_type(4))) float float4_t;   // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float float16_t; // 32x32 MFMA accumulator
+
+extern thread_local char g_devqa_err[512];
+int devqa_fail(int code, const char* fmt, ...);
+
+#define DEVQA_CHECK_ARG(cond, ...)                                   \
+    do {                                                             \
+        if (!(cond)) return devqa_fail(DEVQA_E_ARG, __VA_ARGS__);    \
+    } while (0)
+#define DEVQA_CHECK_SHAPE(cond, ...)                                 \
+    do {                                                             \
+        if (!(cond)) return devqa_fail(DEVQA_E_SHAPE, __VA_ARGS__);  \
+    } while (0)
+#define DEVQA_LAUNCH_CHECK(name)                                                                 \
+    do {                                                                                         \
+        hipError_t e_ = hipGetLastError();                                                       \
+        if (e_ != hipSuccess) return devqa_fail(DEVQA_E_HIP, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

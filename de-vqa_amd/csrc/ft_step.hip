@@ -1,0 +1,231 @@
+// FT_VL inner-step kernels on the edited matrix W [Dout, Din] (fp32 master copies, one per
+// in-flight edit).  Both kernels are HBM streams over the matrix with 16-byte accesses:
+//
+//   ft_adamw_step : rank-L gradient (built on the fly from dy and a; never written to HBM)
+//                   -> AdamW (torch.optim.AdamW semantics) -> optional L-inf clamp
+//                   -> y = W_new . a for the next step's forward, all in one sweep.
+//                   Algorithmic bytes per edit-step: 6 x 4 x Dout x Din (r/w of w, m, v).
+//   rows_matvec   : y = W . a (+bias +resid) for a few cached rows.
+//
+// Work decomposition: one workgroup (256 threads) owns ROWS consecutive output rows i of one
+// edit; threads stride over Din in float4 units, so each wave-instruction touches 1 KiB of
+// contiguous HBM.  The a-rows (L x Din fp32, <= 320 KB) are re-read by every workgroup and stay
+// L2/MALL resident.  Per-row dot products are reduced with wavefront shuffles + one LDS hop.
+#include "common.h"
+
+template <int L, int ROWS>
+__global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ w, float* __restrict__ m,
+                                                            float* __restrict__ v, const float* __restrict__ w0,
+                                                            const float* __restrict__ a, const float* __restrict__ dy,
+                                                            float* __restrict__ y, const int32_t* __restrict__ do_update,
+                                                            const int32_t* __restrict__ adam_t, int Lmax, int Dout, int Din,
+                                                            float lr, float beta1, float beta2, float eps, float wd,
+                                                            float clamp_eps, int row_blocks) {
+    __shared__ float red[4][ROWS * L];
+    const int e = blockIdx.x / row_blocks;
+    const int rb = blockIdx.x % row_blocks;
+    if (!do_update[e]) return;  // uniform
+    const int t = adam_t[e];
+    const bool first = (t <= 1);
+    const float bc1 = 1.f - powf(beta1, (float)t);
+    const float bc2 = 1.f - powf(beta2, (float)t);
+    const float step_size = lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    const float decay = 1.f - lr * wd;
+
+    const int i0 = rb * ROWS;
+    const int64_t mat = (int64_t)Dout * Din;
+    float* we = w + (int64_t)e * mat;
+    float* me = m + (int64_t)e * mat;
+    float* ve = v + (int64_t)e * mat;
+    const float* ae = a + (int64_t)e * Lmax * Din;
+    const float* dye = dy + (int64_t)e * Lmax * Dout;
+
+    float dyv[ROWS][L];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int l = 0; l < L; ++l) dyv[r][l] = (i0 + r < Dout && l < Lmax) ? dye[(int64_t)l * Dout + i0 + r] : 0.f;
+
+    float ysum[ROWS][L];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int l = 0; l < L; ++l) ysum[r][l] = 0.f;
+
+    const int nv = Din >> 2;
+    for (int c = threadIdx.x; c < nv; c += 256) {
+        float4 av[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            av[l] = (l < Lmax) ? reinterpret_cast<const float4*>(ae + (int64_t)l * Din)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int i = i0 + r;
+            if (i >= Dout) continue;
+            const int64_t off = (int64_t)i * nv + c;
+            float4 wv, mv, vv, w0v;
+            if (first) {
+                w0v = reinterpret_cast<const float4*>(w0)[off];
+                wv = w0v;
+                mv = make_float4(0.f, 0.f, 0.f, 0.f);
+                vv = mv;
+            } else {
+                wv = reinterpret_cast<const float4*>(we)[off];
+                mv = reinterpret_cast<const float4*>(me)[off];
+                vv = reinterpret_cast<const float4*>(ve)[off];
+                if (clamp_eps >= 0.f) w0v = reinterpret_cast<const float4*>(w0)[off];
+            }
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                g[0] += dyv[r][l] * av[l].x;
+                g[1] += dyv[r][l] * av[l].y;
+                g[2] += dyv[r][l] * av[l].z;
+                g[3] += dyv[r][l] * av[l].w;
+            }
+            float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+            float mq[4] = {mv.x, mv.y, mv.z, mv.w};
+            float vq[4] = {vv.x, vv.y, vv.z, vv.w};
+            const float w0q[4] = {w0v.x, w0v.y, w0v.z, w0v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // torch.optim.AdamW (single-tensor path): decay, lerp m, addcmul v, addcdiv
+                wq[k] *= decay;
+                mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
+                vq[k] = vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
+                const float denom = sqrtf(vq[k]) / bc2_sqrt + eps;
+                wq[k] -= step_size * (mq[k] / denom);
+                if (clamp_eps >= 0.f) wq[k] = fminf(fmaxf(wq[k], w0q[k] - clamp_eps), w0q[k] + clamp_eps);
+            }
+            reinterpret_cast<float4*>(we)[off] = make_float4(wq[0], wq[1], wq[2], wq[3]);
+            reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
+            reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                ysum[r][l] += (wq[0] * av[l].x + wq[1] * av[l].y) + (wq[2] * av[l].z + wq[3] * av[l].w);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const float s = wave_sum(ysum[r][l]);
+            if (lane == 0) red[wave][r * L + l] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < ROWS * L) {
+        const int r = threadIdx.x / L, l = threadIdx.x % L;
+        if (i0 + r < Dout && l < Lmax) {
+            const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            y[((int64_t)e * Lmax + l) * Dout + i0 + r] = s;
+        }
+    }
+}
+
+template <int L, int ROWS>
+static int launch_adamw(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
+                        const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din, float lr,
+                        float beta1, float beta2, float eps, float wd, float clamp_eps, hipStream_t st) {
+    const int row_blocks = (Dout + ROWS - 1) / ROWS;
+    hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
+                       do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks);
+    DEVQA_LAUNCH_CHECK("ft_adamw_step");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
+                                   const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
+                                   float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
+                                   void* stream) {
+    DEVQA_CHECK_ARG(w && m && v && w0 && a && dy && y && do_update && adam_t, "ft_adamw_step: null pointer");
+    if (E == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(E > 0 && Lmax >= 1 && Lmax <= 8, "ft_adamw_step: Lmax=%d unsupported (1..8)", Lmax);
+    DEVQA_CHECK_SHAPE(Dout > 0 && Din > 0 && Din % 4 == 0, "ft_adamw_step: bad matrix dims %dx%d", Dout, Din);
+    DEVQA_CHECK_SHAPE((long)E * ((Dout + 1) / 2) < 2147483647L, "ft_adamw_step: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+#define ARGS w, m, v, w0, a, dy, y, do_update, adam_t, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps, st
+    if (Lmax <= 1) return launch_adamw<1, 4>(ARGS);
+    if (Lmax <= 2) return launch_adamw<2, 4>(ARGS);
+    if (Lmax <= 4) return launch_adamw<4, 2>(ARGS);
+    return launch_adamw<8, 2>(ARGS);
+#undef ARGS
+}
+
+// ------------------------------------------------------------------------------------------
+template <int L, int ROWS>
+__global__ __launch_bounds__(256) void rows_matvec_kernel(const float* __restrict__ w, int64_t w_stride_e,
+                                                          const float* __restrict__ a, const float* __restrict__ bias,
+                                                          const float* __restrict__ resid, float* __restrict__ y, int Lr,
+                                                          int Dout, int Din, int row_blocks) {
+    __shared__ float red[4][ROWS * L];
+    const int e = blockIdx.x / row_blocks;
+    const int rb = blockIdx.x % row_blocks;
+    const int i0 = rb * ROWS;
+    const float* we = w + (int64_t)e * w_stride_e;
+    const float* ae = a + (int64_t)e * Lr * Din;
+    float ysum[ROWS][L];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int l = 0; l < L; ++l) ysum[r][l] = 0.f;
+    const int nv = Din >> 2;
+    for (int c = threadIdx.x; c < nv; c += 256) {
+        float4 av[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            av[l] = (l < Lr) ? reinterpret_cast<const float4*>(ae + (int64_t)l * Din)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int i = i0 + r;
+            if (i >= Dout) continue;
+            const float4 wv = reinterpret_cast<const float4*>(we)[(int64_t)i * nv + c];
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                ysum[r][l] += (wv.x * av[l].x + wv.y * av[l].y) + (wv.z * av[l].z + wv.w * av[l].w);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const float s = wave_sum(ysum[r][l]);
+            if (lane == 0) red[wave][r * L + l] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < ROWS * L) {
+        const int r = threadIdx.x / L, l = threadIdx.x % L;
+        if (i0 + r < Dout && l < Lr) {
+            float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            const int64_t o = ((int64_t)e * Lr + l) * Dout + i0 + r;
+            if (bias) s += bias[i0 + r];
+            if (resid) s += resid[o];
+            y[o] = s;
+        }
+    }
+}
+
+extern "C" int devqa_rows_matvec_f32(const float* w, int64_t w_stride_e, const float* a, const float* bias,
+                                     const float* resid, float* y, int E, int L, int Dout, int Din, void* stream) {
+    DEVQA_CHECK_ARG(w && a && y, "rows_matvec: null pointer");
+    if (E == 0 || L == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(E > 0 && L >= 1 && L <= 8, "rows_matvec: L=%d unsupported (1..8)", L);
+    DEVQA_CHECK_SHAPE(Dout > 0 && Din > 0 && Din % 4 == 0, "rows_matvec: bad matrix dims");
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int ROWS = 4;
+    const int row_blocks = (Dout + ROWS - 1) / ROWS;
+    DEVQA_CHECK_SHAPE((long)E * row_blocks < 2147483647L, "rows_matvec: grid too large");
+    if (L <= 2)
+        hipLaunchKernelGGL((rows_matvec_kernel<2, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, a, bias,
+                           resid, y, L, Dout, Din, row_blocks);
+    else if (L <= 4)
+        hipLaunchKernelGGL((rows_matvec_kernel<4, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, a, bias,
+                           resid, y, L, Dout, Din, row_blocks);
+    else
+        hipLaunchKernelGGL((rows_matvec_kernel<8, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, a, bias,
+                           resid, y, L, Dout, Din, row_blocks);
+    DEVQA_LAUNCH_CHECK("rows_matvec");
+    return DEVQA_OK;
+}

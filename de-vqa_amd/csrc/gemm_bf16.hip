@@ -1,0 +1,195 @@
+// bf16 TN GEMM on MFMA for gfx950:  C[M,N] = epi( A[M,K] . W[N,K]^T )
+//
+// Both operands are K-contiguous (activations row-major, nn.Linear weights [out,in]), which is
+// exactly the lane layout v_mfma_f32_16x16x32_bf16 wants: lane l supplies 8 consecutive k
+// (16 bytes) of row l&15, k-group l>>4.  Tiles are staged global -> registers -> LDS
+// (double-buffered, one barrier per K-step); the LDS image is [rows][64 k] bf16 with the 16-byte
+// chunk index XOR-swizzled by (row>>1)&7 so that the 16 rows x 4 chunks a ds_read_b128 fragment
+// read touches land on 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
+//
+// Block = 256 threads = 4 waves arranged WM x WN; wave tile (BM/WM) x (BN/WN) of 16x16 MFMA tiles.
+// blockIdx -> tile mapping is XCD-aware: consecutive tile ids (which share the same W panel)
+// are dealt to the same XCD so a panel is fetched into one L2 instead of eight.
+#include "common.h"
+
+#define BK 64
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(
+    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+    const float* __restrict__ bias, int M, int N, int K, float alpha, int act, const float* residual,
+    bf16_t* out_bf16, float* out_f32, int64_t ldc, int tiles_m, int tiles_n) {
+    constexpr int TM = BM / WM / 16;  // 16-row MFMA tiles per wave along M
+    constexpr int TN = BN / WN / 16;
+    constexpr int A_CHUNKS = BM * (BK / 8) / 256;  // 16-byte chunks per thread per tile
+    constexpr int B_CHUNKS = BN * (BK / 8) / 256;
+    static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small for 256 threads");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: [buf][A tile | B tile]
+    constexpr int A_BYTES = BM * BK * 2;
+    constexpr int B_BYTES = BN * BK * 2;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+
+    // ---- XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous run ----
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // m fastest: consecutive blocks walk down M for one N panel (W panel stays L2 resident)
+    const int tile_m = bid % tiles_m;
+    const int tile_n = bid / tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    float4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[A_CHUNKS], rb[B_CHUNKS];
+    const int nk = (K + BK - 1) / BK;
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            const int id = tid + i * 256;
+            const int row = id >> 3, c = id & 7;
+            const int gm = m0 + row, gk = k0 + c * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gm < M && gk < K) v = *reinterpret_cast<const uint4*>(A + (int64_t)gm * lda + gk);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_CHUNKS; ++i) {
+            const int id = tid + i * 256;
+            const int row = id >> 3, c = id & 7;
+            const int gn = n0 + row, gk = k0 + c * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gn < N && gk < K) v = *reinterpret_cast<const uint4*>(W + (int64_t)gn * ldw + gk);
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE_BYTES;
+        unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            const int id = tid + i * 256;
+            const int row = id >> 3, c = id & 7;
+            *reinterpret_cast<uint4*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_CHUNKS; ++i) {
+            const int id = tid + i * 256;
+            const int row = id >> 3, c = id & 7;
+            *reinterpret_cast<uint4*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = rb[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char* sa = smem + cur * STAGE_BYTES;
+        const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            short8_t af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * (BM / WM) + i * 16 + fr;
+                const int c = ks * 4 + fq;
+                af[i] = *reinterpret_cast<const short8_t*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * (BN / WN) + j * 16 + fr;
+                const int c = ks * 4 + fq;
+                bfr[j] = *reinterpret_cast<const short8_t*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 16 + fr;
+            if (n >= N) continue;
+            const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + fq * 4 + r;
+                if (m >= M) continue;
+                float v = (acc[i][j][r] + b) * alpha;
+                if (act == DEVQA_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (act == DEVQA_ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+                const int64_t o = (int64_t)m * ldc + n;
+                if (residual) v += residual[o];
+                if (out_f32) out_f32[o] = v;
+                if (out_bf16) out_bf16[o] = f32_to_bf16(v);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N,
+                       int K, float alpha, int act, const float* residual, bf16_t* out_bf16, float* out_f32,
+                       int64_t ldc, hipStream_t st) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const size_t smem = 2 * (BM + BN) * BK * 2;
+    auto kern = gemm_bf16_tn_kernel<BM, BN, WM, WN>;
+    static bool attr_done = false;
+    if (!attr_done && smem > 48 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, st, A, lda, W, ldw, bias, M, N, K, alpha, act,
+                       residual, out_bf16, out_f32, ldc, tiles_m, tiles_n);
+    DEVQA_LAUNCH_CHECK("gemm_bf16");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64_t ldw, const float* bias,
+                               int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
+                               float* out_f32, int64_t ldc, void* stream) {
+    DEVQA_CHECK_ARG(A && W, "gemm: null operand");
+    DEVQA_CHECK_ARG(out_bf16 || out_f32, "gemm: no output");
+    DEVQA_CHECK_ARG(act >= 0 && act <= 2, "gemm: bad act %d", act);
+    if (M == 0 || N == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "gemm: bad dims %d %d %d", M, N, K);
+    DEVQA_CHECK_SHAPE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K/lda/ldw must be multiples of 8 (K=%d lda=%lld ldw=%lld)",
+                      K, (long long)lda, (long long)ldw);
+    DEVQA_CHECK_SHAPE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dims too small");
+    DEVQA_CHECK_SHAPE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm: operands must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= 32) return launch_gemm<32, 128, 1, 4>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    if (M <= 64) return launch_gemm<64, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    // mid-size problems: prefer more, smaller tiles when the 128x128 grid would not fill 256 CUs
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (t128 < 384)
+        return launch_gemm<64, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    return launch_gemm<128, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+}

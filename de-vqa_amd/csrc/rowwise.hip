@@ -1,0 +1,386 @@
+// Row-wise / elementwise kernels: LayerNorm fwd, LayerNorm bwd (dx), patch im2col, ViT embedding
+// assembly, token-embedding gather + OPT positions, row gather, casts, delta ops, FT loop control.
+// All are HBM-bound: 16-byte (float4 / 8xbf16) accesses, one wave per row where a row reduction
+// is needed (wavefront shuffles, no LDS), grids capped and grid-strided.
+#include <stdarg.h>
+#include "common.h"
+
+thread_local char g_devqa_err[512] = {0};
+int devqa_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_devqa_err, sizeof(g_devqa_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* devqa_last_error(void) { return g_devqa_err; }
+extern "C" int devqa_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row, row held in registers (D <= 64*4*MAXV).
+// ------------------------------------------------------------------------------------------
+#define LN_MAXV 16
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int M, int D, float eps, bf16_t* __restrict__ out_bf16,
+                                                        float* __restrict__ out_f32) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    const float4* ar = add ? reinterpret_cast<const float4*>(add + (int64_t)row * D) : nullptr;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            float4 t = xr[c];
+            if (ar) {
+                const float4 u = ar[c];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            v[i] = t;
+            s += (t.x + t.y) + (t.z + t.w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            const float4 g = g4[c], b = b4[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x;
+            o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z;
+            o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            if (out_f32) reinterpret_cast<float4*>(out_f32 + (int64_t)row * D)[c] = o;
+            if (out_bf16) {
+                uint2 p;
+                p.x = pack_bf16x2(o.x, o.y);
+                p.y = pack_bf16x2(o.z, o.w);
+                reinterpret_cast<uint2*>(out_bf16 + (int64_t)row * D)[c] = p;
+            }
+        }
+    }
+}
+
+extern "C" int devqa_layernorm(const float* x, const float* add, const float* gamma, const float* beta, int M, int D,
+                               float eps, devqa_bf16* out_bf16, float* out_f32, void* stream) {
+    DEVQA_CHECK_ARG(x && gamma && beta && (out_bf16 || out_f32), "layernorm: null pointer");
+    if (M == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "layernorm: D=%d unsupported", D);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta, M, D,
+                       eps, out_bf16, out_f32);
+    DEVQA_LAUNCH_CHECK("layernorm");
+    return DEVQA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm backward w.r.t. input:  xhat=(x-mean)*rstd, gy=dy*gamma,
+//   dx = rstd * (gy - mean(gy) - xhat*mean(gy*xhat))
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ dy, int M, int D, float eps,
+                                                               float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    const float4* dr = reinterpret_cast<const float4*>(dy + (int64_t)row * D);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    float4 v[LN_MAXV], gy[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            v[i] = xr[c];
+            const float4 d = dr[c], g = g4[c];
+            gy[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            gy[i] = v[i];
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // xhat
+            s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
+            s2 += (gy[i].x * v[i].x + gy[i].y * v[i].y) + (gy[i].z * v[i].z + gy[i].w * v[i].w);
+        }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            float4 o;
+            o.x = rstd * (gy[i].x - m1 - v[i].x * m2);
+            o.y = rstd * (gy[i].y - m1 - v[i].y * m2);
+            o.z = rstd * (gy[i].z - m1 - v[i].z * m2);
+            o.w = rstd * (gy[i].w - m1 - v[i].w * m2);
+            reinterpret_cast<float4*>(dx + (int64_t)row * D)[c] = o;
+        }
+    }
+}
+
+extern "C" int devqa_layernorm_bwd_dx(const float* x, const float* gamma, const float* dy, int M, int D, float eps,
+                                      float* dx, void* stream) {
+    DEVQA_CHECK_ARG(x && gamma && dy && dx, "layernorm_bwd_dx: null pointer");
+    if (M == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "layernorm_bwd_dx: D=%d unsupported", D);
+    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, M, D,
+                       eps, dx);
+    DEVQA_LAUNCH_CHECK("layernorm_bwd_dx");
+    return DEVQA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// im2col for the patch-embedding conv: out[b*np + (py*G+px)][(c*P+ky)*P+kx] (bf16), zero pad
+// ------------------------------------------------------------------------------------------
+__global__ void im2col_kernel(const float* __restrict__ pix, int B, int S, int P, int Kpad, bf16_t* __restrict__ out) {
+    const int G = S / P, np = G * G, Kreal = 3 * P * P;
+    const int64_t total = (int64_t)B * np * Kpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % Kpad);
+        const int64_t rowi = i / Kpad;
+        float v = 0.f;
+        if (col < Kreal) {
+            const int p = (int)(rowi % np), b = (int)(rowi / np);
+            const int c = col / (P * P), rem = col % (P * P), ky = rem / P, kx = rem % P;
+            const int y = (p / G) * P + ky, x = (p % G) * P + kx;
+            v = pix[(((int64_t)b * 3 + c) * S + y) * S + x];
+        }
+        out[i] = f32_to_bf16(v);
+    }
+}
+extern "C" int devqa_im2col_patches(const float* pixels, int B, int S, int P, int Kpad, devqa_bf16* out, void* stream) {
+    DEVQA_CHECK_ARG(pixels && out, "im2col: null pointer");
+    if (B == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(B > 0 && S > 0 && P > 0 && S % P == 0 && Kpad >= 3 * P * P && Kpad % 8 == 0, "im2col: bad shape");
+    const int64_t total = (int64_t)B * (S / P) * (S / P) * Kpad;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pixels, B, S, P, Kpad, out);
+    DEVQA_LAUNCH_CHECK("im2col");
+    return DEVQA_OK;
+}
+
+__global__ void vit_assemble_kernel(const float* __restrict__ patches, const float* __restrict__ cls,
+                                    const float* __restrict__ pos, int B, int np, int D, float* __restrict__ out) {
+    const int nv = D >> 2;
+    const int64_t total = (int64_t)B * (np + 1) * nv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nv);
+        const int64_t r = i / nv;
+        const int t = (int)(r % (np + 1)), b = (int)(r / (np + 1));
+        float4 v = (t == 0) ? reinterpret_cast<const float4*>(cls)[c]
+                            : reinterpret_cast<const float4*>(patches + ((int64_t)b * np + (t - 1)) * D)[c];
+        const float4 p = reinterpret_cast<const float4*>(pos + (int64_t)t * D)[c];
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+extern "C" int devqa_vit_assemble(const float* patches, const float* cls, const float* pos, int B, int np, int D,
+                                  float* out, void* stream) {
+    DEVQA_CHECK_ARG(patches && cls && pos && out, "vit_assemble: null pointer");
+    if (B == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(B > 0 && np > 0 && D > 0 && D % 4 == 0, "vit_assemble: bad shape");
+    const int64_t total = (int64_t)B * (np + 1) * (D / 4);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, patches, cls, pos, B, np, D, out);
+    DEVQA_LAUNCH_CHECK("vit_assemble");
+    return DEVQA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// token embedding / image-token rows + OPT learned positions (offset 2)
+// ------------------------------------------------------------------------------------------
+__global__ void embed_rows_kernel(const int32_t* __restrict__ token, const int32_t* __restrict__ src_row,
+                                  const int32_t* __restrict__ pos, const bf16_t* __restrict__ embed,
+                                  const float* __restrict__ rows_f32, const bf16_t* __restrict__ pos_table, int R, int D,
+                                  int V, int n_rows_f32, int n_pos, float* __restrict__ out) {
+    const int nv = D >> 2;
+    const int64_t total = (int64_t)R * nv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nv), r = (int)(i / nv);
+        float4 v;
+        const int sr = src_row ? src_row[r] : -1;
+        if (sr >= 0) {
+            v = (sr < n_rows_f32) ? reinterpret_cast<const float4*>(rows_f32 + (int64_t)sr * D)[c]
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            int t = token[r];
+            t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+            const uint2 e = reinterpret_cast<const uint2*>(embed + (int64_t)t * D)[c];
+            v = make_float4(bf16_to_f32(e.x & 0xffff), bf16_to_f32(e.x >> 16), bf16_to_f32(e.y & 0xffff),
+                            bf16_to_f32(e.y >> 16));
+        }
+        int p = pos[r] + 2;
+        p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+        const uint2 e = reinterpret_cast<const uint2*>(pos_table + (int64_t)p * D)[c];
+        v.x += bf16_to_f32(e.x & 0xffff); v.y += bf16_to_f32(e.x >> 16);
+        v.z += bf16_to_f32(e.y & 0xffff); v.w += bf16_to_f32(e.y >> 16);
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+extern "C" int devqa_embed_rows(const int32_t* token, const int32_t* src_row, const int32_t* pos, const devqa_bf16* embed,
+                                const float* rows_f32, const devqa_bf16* pos_table, int R, int D, int V, int n_rows_f32,
+                                int n_pos, float* out, void* stream) {
+    DEVQA_CHECK_ARG(token && pos && embed && pos_table && out, "embed_rows: null pointer");
+    DEVQA_CHECK_ARG(!src_row || rows_f32 || n_rows_f32 == 0, "embed_rows: src_row given without rows_f32");
+    if (R == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(R > 0 && D > 0 && D % 4 == 0 && V > 0 && n_pos > 0, "embed_rows: bad shape");
+    const int64_t total = (int64_t)R * (D / 4);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, token, src_row, pos, embed,
+                       rows_f32, pos_table, R, D, V, n_rows_f32, n_pos, out);
+    DEVQA_LAUNCH_CHECK("embed_rows");
+    return DEVQA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ in, const int32_t* __restrict__ idx, int R, int nv,
+                                   T* __restrict__ out) {
+    const int64_t total = (int64_t)R * nv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nv), r = (int)(i / nv);
+        out[i] = in[(int64_t)idx[r] * nv + c];
+    }
+}
+extern "C" int devqa_gather_rows(const void* in, const int32_t* idx, int R, int D, int elem_bytes, void* out, void* stream) {
+    DEVQA_CHECK_ARG(in && idx && out, "gather_rows: null pointer");
+    DEVQA_CHECK_ARG(elem_bytes == 2 || elem_bytes == 4, "gather_rows: elem_bytes must be 2 or 4");
+    if (R == 0) return DEVQA_OK;
+    const int row_bytes = D * elem_bytes;
+    DEVQA_CHECK_SHAPE(R > 0 && D > 0 && row_bytes % 16 == 0, "gather_rows: row bytes must be a multiple of 16");
+    const int nv = row_bytes / 16;
+    const int64_t total = (int64_t)R * nv;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gather_rows_kernel<uint4>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(in), idx, R, nv, reinterpret_cast<uint4*>(out));
+    DEVQA_LAUNCH_CHECK("gather_rows");
+    return DEVQA_OK;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        uint2 p;
+        p.x = pack_bf16x2(v.x, v.y);
+        p.y = pack_bf16x2(v.z, v.w);
+        reinterpret_cast<uint2*>(out)[i] = p;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = f32_to_bf16(in[n4 * 4 + threadIdx.x]);
+}
+extern "C" int devqa_cast_f32_bf16(const float* in, devqa_bf16* out, int64_t n, void* stream) {
+    DEVQA_CHECK_ARG(in && out && n >= 0, "cast: bad args");
+    if (n == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE((((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "cast: misaligned");
+    const int64_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, (hipStream_t)stream, in, out, n4, n);
+    DEVQA_LAUNCH_CHECK("cast_f32_bf16");
+    return DEVQA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void delta_op_kernel(int mode, float* __restrict__ w, const float* __restrict__ w0, float* __restrict__ delta,
+                                int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        if (mode == 0) {
+            const float4 a = reinterpret_cast<const float4*>(w)[i], b = reinterpret_cast<const float4*>(w0)[i];
+            reinterpret_cast<float4*>(delta)[i] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+        } else if (mode == 1) {
+            float4 a = reinterpret_cast<float4*>(w)[i];
+            const float4 d = reinterpret_cast<const float4*>(delta)[i];
+            a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+            reinterpret_cast<float4*>(w)[i] = a;
+        } else {
+            reinterpret_cast<float4*>(w)[i] = reinterpret_cast<const float4*>(w0)[i];
+        }
+    }
+}
+extern "C" int devqa_delta_op(int mode, float* w, const float* w0, float* delta, int64_t n, void* stream) {
+    DEVQA_CHECK_ARG(mode >= 0 && mode <= 2 && w, "delta_op: bad args");
+    DEVQA_CHECK_ARG((mode == 1) ? (delta != nullptr) : (w0 != nullptr), "delta_op: missing operand");
+    DEVQA_CHECK_ARG(mode != 0 || delta, "delta_op: missing delta");
+    if (n == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(n > 0 && n % 4 == 0, "delta_op: n must be a multiple of 4");
+    const int64_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(delta_op_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode, w, w0, delta, n4);
+    DEVQA_LAUNCH_CHECK("delta_op");
+    return DEVQA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// FT loop control (one thread per edit)
+// ------------------------------------------------------------------------------------------
+__global__ void ft_step_control_kernel(const float* __restrict__ nll, const float* __restrict__ mask, int E, int Lmax,
+                                       int step, int max_steps, float floor_, int32_t* active, int32_t* do_update,
+                                       int32_t* n_steps, int32_t* adam_t, float* losses) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    if (!active[e]) {
+        do_update[e] = 0;
+        return;
+    }
+    float s = 0.f, c = 0.f;
+    for (int r = 0; r < Lmax; ++r) {
+        const float mk = mask[e * Lmax + r];
+        if (mk != 0.f) s += nll[e * Lmax + r] * mk;
+        c += mk;
+    }
+    const float loss = s / c;
+    losses[(int64_t)e * max_steps + step] = loss;
+    n_steps[e] = step + 1;
+    const bool upd = loss >= floor_;  // ft_vl.py:131 (NaN: no update, no break -- same as the reference)
+    do_update[e] = upd ? 1 : 0;
+    if (upd) adam_t[e] += 1;          // torch.optim.AdamW step counter (1-based t of this update)
+    if (loss < floor_) active[e] = 0;  // ft_vl.py:145-146: loop breaks after this step
+}
+extern "C" int devqa_ft_step_control(const float* nll, const float* mask, int E, int Lmax, int step, int max_steps,
+                                     float floor_, int32_t* active, int32_t* do_update, int32_t* n_steps, int32_t* adam_t,
+                                     float* losses, void* stream) {
+    DEVQA_CHECK_ARG(nll && mask && active && do_update && n_steps && adam_t && losses, "ft_step_control: null pointer");
+    if (E == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(E > 0 && Lmax > 0 && step >= 0 && step < max_steps, "ft_step_control: bad shape");
+    hipLaunchKernelGGL(ft_step_control_kernel, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, nll, mask, E, Lmax,
+                       step, max_steps, floor_, active, do_update, n_steps, adam_t, losses);
+    DEVQA_LAUNCH_CHECK("ft_step_control");
+    return DEVQA_OK;
+}

@@ -1,0 +1,266 @@
+"""ctypes binding of csrc/libdevqa_hip.so (C ABI: include/devqa.h).
+
+There is NO CPU fallback: if the library is missing or a call fails, this module raises.
+PyTorch is used only for device memory and streams (tensor.data_ptr(), current stream).
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdevqa_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+class DevqaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _sig(fn, argtypes, restype=c_int):
+    fn.argtypes = argtypes
+    fn.restype = restype
+
+
+def load():
+    """Load the shared library (idempotent). Raises DevqaError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DevqaError("libdevqa_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no CPU fallback for the product path)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    P, I, F, I64 = c_void_p, c_int, c_float, c_int64
+    _sig(L.devqa_last_error, [], ctypes.c_char_p)
+    _sig(L.devqa_abi_version, [])
+    _sig(L.devqa_gemm_bf16, [P, I64, P, I64, P, I, I, I, F, I, P, P, P, I64, P])
+    _sig(L.devqa_layernorm, [P, P, P, P, I, I, F, P, P, P])
+    _sig(L.devqa_attention, [P, I64, P, I64, P, I64, P, I64, P, I, I, I, I, F, I, P])
+    _sig(L.devqa_im2col_patches, [P, I, I, I, I, P, P])
+    _sig(L.devqa_vit_assemble, [P, P, P, I, I, I, P, P])
+    _sig(L.devqa_embed_rows, [P, P, P, P, P, P, I, I, I, I, I, P, P])
+    _sig(L.devqa_gather_rows, [P, P, I, I, I, P, P])
+    _sig(L.devqa_cast_f32_bf16, [P, P, I64, P])
+    _sig(L.devqa_vocab_rows, [P, I64, I, I, P, P, P, P, P, I64, P])
+    _sig(L.devqa_layernorm_bwd_dx, [P, P, P, I, I, F, P, P])
+    _sig(L.devqa_ft_adamw_step, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, P])
+    _sig(L.devqa_rows_matvec_f32, [P, I64, P, P, P, P, I, I, I, I, P])
+    _sig(L.devqa_delta_op, [I, P, P, P, I64, P])
+    _sig(L.devqa_ft_step_control, [P, P, I, I, I, I, F, P, P, P, P, P, P])
+    _sig(L.devqa_cosine_topk_workspace, [I, I, I], c_int64)
+    _sig(L.devqa_cosine_topk, [P, P, I, I, I, I, I, I, P, P, P, P])
+    _lib = L
+    return L
+
+
+EXPORTS = ["devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_layernorm", "devqa_attention",
+           "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
+           "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
+           "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk"]
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise DevqaError("%s failed (%d): %s" % (name, rc, load().devqa_last_error().decode()))
+
+
+def _p(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t, dtype, name):
+    if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
+        raise DevqaError("%s: expected contiguous cuda %s, got %s %s contiguous=%s" %
+                         (name, dtype, t.device, t.dtype, t.is_contiguous()))
+
+
+# ---------------------------------------------------------------------------------------------
+# thin typed wrappers (shape bookkeeping only; every FLOP happens in the library)
+# ---------------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, alpha=1.0, act=ACT_NONE, residual=None, out_bf16=None, out_f32=None, want="bf16"):
+    """C = epi(a @ w.T). a bf16 [M,K] (row stride may exceed K), w bf16 [N,K]."""
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_cuda and w.is_cuda
+    assert a.stride(-1) == 1 and w.stride(-1) == 1 and a.dim() == 2 and w.dim() == 2
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, (a.shape, w.shape)
+    if out_bf16 is None and out_f32 is None:
+        if want == "bf16":
+            out_bf16 = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+        elif want == "f32":
+            out_f32 = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        else:
+            out_bf16 = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+            out_f32 = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    ldc = N
+    for o in (out_bf16, out_f32, residual):
+        if o is not None:
+            assert o.shape == (M, N) and o.is_contiguous(), "gemm outputs/residual must be contiguous [M,N]"
+    if bias is not None:
+        _need(bias, torch.float32, "gemm bias")
+        assert bias.numel() == N
+    if residual is not None:
+        _need(residual, torch.float32, "gemm residual")
+    _chk(load().devqa_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), M, N, K, float(alpha), int(act),
+                                _p(residual), _p(out_bf16), _p(out_f32), ldc, _stream()), "devqa_gemm_bf16")
+    if out_bf16 is not None and out_f32 is not None:
+        return out_bf16, out_f32
+    return out_bf16 if out_bf16 is not None else out_f32
+
+
+def layernorm(x, gamma, beta, eps, add=None, want="bf16"):
+    _need(x, torch.float32, "layernorm x")
+    M, D = x.shape
+    ob = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if want in ("bf16", "both") else None
+    of = torch.empty((M, D), dtype=torch.float32, device=x.device) if want in ("f32", "both") else None
+    if add is not None:
+        _need(add, torch.float32, "layernorm add")
+        assert add.shape == x.shape
+    _chk(load().devqa_layernorm(_p(x), _p(add), _p(gamma), _p(beta), M, D, float(eps), _p(ob), _p(of), _stream()),
+         "devqa_layernorm")
+    if want == "both":
+        return ob, of
+    return ob if ob is not None else of
+
+
+def layernorm_bwd_dx(x, gamma, dy, eps):
+    _need(x, torch.float32, "ln_bwd x")
+    _need(dy, torch.float32, "ln_bwd dy")
+    M, D = x.shape
+    dx = torch.empty_like(x)
+    _chk(load().devqa_layernorm_bwd_dx(_p(x), _p(gamma), _p(dy), M, D, float(eps), _p(dx), _stream()),
+         "devqa_layernorm_bwd_dx")
+    return dx
+
+
+def attention(q, k, v, seq_desc, n_seq, max_q_len, H, dh, scale, causal, out=None):
+    """q,k,v: bf16 2-D views (rows x >=H*dh, unit inner stride). seq_desc int32 [n_seq,6] on device."""
+    for t in (q, k, v):
+        assert t.dtype == torch.bfloat16 and t.is_cuda and t.dim() == 2 and t.stride(1) == 1
+    assert seq_desc.dtype == torch.int32 and seq_desc.is_cuda and seq_desc.is_contiguous()
+    if out is None:
+        out = torch.empty((q.shape[0], H * dh), dtype=torch.bfloat16, device=q.device)
+    _chk(load().devqa_attention(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                                _p(seq_desc), int(n_seq), int(max_q_len), int(H), int(dh), float(scale), int(causal),
+                                _stream()), "devqa_attention")
+    return out
+
+
+def im2col_patches(pixels, P, Kpad):
+    _need(pixels, torch.float32, "im2col pixels")
+    B, C, S, S2 = pixels.shape
+    assert C == 3 and S == S2
+    out = torch.empty((B * (S // P) ** 2, Kpad), dtype=torch.bfloat16, device=pixels.device)
+    _chk(load().devqa_im2col_patches(_p(pixels), B, S, P, Kpad, _p(out), _stream()), "devqa_im2col_patches")
+    return out
+
+
+def vit_assemble(patches, cls, pos, B, np_, D):
+    _need(patches, torch.float32, "vit_assemble patches")
+    out = torch.empty((B * (np_ + 1), D), dtype=torch.float32, device=patches.device)
+    _chk(load().devqa_vit_assemble(_p(patches), _p(cls), _p(pos), B, np_, D, _p(out), _stream()), "devqa_vit_assemble")
+    return out
+
+
+def embed_rows(token, src_row, pos, embed, rows_f32, pos_table):
+    R = token.numel()
+    D = embed.shape[1]
+    out = torch.empty((R, D), dtype=torch.float32, device=embed.device)
+    n_rows = 0 if rows_f32 is None else rows_f32.shape[0]
+    _chk(load().devqa_embed_rows(_p(token), _p(src_row), _p(pos), _p(embed), _p(rows_f32), _p(pos_table), R, D,
+                                 embed.shape[0], n_rows, pos_table.shape[0], _p(out), _stream()), "devqa_embed_rows")
+    return out
+
+
+def gather_rows(x, idx):
+    assert x.is_contiguous() and x.dim() == 2 and idx.dtype == torch.int32
+    out = torch.empty((idx.numel(), x.shape[1]), dtype=x.dtype, device=x.device)
+    _chk(load().devqa_gather_rows(_p(x), _p(idx), idx.numel(), x.shape[1], x.element_size(), _p(out), _stream()),
+         "devqa_gather_rows")
+    return out
+
+
+def cast_f32_bf16(x, out=None):
+    _need(x, torch.float32, "cast in")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _chk(load().devqa_cast_f32_bf16(_p(x), _p(out), x.numel(), _stream()), "devqa_cast_f32_bf16")
+    return out
+
+
+def vocab_rows(logits, labels=None, coef=None, want_argmax=True, want_nll=False, want_dlogits=False):
+    _need(logits, torch.float32, "vocab_rows logits")
+    R, V = logits.shape
+    dev = logits.device
+    am = torch.empty((R,), dtype=torch.int32, device=dev) if want_argmax else None
+    nll = torch.empty((R,), dtype=torch.float32, device=dev) if want_nll else None
+    dl = torch.empty((R, V), dtype=torch.bfloat16, device=dev) if want_dlogits else None
+    _chk(load().devqa_vocab_rows(_p(logits), logits.stride(0), R, V, _p(labels), _p(coef), _p(am), _p(nll), _p(dl), V,
+                                 _stream()), "devqa_vocab_rows")
+    return am, nll, dl
+
+
+def ft_adamw_step(w, m, v, w0, a, dy, y, do_update, adam_t, lr, beta1, beta2, eps, wd, clamp_eps):
+    E, Dout, Din = w.shape
+    Lmax = a.shape[1]
+    for t, n in ((w, "w"), (m, "m"), (v, "v"), (w0, "w0"), (a, "a"), (dy, "dy"), (y, "y")):
+        _need(t, torch.float32, "ft_adamw_step " + n)
+    assert a.shape == (E, Lmax, Din) and dy.shape == (E, Lmax, Dout) and y.shape == (E, Lmax, Dout)
+    assert w0.shape == (Dout, Din) and m.shape == w.shape and v.shape == w.shape
+    assert do_update.dtype == torch.int32 and adam_t.dtype == torch.int32
+    _chk(load().devqa_ft_adamw_step(_p(w), _p(m), _p(v), _p(w0), _p(a), _p(dy), _p(y), _p(do_update), _p(adam_t), E, Lmax,
+                                    Dout, Din, float(lr), float(beta1), float(beta2), float(eps), float(wd),
+                                    float(clamp_eps), _stream()), "devqa_ft_adamw_step")
+
+
+def rows_matvec(w, a, bias=None, resid=None, shared=False):
+    """y[e,l,:] = W_e . a[e,l,:] (+bias +resid). w fp32 [E,Dout,Din] or shared [Dout,Din]; a fp32 [E,L,Din]."""
+    _need(w, torch.float32, "rows_matvec w")
+    _need(a, torch.float32, "rows_matvec a")
+    E, L, Din = a.shape
+    Dout = w.shape[-2]
+    assert w.shape[-1] == Din
+    stride_e = 0 if (shared or w.dim() == 2) else Dout * Din
+    y = torch.empty((E, L, Dout), dtype=torch.float32, device=a.device)
+    if resid is not None:
+        _need(resid, torch.float32, "rows_matvec resid")
+        assert resid.shape == y.shape
+    _chk(load().devqa_rows_matvec_f32(_p(w), stride_e, _p(a), _p(bias), _p(resid), _p(y), E, L, Dout, Din, _stream()),
+         "devqa_rows_matvec_f32")
+    return y
+
+
+def delta_op(mode, w, w0=None, delta=None):
+    _chk(load().devqa_delta_op(int(mode), _p(w), _p(w0), _p(delta), w.numel(), _stream()), "devqa_delta_op")
+
+
+def ft_step_control(nll, mask, step, max_steps, floor, active, do_update, n_steps, adam_t, losses):
+    E, Lmax = mask.shape
+    _chk(load().devqa_ft_step_control(_p(nll), _p(mask), E, Lmax, int(step), int(max_steps), float(floor), _p(active),
+                                      _p(do_update), _p(n_steps), _p(adam_t), _p(losses), _stream()),
+         "devqa_ft_step_control")
+
+
+def cosine_topk(corpus, queries, k, normalize_corpus=True, normalize_queries=True):
+    _need(corpus, torch.float32, "cosine_topk corpus")
+    _need(queries, torch.float32, "cosine_topk queries")
+    N, D = corpus.shape
+    Q = queries.shape[0]
+    ws_bytes = load().devqa_cosine_topk_workspace(N, Q, k)
+    ws = torch.empty((ws_bytes + 256,), dtype=torch.uint8, device=corpus.device)
+    off = (-ws.data_ptr()) % 256
+    idx = torch.empty((Q, k), dtype=torch.int64, device=corpus.device)
+    sc = torch.empty((Q, k), dtype=torch.float32, device=corpus.device)
+    _chk(load().devqa_cosine_topk(_p(corpus), _p(queries), N, Q, D, int(k), int(normalize_corpus), int(normalize_queries),
+                                  _p(idx), _p(sc), c_void_p(ws.data_ptr() + off), _stream()), "devqa_cosine_topk")
+    return idx, sc

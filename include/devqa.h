@@ -1,0 +1,187 @@
+/*
+ * devqa.h -- C ABI of libdevqa_hip.so: the MI355X (gfx950) kernels behind the
+ * DE-VQA edit-then-evaluate hot path (BLIP-2 + FT_VL).
+ *
+ * The reference (sev777/DE-VQA) is pure Python with no FFI of its own; every
+ * entry point below replaces a PyTorch op sequence that the reference reaches
+ * through the call site cited on it ("R/" = /root/reference/DE-VQA/).  The host
+ * side (de-vqa_amd/, Python, mirrors the reference's plugin API) binds these
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative DEVQA_E_* code; it never
+ *     throws and never synchronises the device; devqa_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - tensors are raw DEVICE pointers, row-major, caller-owned; the library
+ *     allocates nothing.  bf16 is passed as uint16_t bit patterns.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - shapes are checked on the host before any launch (a kernel is never
+ *     launched with operands its indexing does not cover).
+ */
+#ifndef DEVQA_H_
+#define DEVQA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEVQA_OK 0
+#define DEVQA_E_ARG (-1)   /* null pointer / bad flag */
+#define DEVQA_E_SHAPE (-2) /* dimension outside what the kernel supports */
+#define DEVQA_E_HIP (-3)   /* launch failed */
+
+typedef uint16_t devqa_bf16;
+
+const char* devqa_last_error(void);
+int devqa_abi_version(void);
+
+/* ---- GEMM (K2, K3, K4, K5, K7, K8, K10: every nn.Linear on the path) --------------------
+ * C[M,N] = epilogue( A[M,K] . W[N,K]^T ),  A/W bf16 K-contiguous (nn.Linear layout),
+ * fp32 accumulate on MFMA.  Replaces F.linear at e.g. HF Blip2Attention.qkv/projection,
+ * Blip2MLP, QFormer dense layers, OPT q/k/v/out_proj/fc1/fc2 and lm_head, reached from
+ * R/editor/vllms_for_edit/blip2/blip2.py:25-31,35-45,69-74.
+ *   bias      : fp32 [N] or NULL
+ *   alpha     : result = (acc + bias) * alpha   (OPT q-scaling, modeling_opt q_proj*scaling)
+ *   act       : DEVQA_ACT_*
+ *   residual  : fp32 [M,ldc] or NULL, added after the activation (may alias out_f32)
+ *   out_bf16 / out_f32 : at least one non-NULL; both are written when both are given
+ * Requirements: K % 8 == 0, lda/ldw % 8 == 0, N % 4 == 0.
+ */
+#define DEVQA_ACT_NONE 0
+#define DEVQA_ACT_RELU 1
+#define DEVQA_ACT_GELU 2 /* exact erf GELU (HF "gelu") */
+int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64_t ldw, const float* bias,
+                    int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
+                    float* out_f32, int64_t ldc, void* stream);
+
+/* ---- LayerNorm (every nn.LayerNorm on the path) --------------------------------------------
+ * y = (x - mean) * rsqrt(var + eps) * gamma + beta over the last dim, fp32 statistics.
+ * x fp32 [M,D]; optional add: x := x + add (fp32 [M,D], BERT-style post-LN residual,
+ * HF Blip2QFormerSelfOutput/Output); outputs bf16 and/or fp32.  D % 4 == 0, D <= 16384.
+ */
+int devqa_layernorm(const float* x, const float* add, const float* gamma, const float* beta, int M, int D, float eps,
+                    devqa_bf16* out_bf16, float* out_f32, void* stream);
+
+/* ---- attention (K3 ViT self-attn, K4 Q-Former self/cross-attn, K7 OPT causal attn) ----------
+ * Packed varlen softmax attention: for sequence s (0..n_seq), query rows
+ * [q_start[s], q_start[s]+q_len[s]) attend to
+ *   - a fully visible key range  [kp_start[s], kp_start[s]+kp_len[s])   (shared image-token
+ *     prefix for OPT probes; the whole key set for ViT / Q-Former), then
+ *   - an own key range [ko_start[s], ko_start[s]+ko_len[s]) that is causal when `causal` != 0
+ *     (query i sees own keys 0..i+ko_len-q_len; OPT) or fully visible otherwise.
+ * q/k/v bf16 rows with row strides ldq/ldk/ldv (elements) and head h at column h*dh;
+ * scores = (q.k) * scale; softmax in fp32; out bf16 [rows, H*dh] row stride ldo.
+ * seq_desc: int32 [n_seq][6] = {q_start,q_len,kp_start,kp_len,ko_start,ko_len} (device).
+ * max_q_len is the host-known max of q_len (grid sizing).  dh % 8 == 0, dh <= 128.
+ * Replaces eager/sdpa attention in HF Blip2Attention, Blip2QFormerMultiHeadAttention and
+ * OPTAttention (same call sites as above).
+ */
+int devqa_attention(const devqa_bf16* q, int64_t ldq, const devqa_bf16* k, int64_t ldk, const devqa_bf16* v,
+                    int64_t ldv, devqa_bf16* out, int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len,
+                    int H, int dh, float scale, int causal, void* stream);
+
+/* ---- K2 patch-embed staging ---------------------------------------------------------------
+ * im2col for Conv2d(3->D, k=P, s=P): pixels fp32 [B,3,S,S] -> bf16 [B*(S/P)^2, Kpad] with
+ * column (c*P+py)*P+px, zero padded to Kpad (Kpad % 8 == 0).  HF Blip2VisionEmbeddings,
+ * reached from blip2.py:25-31.
+ */
+int devqa_im2col_patches(const float* pixels, int B, int S, int P, int Kpad, devqa_bf16* out, void* stream);
+/* x[b,0,:] = cls + pos[0]; x[b,1+p,:] = patches[b*np+p,:] + pos[1+p]  (fp32 [B,np+1,D]) */
+int devqa_vit_assemble(const float* patches, const float* cls, const float* pos, int B, int np, int D, float* out,
+                       void* stream);
+
+/* ---- K6 token embedding + OPT learned positions ---------------------------------------------
+ * out[r,:] = (src_row[r] >= 0 ? table_f32rows[src_row[r]] : embed[token[r]]) + pos_table[pos[r]+2]
+ * i.e. rows are either gathered from a bf16 embedding table [V,D] by token id or copied from an
+ * fp32 row buffer (the projected image tokens), then the OPT positional embedding (offset 2,
+ * HF OPTLearnedPositionalEmbedding) is added.  out fp32 [R,D].  blip2.py:45-52,63; OPTDecoder.
+ */
+int devqa_embed_rows(const int32_t* token, const int32_t* src_row, const int32_t* pos, const devqa_bf16* embed,
+                     const float* rows_f32, const devqa_bf16* pos_table, int R, int D, int V, int n_rows_f32,
+                     int n_pos, float* out, void* stream);
+
+/* gather rows: out[r,:] = in[idx[r],:] (fp32 or bf16 by elem_bytes 4/2) */
+int devqa_gather_rows(const void* in, const int32_t* idx, int R, int D, int elem_bytes, void* out, void* stream);
+/* fp32 -> bf16 (round to nearest even), n elements */
+int devqa_cast_f32_bf16(const float* in, devqa_bf16* out, int64_t n, void* stream);
+
+/* ---- K9/K14 rows over the vocabulary ------------------------------------------------------
+ * For each logits row r (fp32 [R,V], row stride ldl): argmax (first max wins, as torch.argmax),
+ * and when labels != NULL: nll[r] = logsumexp(row) - row[label[r]];  when dlogits != NULL:
+ * dlogits[r,:] = (softmax(row) - onehot(label[r])) * coef[r]  (bf16 [R,V]; coef = mask/mask.sum,
+ * the gradient of R/editor/vllm_editors/ft_vl/ft_vl.py:191-199 w.r.t. the logits).
+ * Replaces log_softmax+gather (ft_vl.py:193-195) and softmax+argmax
+ * (R/evaluation/vllm_editor_eval.py:111,147).
+ */
+int devqa_vocab_rows(const float* logits, int64_t ldl, int R, int V, const int32_t* labels, const float* coef,
+                     int32_t* argmax_out, float* nll_out, devqa_bf16* dlogits, int64_t ldd, void* stream);
+
+/* LayerNorm backward w.r.t. the input only: dx from dy, for rows x fp32 [M,D] (gamma fp32 [D]). */
+int devqa_layernorm_bwd_dx(const float* x, const float* gamma, const float* dy, int M, int D, float eps, float* dx,
+                           void* stream);
+
+/* ---- K10/K11/K12: fused FT_VL inner step on the edited matrix ---------------------------------
+ * One launch per optimiser step, batched over E concurrent edits that each own a private
+ * fp32 copy of the edited matrix W_e [Dout,Din] and AdamW moments m_e, v_e:
+ *   g_e      = sum_{r<L} dy[e,r,:]^T (x) a[e,r,:]            (rank-L gradient, never materialised)
+ *   m,v,w    = torch.optim.AdamW update (decoupled weight decay; bias correction with
+ *              step t = adam_t[e]), optional L-inf clamp of w around w0 (norm_constraint)
+ *   y[e,r,:] = W_e_new . a[e,r,:]                           (next step's fc2 output rows, no bias)
+ * Edits with do_update[e] == 0 are skipped (their state and y are left unchanged).  On the first
+ * update (adam_t[e]==1) w is read from w0 (shared, read-only) and m,v are taken as zero, so no
+ * initialisation pass is needed.  Algorithmic HBM traffic per edit-step: read w,m,v + write
+ * w,m,v = 6*4*Dout*Din bytes (the reference additionally round-trips g: 7 tensors, 734 MB at
+ * 2560x10240).
+ * Replaces loss.backward() onto the weight + opt.step() + clamp (ft_vl.py:131-141).
+ *   w,m,v : fp32 [E][Dout][Din]      w0 : fp32 [Dout][Din]
+ *   a     : fp32 [E][Lmax][Din]      dy : fp32 [E][Lmax][Dout]     y : fp32 [E][Lmax][Dout]
+ *   do_update, adam_t : int32 [E] (device, from devqa_ft_step_control)
+ *   clamp_eps < 0 disables the clamp.  1 <= Lmax <= 8, Din % 4 == 0.
+ */
+int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
+                        const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
+                        void* stream);
+
+/* y[e,r,:] = W[e or shared] . a[e,r,:] (+ bias) (+ resid[e,r,:]) : fc2 on a few cached rows with an
+ * fp32 matrix (pre-/post-edit probe tails, step-0 forward).  w_stride_e = 0 shares one matrix. */
+int devqa_rows_matvec_f32(const float* w, int64_t w_stride_e, const float* a, const float* bias, const float* resid,
+                          float* y, int E, int L, int Dout, int Din, void* stream);
+
+/* ---- K13 delta / restore / apply ---------------------------------------------------------
+ * mode 0: delta = w - w0            (ft_vl.py:148)
+ * mode 1: w += delta                (ft_vl.py:60-61)
+ * mode 2: w = w0                    (ft_vl.py:151-153, :44-45)
+ */
+int devqa_delta_op(int mode, float* w, const float* w0, float* delta, int64_t n, void* stream);
+
+/* ---- FT loop control on device (ft_vl.py:125-133,145-146) ------------------------------------
+ * For every edit e with active[e] != 0:
+ *   loss = sum_r nll[e,r]*mask[e,r] / sum_r mask[e,r];  losses[e][step] = loss;  n_steps[e] = step+1;
+ *   do_update[e] = (loss >= floor); if so adam_t[e] += 1 (the 1-based AdamW step index);
+ *   if (loss < floor) active[e] = 0   (the reference skips backward/step below the floor, then breaks).
+ * Inactive edits get do_update[e] = 0.  int32/fp32 device arrays of length E (losses: [E][max_steps]).
+ */
+int devqa_ft_step_control(const float* nll, const float* mask, int E, int Lmax, int step, int max_steps, float floor,
+                          int32_t* active, int32_t* do_update, int32_t* n_steps, int32_t* adam_t, float* losses,
+                          void* stream);
+
+/* ---- K19 cosine top-k (dynamic-eval retrieval / IKE) ----------------------------------------
+ * scores = normalise?(Q) . normalise?(C)^T ; per query the k best corpus ids sorted by
+ * descending score, ties -> lowest id.  fp32 scan of the corpus (HBM-bound: N*D*4 bytes per
+ * query batch) keeps k+8 candidates per query which are re-scored in fp64 for exact ordering.
+ * corpus fp32 [N,D], queries fp32 [Q,D]; workspace bytes from devqa_cosine_topk_workspace.
+ * Replaces util.normalize_embeddings + util.semantic_search(dot_score)
+ * (R/dataset/vllm.py:65-70,104,117; R/easyeditor/models/ike/ike_main.py:193-202).
+ * k <= 32, D % 4 == 0, D <= 1024.
+ */
+int64_t devqa_cosine_topk_workspace(int N, int Q, int k);
+int devqa_cosine_topk(const float* corpus, const float* queries, int N, int Q, int D, int k, int normalize_corpus,
+                      int normalize_queries, int64_t* out_idx, float* out_score, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEVQA_H_ */

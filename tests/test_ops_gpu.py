@@ -1,0 +1,306 @@
+"""Op-level parity of every C-ABI entry point against plain fp32 PyTorch (CPU) on the same
+(bf16-rounded) inputs.  Integer outputs (argmax, top-k ids) must match exactly; floating point
+tolerances are written per test."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import devqa_amd  # noqa: F401
+    from devqa_amd import lib
+    lib.load()
+    return lib
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def bf(t):  # round to bf16 and back (fp32 CPU reference sees the same operand values)
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("M,N,K,act,res,alpha", [
+    (257, 4224, 1408, 0, False, 1.0),
+    (1028, 6144, 1408, 2, False, 1.0),
+    (48, 2560, 2560, 0, True, 1.0),
+    (48, 2560, 2560, 0, False, 80 ** -0.5),
+    (3, 50272, 2560, 0, False, 1.0),
+    (130, 136, 40, 1, True, 1.0),
+    (33, 48, 608, 0, False, 1.0),
+    (64, 10240, 2560, 1, False, 1.0),
+    (1000, 2560, 10240, 0, True, 1.0),
+])
+def test_gemm(L, M, N, K, act, res, alpha):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if res else None
+    ref = (a @ w.T + b) * alpha
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + r
+    ob, of = L.gemm(dev(a).to(torch.bfloat16), dev(w).to(torch.bfloat16), dev(b), alpha, act,
+                    dev(r) if res else None, want="both")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(of.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-4)
+    np.testing.assert_allclose(ob.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=1e-2)
+
+
+def test_gemm_strided_a_and_inplace_residual(L):
+    g = torch.Generator().manual_seed(5)
+    big = bf(torch.randn(100, 3 * 64, generator=g))
+    w = bf(torch.randn(96, 64, generator=g))
+    a_view = dev(big).to(torch.bfloat16)[:, 64:128]  # row stride 192, unit inner stride
+    resid = dev(torch.randn(100, 96, generator=g))
+    ref = big[:, 64:128] @ w.T + resid.cpu()
+    L.gemm(a_view, dev(w).to(torch.bfloat16), residual=resid, out_f32=resid)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(resid.cpu().numpy(), ref.numpy(), atol=1e-4, rtol=1e-4)
+
+
+def test_gemm_rejects_bad_shapes(L):
+    a = torch.zeros(4, 12, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(8, 12, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(L.DevqaError):
+        L.gemm(a, w)  # K % 8 != 0
+
+
+@pytest.mark.parametrize("M,D,eps", [(257, 1408, 1e-6), (32, 768, 1e-12), (48, 2560, 1e-5), (5, 40, 1e-5)])
+def test_layernorm_fwd_bwd(L, M, D, eps):
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(M, D, generator=g) * 3 + 1
+    add = torch.randn(M, D, generator=g)
+    gamma = 1 + 0.1 * torch.randn(D, generator=g)
+    beta = 0.1 * torch.randn(D, generator=g)
+    ref = torch.nn.functional.layer_norm(x + add, (D,), gamma, beta, eps)
+    ob, of = L.layernorm(dev(x), dev(gamma), dev(beta), eps, add=dev(add), want="both")
+    np.testing.assert_allclose(of.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(ob.float().cpu().numpy(), ref.numpy(), atol=3e-2, rtol=1e-2)
+    xr = x.clone().requires_grad_(True)
+    dy = torch.randn(M, D, generator=g)
+    torch.nn.functional.layer_norm(xr, (D,), gamma, beta, eps).backward(dy)
+    dx = L.layernorm_bwd_dx(dev(x), dev(gamma), dev(dy), eps)
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), atol=2e-5, rtol=1e-4)
+
+
+def _ref_attention(q, k, v, desc, H, dh, scale, causal):
+    out = torch.zeros(q.shape[0], H * dh)
+    for (qs, ql, kps, kpl, kos, kol) in desc:
+        for h in range(H):
+            qq = q[qs:qs + ql, h * dh:(h + 1) * dh]
+            kk = torch.cat([k[kps:kps + kpl, h * dh:(h + 1) * dh], k[kos:kos + kol, h * dh:(h + 1) * dh]])
+            vv = torch.cat([v[kps:kps + kpl, h * dh:(h + 1) * dh], v[kos:kos + kol, h * dh:(h + 1) * dh]])
+            s = (qq @ kk.T) * scale
+            if causal:
+                qi = torch.arange(ql)[:, None] + (kol - ql)
+                kj = torch.arange(kol)[None, :]
+                mask = torch.cat([torch.ones(ql, kpl, dtype=torch.bool), kj <= qi], 1)
+                s = s.masked_fill(~mask, float("-inf"))
+            out[qs:qs + ql, h * dh:(h + 1) * dh] = torch.softmax(s, -1) @ vv
+    return out
+
+
+@pytest.mark.parametrize("name", ["vit", "qformer_cross", "opt_causal", "opt_prefix", "tiny_heads"])
+def test_attention(L, name):
+    g = torch.Generator().manual_seed(11)
+    if name == "vit":  # 2 images x 257 tokens, fused qkv buffer
+        H, dh, n = 16, 88, 257
+        qkv = bf(torch.randn(2 * n, 3 * H * dh, generator=g))
+        q, k, v = qkv[:, :H * dh], qkv[:, H * dh:2 * H * dh], qkv[:, 2 * H * dh:]
+        desc = [(0, n, 0, n, 0, 0), (n, n, n, n, 0, 0)]
+        causal, scale = 0, dh ** -0.5
+        dq = dev(qkv).to(torch.bfloat16)
+        views = (dq[:, :H * dh], dq[:, H * dh:2 * H * dh], dq[:, 2 * H * dh:])
+    else:
+        if name == "qformer_cross":
+            H, dh = 12, 64
+            q = bf(torch.randn(64, H * dh, generator=g))
+            k = bf(torch.randn(514, H * dh, generator=g))
+            v = bf(torch.randn(514, H * dh, generator=g))
+            desc = [(0, 32, 0, 257, 0, 0), (32, 32, 257, 257, 0, 0)]
+            causal, scale = 0, dh ** -0.5
+        elif name == "opt_causal":
+            H, dh = 32, 80
+            T = [48, 17, 70]
+            tot = sum(T)
+            q = bf(torch.randn(tot, H * dh, generator=g))
+            k = bf(torch.randn(tot, H * dh, generator=g))
+            v = bf(torch.randn(tot, H * dh, generator=g))
+            st = np.cumsum([0] + T)
+            desc = [(int(st[i]), T[i], 0, 0, int(st[i]), T[i]) for i in range(3)]
+            causal, scale = 1, 1.0
+        elif name == "opt_prefix":  # prefix seq (32 rows) + two text seqs attending to it
+            H, dh = 32, 80
+            q = bf(torch.randn(32 + 16 + 21, H * dh, generator=g))
+            k = bf(torch.randn(32 + 16 + 21, H * dh, generator=g))
+            v = bf(torch.randn(32 + 16 + 21, H * dh, generator=g))
+            desc = [(0, 32, 0, 0, 0, 32), (32, 16, 0, 32, 32, 16), (48, 21, 0, 32, 48, 21)]
+            causal, scale = 1, 1.0
+        else:
+            H, dh = 5, 8
+            q = bf(torch.randn(29, H * dh, generator=g))
+            k = bf(torch.randn(29, H * dh, generator=g))
+            v = bf(torch.randn(29, H * dh, generator=g))
+            desc = [(0, 29, 0, 0, 0, 29)]
+            causal, scale = 1, 0.7
+        views = tuple(dev(t).to(torch.bfloat16) for t in (q, k, v))
+    ref = _ref_attention(q, k, v, desc, H, dh, scale, causal)
+    d = torch.tensor(desc, dtype=torch.int32, device="cuda")
+    out = L.attention(views[0], views[1], views[2], d, len(desc), max(x[1] for x in desc), H, dh, scale, causal)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=2e-2)
+
+
+def test_patch_embed_and_assemble(L):
+    g = torch.Generator().manual_seed(2)
+    B, S, P, D = 2, 28, 14, 48
+    pix = torch.randn(B, 3, S, S, generator=g)
+    w = bf(torch.randn(D, 3, P, P, generator=g) * 0.05)
+    b = torch.randn(D, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(bf(pix), w, b, stride=P).flatten(2).transpose(1, 2)
+    Kreal, Kpad = 3 * P * P, ((3 * P * P + 31) // 32) * 32
+    wp = torch.zeros(D, Kpad)
+    wp[:, :Kreal] = w.reshape(D, -1)
+    cols = L.im2col_patches(dev(pix), P, Kpad)
+    out = L.gemm(cols, dev(wp).to(torch.bfloat16), dev(b), want="f32")
+    np.testing.assert_allclose(out.cpu().numpy().reshape(B, -1, D), ref.numpy(), atol=1e-4, rtol=1e-4)
+    cls = torch.randn(D, generator=g)
+    pos = torch.randn(5, D, generator=g)
+    x = L.vit_assemble(out, dev(cls), dev(pos), B, 4, D).cpu().reshape(B, 5, D)
+    refx = torch.cat([cls.expand(B, 1, D), ref], 1) + pos
+    np.testing.assert_allclose(x.numpy(), refx.numpy(), atol=1e-4, rtol=1e-4)
+
+
+def test_embed_rows_and_gather(L):
+    g = torch.Generator().manual_seed(4)
+    V, D, npos = 640, 40, 130
+    emb = bf(torch.randn(V, D, generator=g))
+    post = bf(torch.randn(npos, D, generator=g))
+    img = torch.randn(8, D, generator=g)
+    token = torch.tensor([0] * 8 + [2, 17, 639, 5], dtype=torch.int32)
+    src = torch.tensor(list(range(8)) + [-1] * 4, dtype=torch.int32)
+    pos = torch.arange(12, dtype=torch.int32)
+    out = L.embed_rows(dev(token), dev(src), dev(pos), dev(emb).to(torch.bfloat16), dev(img), dev(post).to(torch.bfloat16))
+    ref = torch.cat([img, emb[token[8:].long()]]) + post[pos.long() + 2]
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-6)
+    idx = torch.tensor([3, 0, 11, 3], dtype=torch.int32)
+    got = L.gather_rows(out, dev(idx))
+    np.testing.assert_array_equal(got.cpu().numpy(), out.cpu().numpy()[idx.numpy()])
+    c = L.cast_f32_bf16(out)
+    np.testing.assert_array_equal(c.float().cpu().numpy(), out.cpu().to(torch.bfloat16).float().numpy())
+
+
+@pytest.mark.parametrize("R,V", [(7, 50272), (3, 640), (2, 1001 * 4)])
+def test_vocab_rows(L, R, V):
+    g = torch.Generator().manual_seed(V)
+    logits = torch.randn(R, V, generator=g) * 4
+    logits[0, 5] = logits[0, 900 % V] = logits[0].max() + 1  # tie -> first index wins
+    labels = torch.randint(0, V, (R,), generator=g).to(torch.int32)
+    coef = torch.rand(R, generator=g)
+    am, nll, dl = L.vocab_rows(dev(logits), dev(labels), dev(coef), True, True, True)
+    np.testing.assert_array_equal(am.cpu().numpy(), logits.argmax(-1).numpy())
+    lp = torch.log_softmax(logits, -1)
+    ref_nll = -lp.gather(-1, labels.long()[:, None])[:, 0]
+    np.testing.assert_allclose(nll.cpu().numpy(), ref_nll.numpy(), atol=2e-4, rtol=1e-5)
+    ref_dl = torch.softmax(logits, -1)
+    ref_dl[torch.arange(R), labels.long()] -= 1
+    ref_dl *= coef[:, None]
+    np.testing.assert_allclose(dl.float().cpu().numpy(), ref_dl.numpy(), atol=1e-5, rtol=1e-2)
+
+
+@pytest.mark.parametrize("Lmax,wd,clamp", [(1, 0.0, -1.0), (3, 0.0, -1.0), (2, 0.1, -1.0), (3, 0.0, 2.5e-3), (6, 0.0, -1.0)])
+def test_ft_adamw_step_matches_torch_adamw(L, Lmax, wd, clamp):
+    g = torch.Generator().manual_seed(Lmax)
+    E, Dout, Din = 3, 40, 80
+    lr = 1e-3
+    w0 = torch.randn(Dout, Din, generator=g) * 0.05
+    a = torch.relu(torch.randn(E, Lmax, Din, generator=g))
+    w = torch.zeros(E, Dout, Din, device="cuda")
+    m = torch.zeros_like(w)
+    v = torch.zeros_like(w)
+    y = torch.zeros(E, Lmax, Dout, device="cuda")
+    do_update = torch.tensor([1, 0, 1], dtype=torch.int32, device="cuda")  # edit 1 never updates
+    adam_t = torch.zeros(E, dtype=torch.int32, device="cuda")
+    params = [w0.clone().requires_grad_(True) for _ in range(E)]
+    opts = [torch.optim.AdamW([p], lr=lr, weight_decay=wd) for p in params]
+    for step in range(4):
+        dy = torch.randn(E, Lmax, Dout, generator=g) * 0.1
+        adam_t += do_update
+        L.ft_adamw_step(w, m, v, dev(w0), dev(a), dev(dy), y, do_update, adam_t, lr, 0.9, 0.999, 1e-8, wd, clamp)
+        for e in range(E):
+            if int(do_update[e]) == 0:
+                continue
+            params[e].grad = torch.einsum("lo,li->oi", dy[e], a[e])
+            opts[e].step()
+            if clamp >= 0:
+                with torch.no_grad():
+                    params[e][...] = torch.clamp(params[e], w0 - clamp, w0 + clamp)
+        torch.cuda.synchronize()
+        for e in (0, 2):
+            np.testing.assert_allclose(w[e].cpu().numpy(), params[e].detach().numpy(), atol=2e-6, rtol=1e-5)
+            ref_y = a[e] @ params[e].detach().T
+            np.testing.assert_allclose(y[e].cpu().numpy(), ref_y.numpy(), atol=1e-4, rtol=1e-4)
+    assert float(y[1].abs().sum()) == 0.0  # inactive edit untouched
+
+
+def test_rows_matvec_delta_and_control(L):
+    g = torch.Generator().manual_seed(9)
+    E, Lr, Dout, Din = 2, 5, 40, 80
+    w = torch.randn(E, Dout, Din, generator=g)
+    a = torch.randn(E, Lr, Din, generator=g)
+    b = torch.randn(Dout, generator=g)
+    r = torch.randn(E, Lr, Dout, generator=g)
+    y = L.rows_matvec(dev(w), dev(a), dev(b), dev(r))
+    ref = torch.einsum("eoi,eli->elo", w, a) + b + r
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=1e-4, rtol=1e-4)
+    y2 = L.rows_matvec(dev(w[0]), dev(a), shared=True)
+    np.testing.assert_allclose(y2.cpu().numpy(), torch.einsum("oi,eli->elo", w[0], a).numpy(), atol=1e-4, rtol=1e-4)
+    # delta ops
+    w0 = dev(w[0].contiguous())
+    wc = dev(w[1].contiguous())
+    d = torch.empty_like(wc)
+    L.delta_op(0, wc, w0, d)
+    np.testing.assert_array_equal(d.cpu().numpy(), (w[1] - w[0]).numpy())
+    L.delta_op(2, wc, w0, None)
+    np.testing.assert_array_equal(wc.cpu().numpy(), w[0].numpy())
+    L.delta_op(1, wc, None, d)
+    np.testing.assert_array_equal(wc.cpu().numpy(), (w[0] + (w[1] - w[0])).numpy())
+    # loop control
+    nll = dev(torch.tensor([[2.0, 4.0, 9.0], [0.004, 0.006, 9.0], [1.0, 1.0, 1.0]]))
+    mask = dev(torch.tensor([[1.0, 1.0, 0.0], [1.0, 1.0, 0.0], [1.0, 0.0, 0.0]]))
+    active = torch.tensor([1, 1, 0], dtype=torch.int32, device="cuda")
+    do_update = torch.zeros(3, dtype=torch.int32, device="cuda")
+    n_steps = torch.zeros(3, dtype=torch.int32, device="cuda")
+    adam_t = torch.zeros(3, dtype=torch.int32, device="cuda")
+    losses = torch.zeros(3, 25, device="cuda")
+    L.ft_step_control(nll, mask, 0, 25, 1e-2, active, do_update, n_steps, adam_t, losses)
+    assert active.tolist() == [1, 0, 0] and do_update.tolist() == [1, 0, 0]
+    assert n_steps.tolist() == [1, 1, 0] and adam_t.tolist() == [1, 0, 0]
+    np.testing.assert_allclose(losses[:, 0].cpu().numpy(), [3.0, 0.005, 0.0], rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,Q,D,k", [(15000, 100, 384, 5), (19035, 7, 384, 32), (300, 3, 64, 5)])
+def test_cosine_topk_exact_indices(L, N, Q, D, k):
+    from oracle import devqa_oracle as O
+    rng = np.random.default_rng(N + Q)
+    c = rng.standard_normal((N, D)).astype(np.float32)
+    q = rng.standard_normal((Q, D)).astype(np.float32)
+    q[0] = c[17]  # exact hit
+    c[41] = c[17]  # duplicate row: tie -> lowest id first
+    ridx, rsc = O.cosine_topk(c, q, k)
+    idx, sc = L.cosine_topk(dev(torch.from_numpy(c)), dev(torch.from_numpy(q)), k)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_allclose(sc.cpu().numpy(), rsc, atol=1e-6)
+    assert idx[0, 0].item() == 17 and idx[0, 1].item() == 41
+    # raw dot score (no normalisation), as semantic_search(dot_score) on pre-normalised data
+    ridx2, _ = O.cosine_topk(c, q, k, False, False)
+    idx2, _ = L.cosine_topk(dev(torch.from_numpy(c)), dev(torch.from_numpy(q)), k, False, False)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), ridx2)

@@ -108,7 +108,7 @@ REALDIM = dict(
 )
 
 
-def build_model(spec, seed):
+def build_model(spec, seed, style="unit"):
     from transformers import (Blip2Config, Blip2VisionConfig, Blip2QFormerConfig, OPTConfig,
                               Blip2ForConditionalGeneration)
     vc = Blip2VisionConfig(**spec["vision"])
@@ -123,7 +123,7 @@ def build_model(spec, seed):
     model = Blip2ForConditionalGeneration(cfg)
     with torch.no_grad():
         for name, p in model.named_parameters():
-            p.copy_(torch.from_numpy(param_init(name, p.shape, seed)))
+            p.copy_(torch.from_numpy(param_init(name, p.shape, seed, style)))
     model.tie_weights()
     return model.eval()
 
@@ -386,13 +386,13 @@ def main():
 
     if args.realdim:
         rd_dir = "/tmp/devqa_realdim_blip2"
-        model = build_model(REALDIM, seed=2)
+        model = build_model(REALDIM, seed=2, style="opt")
         save_tiny(model, tok, rd_dir, 224)
         del model
         rng2 = np.random.default_rng(20251122)
         img_paths, odd = write_images(os.path.join(GOLD, "images224"), 2, 224, rng2)
         records, raw = build_records(2, img_paths)
-        json.dump({"records": records, "raw": raw, "odd_image": odd, "spec": REALDIM, "seed": 2},
+        json.dump({"records": records, "raw": raw, "odd_image": odd, "spec": REALDIM, "seed": 2, "style": "opt"},
                   open(os.path.join(GOLD, "realdim_records.json"), "w"), indent=1)
         npz, js = run_reference_suite(rd_dir, "realdim", records, odd, False, 0, [1])
         # embeds are large at real dims: keep only checksums + a slice
