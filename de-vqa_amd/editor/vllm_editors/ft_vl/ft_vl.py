@@ -1,0 +1,170 @@
+"""FT_VL editor on the HIP path: drop-in for R/editor/vllm_editors/ft_vl/ft_vl.py:11-199.
+
+Same config dataclass, same plugin methods, same loop semantics (<= num_steps iterations, skip the
+update when loss < 1e-2, stop when the epoch-average loss < 1e-2, optional L-inf clamp, delta =
+w - w0, model restored, delta then added in place).  What changes is how a step is computed:
+
+  * the frozen part of the network (ViT, Q-Former, decoder up to the edited layer's fc2 input) is
+    evaluated ONCE per request chunk instead of once per step -- only fc2.weight of the last
+    decoder layer changes between steps, so the fc2 input rows `a` and the residual rows are
+    constants of the loop (the reference recomputes them 25 times, ft_vl.py:121);
+  * forward/backward run on the label rows that carry loss only (mask == 1);
+  * gradient + AdamW + the next forward's fc2 rows are ONE HBM sweep over the matrix
+    (devqa_ft_adamw_step), the rank-L gradient is never materialised.
+
+Supported edit target on this path: `...decoder.layers.<last>.fc2.weight` (what every shipped
+FT_VL config selects: R/configs/ft_vl/blip2-opt-2.7b.yaml:2,8).  Other targets would need a full
+backward pass through the network and raise NotImplementedError.
+"""
+from copy import deepcopy
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import torch
+
+from ... import nethook
+from ...base import BaseConfig
+from ..base import VLLMBaseEditor
+from .... import lib
+
+
+@dataclass
+class FTvlConfig(BaseConfig):
+    edit_model_name: str
+    # Method
+    rewrite_module_tmp: str
+    layers: List[int]
+    num_steps: int
+    lr: float
+    weight_decay: float
+    norm_constraint: float
+    batch_size: int = 128
+
+
+LOSS_FLOOR = 1e-2  # ft_vl.py:131,145
+
+
+class FTvl(VLLMBaseEditor):
+    def __init__(self, vllm, config: FTvlConfig, device="cuda:0", verbose=False):
+        super().__init__(vllm, device)
+        self.cfg = config
+        self.verbose = verbose
+        names = self._selected_names()
+        for n in names:  # edit targets become fp32 masters (bf16 shadow for GEMMs)
+            self.vllm.model.promote_to_fp32(n)
+        self.original_w = {n: p.clone() for n, p in self.vllm.model.named_parameters() if n in names}
+        self.last_losses: List[float] = []
+
+    def _selected_names(self):
+        # substring selection rule of the reference (ft_vl.py:31-36)
+        return [n for n, _ in self.vllm.model.named_parameters() for layer in self.cfg.layers
+                if self.cfg.rewrite_module_tmp.format(layer) in n]
+
+    def name_of_editor_and_model(self) -> Tuple[str, str]:
+        return "ft_vl", self.cfg.edit_model_name
+
+    def if_can_batch_edit(self):
+        return True
+
+    def restore_to_original_model(self):
+        self.vllm.model.load_state_dict(self.original_w, strict=False)
+
+    def edit_one_piece(self, request: Dict) -> None:
+        self.edit_batch([request])
+
+    def edit_batch(self, requests: List[Dict]):
+        deltas = self.execute_ft(requests)
+        with torch.no_grad():
+            for w_name, upd in deltas.items():
+                w = nethook.get_parameter(self.vllm.model, w_name)
+                lib.delta_op(1, w, None, upd)   # w[...] += upd_matrix (ft_vl.py:60-61)
+                self.vllm.model.mark_dirty(w_name)  # HIP wrote in place: the bf16 shadow is stale
+
+    # ---------------------------------------------------------------------------------------
+    def _edit_target(self):
+        names = self._selected_names()
+        t = self.vllm.model.cfg["text_config"]
+        want = "language_model.model.decoder.layers.%d.fc2.weight" % (t["num_hidden_layers"] - 1)
+        if names != [want]:
+            raise NotImplementedError("native FT_VL edits %s only; config selects %s" % (want, names))
+        return want
+
+    def _chunk_prefix(self, imgs, texts, targets):
+        """Frozen prefix for one request chunk -> fp32 a_rows [1,k,ffn], resid_rows [k,d] (+fc2 bias),
+        labels int32 [k] for the k loss-carrying rows."""
+        vllm, eng = self.vllm, self.vllm.engine
+        (x, vt), y, m = vllm.prompts_imgs_target_to_xym(texts, imgs, targets)
+        ps = eng.pack_from_embeds(x["inputs_embeds"], x["attention_mask"])
+        B, T = x["inputs_embeds"].shape[:2]
+        x_mid, a = eng.decoder_layers(ps, stop_before_fc2=True)
+        L = y.shape[1]
+        rows, labels = [], []
+        for b in range(B):
+            for j in range(L):
+                if int(m[b, j]) != 0:
+                    rows.append(b * T + (T - L) + j)
+                    labels.append(int(y[b, j]))
+        if len(rows) > 8:
+            raise NotImplementedError("native FT_VL supports <= 8 loss-carrying label rows per chunk (got %d)" % len(rows))
+        idx = torch.tensor(rows, dtype=torch.int32, device=eng.dev)
+        a_rows = lib.gather_rows(a, idx).to(torch.float32).unsqueeze(0).contiguous()
+        resid = lib.gather_rows(x_mid, idx)
+        resid = resid + eng._p("language_model.model.decoder.layers.%d.fc2.bias" % eng.edit_layer)
+        return a_rows, resid.contiguous(), torch.tensor(labels, dtype=torch.int32, device=eng.dev)
+
+    def execute_ft(self, requests: List[Dict]) -> Dict[str, torch.Tensor]:
+        requests = deepcopy(requests)
+        for r in requests:
+            if r["target_new"][0] != " ":
+                r["target_new"] = " " + r["target_new"]  # ft_vl.py:73-75
+        wname = self._edit_target()
+        eng = self.vllm.engine
+        w0 = nethook.get_parameter(self.vllm.model, wname)
+        Dout, Din = w0.shape
+        dev = eng.dev
+        cfg = self.cfg
+        bs = cfg.batch_size
+        chunks = [requests[i:i + bs] for i in range(0, len(requests), bs)]
+        prefixes = [self._chunk_prefix([r["image"] for r in c], [r["prompt"] for r in c],
+                                       [r["target_new"] for r in c]) for c in chunks]
+        w = torch.empty((1, Dout, Din), dtype=torch.float32, device=dev)
+        mom = torch.empty_like(w)
+        var = torch.empty_like(w)
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        adam_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else -1.0  # ft_vl.py:135
+        gamma = eng._p("language_model.model.decoder.final_layer_norm.weight")
+        updated = False
+        y_next = None
+        self.last_losses = []
+        for it in range(cfg.num_steps):
+            loss_sum, cnt = 0.0, 0
+            for ci, (a_rows, resid, labels) in enumerate(prefixes):
+                k = labels.numel()
+                if y_next is not None and len(prefixes) == 1:
+                    y = y_next
+                else:
+                    y = lib.rows_matvec(w if updated else w0, a_rows, shared=not updated)
+                pre_ln = (y.view(k, Dout) + resid).contiguous()
+                logits = eng.lm_head(pre_ln)
+                coef = torch.full((k,), 1.0 / k, dtype=torch.float32, device=dev)
+                _, nll, dlog = lib.vocab_rows(logits, labels, coef, want_argmax=False, want_nll=True, want_dlogits=True)
+                loss = float(nll.mean().item())  # the reference syncs here too (loss.item(), ft_vl.py:129-131)
+                self.last_losses.append(loss)
+                n_items = len(chunks[ci])
+                loss_sum += loss * n_items
+                cnt += n_items
+                if loss >= LOSS_FLOOR:
+                    dH = lib.gemm(dlog, self.vllm.model.embed_T, want="f32")
+                    dy = lib.layernorm_bwd_dx(pre_ln, gamma, dH, 1e-5).view(1, k, Dout)
+                    adam_t += 1
+                    y_next = torch.empty((1, k, Dout), dtype=torch.float32, device=dev)
+                    lib.ft_adamw_step(w, mom, var, w0, a_rows, dy.contiguous(), y_next, one, adam_t, cfg.lr, 0.9, 0.999,
+                                      1e-8, cfg.weight_decay, clamp)
+                    updated = True
+            if loss_sum / cnt < LOSS_FLOOR:
+                break
+        delta = torch.zeros((Dout, Din), dtype=torch.float32, device=dev)
+        if updated:
+            lib.delta_op(0, w.view(Dout, Din), w0, delta)
+        return {wname: delta}

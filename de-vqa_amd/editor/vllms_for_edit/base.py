@@ -1,0 +1,147 @@
+"""BaseVLLMForEdit: the VLLM wrapper plugin API of the reference
+(R/editor/vllms_for_edit/base.py:22-233), host logic restated; losses run on the HIP kernels.
+
+Same public names, argument meaning and error behaviour (BaseException on invalid input).
+Not provided on the native path: get_mid_module_inpt/outpt and forward_from_mid_layer (they are
+torch-forward-hook utilities, base.py:138-185, unused by FT_VL) -- they raise NotImplementedError.
+"""
+from abc import ABC, abstractmethod
+from typing import List, Optional
+
+import torch
+from torch.nn.utils.rnn import pad_sequence
+
+from ... import lib
+
+
+def set_tokenizer_pad_id(tokenizer, padding_side="right"):  # base.py:12-17
+    if tokenizer.pad_token_id is None:
+        tokenizer.pad_token_id = tokenizer.eos_token_id
+        print("Set [pad_token] as [eos_token].")
+    print('Padding side is set as "%s".' % padding_side)
+    tokenizer.padding_side = padding_side
+
+
+class BaseVLLMForEdit(ABC):
+    def __init__(self, model, device: str, auto_add_img_special_token: bool) -> None:
+        super().__init__()
+        self.model = model
+        self.device = device
+        self.auto_add_img_special_token = auto_add_img_special_token
+        set_tokenizer_pad_id(self.get_llm_tokenizer(), padding_side="right")
+        self.get_llm_input_embeds = self.__get_llm_input_embeds_wrap__(self.get_llm_input_embeds)
+
+    # base.py:37-73 -- input validation + optional image-token auto prefix
+    def __get_llm_input_embeds_wrap__(self, inner):
+        def wrapped(texts: List[str], imgs: Optional[List] = None):
+            if not isinstance(imgs, (list, type(None))) or not isinstance(texts, list):
+                raise BaseException("Not support type.")
+            if isinstance(imgs, list) and all(i is None for i in imgs):
+                imgs = None
+            ist = self.get_img_special_token_str()
+            if self.auto_add_img_special_token and imgs is not None and ist is not None:
+                texts = [ist + "\n" + t if t.find(ist) == -1 else t for t in texts]
+            if imgs is None:
+                if ist is not None:
+                    for t in texts:
+                        if t.find(ist) != -1:
+                            raise BaseException("`imgs` is None but found special image token in `texts`.")
+            else:
+                if len(texts) != len(imgs):
+                    raise BaseException("Number of texts (n = %s) and images (n = %s) not matched."
+                                        % (len(texts), len(imgs)))
+                if ist is not None:
+                    begin = texts[0].find(ist)
+                    for t in texts:
+                        if t.count(ist) != 1:
+                            raise BaseException("One image must correspond to one text.")
+                        if t[:begin] != texts[0][:begin]:
+                            raise BaseException("Special image token with different prefixes is not supported")
+            return inner(texts, imgs)
+        return wrapped
+
+    # base.py:75-109 -- strings -> (embeds, vt_range), label ids, label masks (int bookkeeping on host)
+    def xym_token_bookkeeping(self, prompts, targets):
+        """Returns (input_strs, label_ids [B,L] int64 cpu, label_masks [B,L] int64 cpu, min_prompt_tok_n)."""
+        targets = [" " + t if p[-1] not in [" ", "\n"] and t[0] not in [" ", "\n"] else t
+                   for p, t in zip(prompts, targets)]
+        tokenizer = self.get_llm_tokenizer()
+        input_strs, label_ids, label_masks = [], [], []
+        min_prompt_tok_n = 999
+        for p, t in zip(prompts, targets):
+            s = p + t
+            input_strs.append(s)
+            ids = torch.as_tensor(tokenizer(s)["input_ids"], dtype=torch.long)
+            lab = torch.roll(ids, -1, 0)
+            n_prompt = len(tokenizer(p)["input_ids"])
+            min_prompt_tok_n = min(min_prompt_tok_n, n_prompt)
+            m = torch.zeros_like(lab)
+            m[n_prompt - 1:-1] += 1
+            label_ids.append(lab)
+            label_masks.append(m)
+        y = pad_sequence(label_ids, True, tokenizer.pad_token_id)[:, min_prompt_tok_n - 1:]
+        m = pad_sequence(label_masks, True, 0)[:, min_prompt_tok_n - 1:]
+        return input_strs, y, m, min_prompt_tok_n
+
+    def prompts_imgs_target_to_xym(self, prompts: List[str], imgs: List, targets: List[str]):
+        input_strs, y, m, _ = self.xym_token_bookkeeping(prompts, targets)
+        input_embeds, vt_range = self.get_llm_input_embeds(input_strs, imgs)
+        return (input_embeds, vt_range), y.to(self.device), m.to(self.device)
+
+    # base.py:111-119 (K9) -- masked NLL on the HIP vocab-rows kernel (no autograd graph)
+    def label_loss(self, logits, label_ids, label_masks, average=True):
+        L = label_ids.shape[1]
+        rows = logits[:, -L:].reshape(-1, logits.shape[-1]).to(torch.float32).contiguous()
+        labels = label_ids.reshape(-1).to(torch.int32).contiguous()
+        _, nll, _ = lib.vocab_rows(rows, labels, None, want_argmax=False, want_nll=True)
+        msk = label_masks.reshape(-1).to(torch.float32)
+        loss = torch.where(msk != 0, nll * msk, torch.zeros_like(nll)).sum()
+        return loss / msk.sum() if average else loss
+
+    def logit_KL_loss(self, logits1, logits2, label_masks, average=True):  # base.py:121-132 (MEND training only)
+        raise NotImplementedError("logit_KL_loss (MEND_VL training, K18) is not part of the FT_VL hot path yet")
+
+    def set_device(self, device):  # base.py:134-136
+        self.device = device
+        self.model.to(device)
+
+    def get_mid_module_inpt(self, *a, **k):
+        raise NotImplementedError("torch-hook utilities are not available on the native HIP path")
+
+    get_mid_module_outpt = get_mid_module_inpt
+    forward_from_mid_layer = get_mid_module_inpt
+
+    # base.py:187-196 incl. the dim=1 normalisation quirk; tiny, host-side torch
+    def find_closest_tokens(self, embeddings, embedding_matrix, top_k=1):
+        en = embeddings / embeddings.norm(dim=1, keepdim=True)
+        mn = embedding_matrix / embedding_matrix.norm(dim=1, keepdim=True)
+        r = torch.topk(torch.matmul(en, mn.T), top_k, dim=-1)
+        return r.indices, r.values
+
+    @abstractmethod
+    def get_llm_tokenizer(self):
+        """tokenizer of the llm in the vllm"""
+
+    @abstractmethod
+    def get_llm_input_embeds(self, texts, imgs=None):
+        """-> (llm_inpt dict, vt_range)"""
+
+    @abstractmethod
+    def get_llm_outpt(self, input_embeds, vt_range=None):
+        """-> object with .logits"""
+
+    @abstractmethod
+    def get_img_special_token_str(self):
+        pass
+
+    @abstractmethod
+    def get_img_special_token_id(self):
+        pass
+
+    @abstractmethod
+    def get_img_token_n(self):
+        pass
+
+    @abstractmethod
+    def is_q_former_based(self):
+        pass

@@ -1,0 +1,201 @@
+"""BLIP-2-OPT parameter tree with the HF parameter names, backed by device buffers laid out for
+the HIP kernels.
+
+`.model` of the reference's wrapper is an nn.Module whose `named_parameters()` names are what
+editor configs address (R/configs/ft_vl/blip2-opt-2.7b.yaml:8; selection by substring at
+R/editor/vllm_editors/ft_vl/ft_vl.py:31-36) and whose parameters editors mutate in place
+(ft_vl.py:56-61) and restore through `load_state_dict(strict=False)` (ft_vl.py:44-45).  This tree
+keeps exactly that contract; its `forward` is not used -- arithmetic goes through
+devqa_amd.engine.Blip2Engine (HIP kernels behind the C ABI).
+
+HBM layout / dtype policy (bf16 compute mode):
+  * every >=2-D weight is bf16, K-contiguous [out, in] -- the TN operand layout of the MFMA GEMM;
+  * OPT q/k/v projections of a layer are three row-blocks of ONE fused [3d, d] buffer (one GEMM
+    per layer); the three HF parameters are views into it, so in-place edits stay visible;
+  * the ViT patch-embedding conv weight is stored as a [D, Kpad] GEMM operand (K = 3*P*P padded
+    to a multiple of 32); the HF parameter is a [D,3,P,P] fp32 master kept for the name contract;
+  * all 1-D parameters (biases, LayerNorm) and the small ViT/Q-Former embeddings are fp32;
+  * parameters selected as EDIT TARGETS are promoted to fp32 masters (`promote_to_fp32`) with a
+    bf16 shadow that GEMMs read; the shadow is refreshed when the master's version changes.
+"""
+import json
+import os
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from ....blip2_spec import param_shapes
+
+
+class _Node(nn.Module):
+    """Plain container; children/parameters are attached by name."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("devqa_amd modules are parameter containers; use Blip2Engine for arithmetic")
+
+
+def _attach(root, name, param):
+    parts = name.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    node.register_parameter(parts[-1], param)
+
+
+class Blip2Native(nn.Module):
+    def __init__(self, cfg, device="cuda"):
+        super().__init__()
+        self.cfg = cfg
+        t = cfg["text_config"]
+        self.config = SimpleNamespace(is_encoder_decoder=False, num_query_tokens=cfg["num_query_tokens"],
+                                      text_config=SimpleNamespace(**t), vision_config=SimpleNamespace(**cfg["vision_config"]),
+                                      qformer_config=SimpleNamespace(**cfg["qformer_config"]))
+        self.dev = torch.device(device)
+        self._shapes = param_shapes(cfg)
+        self._fp32_masters = {}   # name -> (param fp32, bf16 shadow, version seen)
+        self._build()
+
+    # -- construction -------------------------------------------------------------------------
+    def _build(self):
+        dev = self.dev
+        d = self.cfg["text_config"]["hidden_size"]
+        fused_w, fused_b = {}, {}
+        for name, shape in self._shapes.items():
+            is_vec = len(shape) == 1
+            small_f32 = name in ("query_tokens", "vision_model.embeddings.class_embedding",
+                                 "vision_model.embeddings.position_embedding",
+                                 "vision_model.embeddings.patch_embedding.weight")
+            dt = torch.float32 if (is_vec or small_f32) else torch.bfloat16
+            if ".self_attn." in name and "decoder.layers" in name and any(
+                    k in name for k in ("q_proj", "k_proj", "v_proj")):
+                layer = name.split("decoder.layers.")[1].split(".")[0]
+                slot = {"q_proj": 0, "k_proj": 1, "v_proj": 2}[name.split("self_attn.")[1].split(".")[0]]
+                if name.endswith("weight"):
+                    buf = fused_w.setdefault(layer, torch.zeros((3 * d, d), dtype=torch.bfloat16, device=dev))
+                else:
+                    buf = fused_b.setdefault(layer, torch.zeros((3 * d,), dtype=torch.float32, device=dev))
+                data = buf[slot * d:(slot + 1) * d]
+            else:
+                data = torch.zeros(shape, dtype=dt, device=dev)
+            _attach(self, name, nn.Parameter(data, requires_grad=False))
+        self.fused_qkv_w = fused_w
+        self.fused_qkv_b = fused_b
+        v = self.cfg["vision_config"]
+        self.patch_kreal = 3 * v["patch_size"] ** 2
+        self.patch_kpad = (self.patch_kreal + 31) // 32 * 32
+        self.patch_w_gemm = torch.zeros((v["hidden_size"], self.patch_kpad), dtype=torch.bfloat16, device=dev)
+        self.embed_T = None  # [d, V] bf16 transposed copy of the tied embedding (dH = dlogits . E)
+        self._derived_version = None
+
+    def get(self, name):
+        node = self
+        for p in name.split("."):
+            node = node._modules[p] if p in node._modules else node._parameters[p]
+        return node
+
+    # -- loading --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def load_named_tensors(self, get_tensor, names=None):
+        """get_tensor(name) -> CPU/GPU tensor (any float dtype) for each HF name."""
+        for name in (names or self._shapes.keys()):
+            src = get_tensor(name)
+            dst = self.get(name)
+            dst.copy_(src.to(dst.device).reshape(dst.shape).to(dst.dtype))
+        self.refresh_derived(force=True)
+
+    @torch.no_grad()
+    def refresh_derived(self, force=False):
+        pw = self.get("vision_model.embeddings.patch_embedding.weight")
+        emb = self.get("language_model.model.decoder.embed_tokens.weight")
+        ver = (pw._version, emb._version)
+        if not force and ver == self._derived_version:
+            return
+        self.patch_w_gemm.zero_()
+        self.patch_w_gemm[:, :self.patch_kreal] = pw.reshape(pw.shape[0], -1).to(torch.bfloat16)
+        self.embed_T = emb.t().contiguous()
+        self._derived_version = (pw._version, emb._version)
+
+    @classmethod
+    def from_pretrained_dir(cls, path, device="cuda"):
+        from safetensors import safe_open
+        cfg = json.load(open(os.path.join(path, "config.json")))
+        model = cls(cfg, device)
+        files = [f for f in sorted(os.listdir(path)) if f.endswith(".safetensors")]
+        if not files:
+            raise FileNotFoundError("no *.safetensors under %s" % path)
+        handles = [safe_open(os.path.join(path, f), framework="pt", device="cpu") for f in files]
+        key2h = {}
+        for h in handles:
+            for k in h.keys():
+                key2h[k] = h
+
+        def get_tensor(name):
+            if name in key2h:
+                return key2h[name].get_tensor(name)
+            if name.endswith("self_attn.qkv.bias"):  # older checkpoints: separate q_bias / v_bias
+                base = name[:-len("qkv.bias")]
+                qb = key2h[base + "q_bias"].get_tensor(base + "q_bias")
+                vb = key2h[base + "v_bias"].get_tensor(base + "v_bias")
+                return torch.cat([qb, torch.zeros_like(vb), vb])
+            raise KeyError(name)
+        model.load_named_tensors(get_tensor)
+        return model
+
+    @classmethod
+    def from_synth(cls, cfg, seed, style="opt", device="cuda"):
+        from ....synth import param_init
+        model = cls(cfg, device)
+        model.load_named_tensors(lambda n: torch.from_numpy(param_init(n, model._shapes[n], seed, style)))
+        return model
+
+    # -- edit targets -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def promote_to_fp32(self, name):
+        """Make parameter `name` an fp32 master (idempotent). GEMMs read its bf16 shadow."""
+        if name in self._fp32_masters:
+            return self._fp32_masters[name][0]
+        p = self.get(name)
+        if p.dtype == torch.float32:
+            return p
+        parts = name.split(".")
+        node = self
+        for q in parts[:-1]:
+            node = node._modules[q]
+        shadow = p.data  # keep the existing bf16 buffer as the shadow
+        master = nn.Parameter(p.data.to(torch.float32), requires_grad=False)
+        node._parameters[parts[-1]] = master
+        self._fp32_masters[name] = [master, shadow, master._version]
+        return master
+
+    @torch.no_grad()
+    def weight_for_gemm(self, name):
+        """bf16 operand for parameter `name` (refreshing the shadow of an fp32 master if stale)."""
+        ent = self._fp32_masters.get(name)
+        if ent is None:
+            return self.get(name)
+        master, shadow, ver = ent
+        if master._version != ver:
+            from .... import lib
+            lib.cast_f32_bf16(master.data, shadow)
+            ent[2] = master._version
+        return shadow
+
+    def mark_dirty(self, name):
+        """Call after writing an fp32 master through a raw pointer (torch's version counter
+        only sees torch ops)."""
+        ent = self._fp32_masters.get(name)
+        if ent is not None:
+            ent[2] = -1
+
+    def is_fp32_master(self, name):
+        return name in self._fp32_masters
+
+    def _load_from_state_dict(self, *a, **k):  # default behaviour is fine (copy_ into params)
+        return super()._load_from_state_dict(*a, **k)
+
+    def to(self, *args, **kwargs):  # buffers are created on the target device; moving is a no-op
+        return self

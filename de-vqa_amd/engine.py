@@ -1,0 +1,217 @@
+"""Blip2Engine: the BLIP-2-OPT forward / FT_VL backward schedule over the C-ABI HIP kernels.
+
+Python here only orders kernel launches on the current HIP stream and owns no arithmetic.
+Activations are packed row-major [rows, D]; the residual stream is fp32, GEMM operands bf16.
+
+Reference call sites replaced (R/ = /root/reference/DE-VQA/):
+  encode_images      <- vision_model -> qformer -> language_projection  (R/editor/vllms_for_edit/blip2/blip2.py:25-45)
+  decoder_*          <- language_model(inputs_embeds, attention_mask)    (blip2.py:68-75)
+  tail_logits        <- last-layer fc2 + residual + final LN + lm_head on the label rows only
+  ft_edit_batch      <- FTvl.execute_ft hot loop                         (R/editor/vllm_editors/ft_vl/ft_vl.py:111-146)
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import lib
+
+LN_EPS_OPT = 1e-5
+
+
+@dataclass
+class PackedSeqs:
+    """Sequences packed along rows.  Row r of sequence s sits at start[s] + r."""
+    x: torch.Tensor                 # fp32 [R, d]  embeddings + positions (decoder input)
+    start: List[int]
+    length: List[int]               # real (unpadded) length per sequence
+    desc: torch.Tensor              # int32 [n_seq, 6] attention descriptor (device)
+    max_len: int
+
+
+class Blip2Engine:
+    def __init__(self, model):
+        self.m = model
+        cfg = model.cfg
+        self.v, self.q, self.t = cfg["vision_config"], cfg["qformer_config"], cfg["text_config"]
+        self.Q = cfg["num_query_tokens"]
+        self.dev = model.dev
+        self.edit_layer = self.t["num_hidden_layers"] - 1
+        self._seq_desc_cache = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _w(self, name):
+        return self.m.weight_for_gemm(name)
+
+    def _p(self, name):
+        return self.m.get(name)
+
+    def _full_desc(self, n_seq, q_len, kv_len):
+        """n_seq independent sequences: q rows [i*q_len, ...), keys [i*kv_len, ...), all visible."""
+        key = (n_seq, q_len, kv_len)
+        d = self._seq_desc_cache.get(key)
+        if d is None:
+            rows = [[i * q_len, q_len, i * kv_len, kv_len, 0, 0] for i in range(n_seq)]
+            d = torch.tensor(rows, dtype=torch.int32, device=self.dev)
+            self._seq_desc_cache[key] = d
+        return d
+
+    # ------------------------------------------------------------------------------------------
+    # K2-K5: images -> projected query tokens [B, Q, d_llm] (fp32)
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_images(self, pixels):
+        m, v, q = self.m, self.v, self.q
+        m.refresh_derived()
+        B = pixels.shape[0]
+        P, D = v["patch_size"], v["hidden_size"]
+        G = v["image_size"] // P
+        N = G * G + 1
+        H = v["num_attention_heads"]
+        dh = D // H
+        eps = v["layer_norm_eps"]
+        cols = lib.im2col_patches(pixels.contiguous(), P, m.patch_kpad)
+        patches = lib.gemm(cols, m.patch_w_gemm, self._p("vision_model.embeddings.patch_embedding.bias"), want="f32")
+        x = lib.vit_assemble(patches, self._p("vision_model.embeddings.class_embedding"),
+                             self._p("vision_model.embeddings.position_embedding"), B, G * G, D)
+        desc = self._full_desc(B, N, N)
+        for i in range(v["num_hidden_layers"]):
+            p = "vision_model.encoder.layers.%d." % i
+            h = lib.layernorm(x, self._p(p + "layer_norm1.weight"), self._p(p + "layer_norm1.bias"), eps)
+            qkv = lib.gemm(h, self._w(p + "self_attn.qkv.weight"), self._p(p + "self_attn.qkv.bias"))
+            att = lib.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], desc, B, N, H, dh, dh ** -0.5, 0)
+            lib.gemm(att, self._w(p + "self_attn.projection.weight"), self._p(p + "self_attn.projection.bias"),
+                     residual=x, out_f32=x)
+            h = lib.layernorm(x, self._p(p + "layer_norm2.weight"), self._p(p + "layer_norm2.bias"), eps)
+            f = lib.gemm(h, self._w(p + "mlp.fc1.weight"), self._p(p + "mlp.fc1.bias"), act=lib.ACT_GELU)
+            lib.gemm(f, self._w(p + "mlp.fc2.weight"), self._p(p + "mlp.fc2.bias"), residual=x, out_f32=x)
+        img = lib.layernorm(x, self._p("vision_model.post_layernorm.weight"), self._p("vision_model.post_layernorm.bias"),
+                            eps)  # bf16 [B*N, D]: keys/values of every cross-attention
+        # ---- Q-Former ----
+        dq = q["hidden_size"]
+        Hq = q["num_attention_heads"]
+        dhq = dq // Hq
+        qeps = q["layer_norm_eps"]
+        Qn = self.Q
+        qt = self._p("query_tokens").reshape(Qn, dq)
+        h32 = lib.layernorm(qt.contiguous(), self._p("qformer.layernorm.weight"), self._p("qformer.layernorm.bias"), qeps,
+                            want="f32")
+        h32 = h32.repeat(B, 1)  # [B*Q, dq] (plumbing: the learned queries are shared by every image)
+        self_desc = self._full_desc(B, Qn, Qn)
+        cross_desc = self._full_desc(B, Qn, N)
+        for i in range(q["num_hidden_layers"]):
+            p = "qformer.encoder.layer.%d." % i
+            h32 = self._bert_attention(p + "attention.", h32, None, self_desc, B, Qn, Hq, dhq, qeps)
+            if i % q["cross_attention_frequency"] == 0:
+                h32 = self._bert_attention(p + "crossattention.", h32, img, cross_desc, B, Qn, Hq, dhq, qeps)
+            hb = lib.cast_f32_bf16(h32)
+            f = lib.gemm(hb, self._w(p + "intermediate_query.dense.weight"), self._p(p + "intermediate_query.dense.bias"),
+                         act=lib.ACT_GELU)
+            o = lib.gemm(f, self._w(p + "output_query.dense.weight"), self._p(p + "output_query.dense.bias"), want="f32")
+            h32 = lib.layernorm(o, self._p(p + "output_query.LayerNorm.weight"), self._p(p + "output_query.LayerNorm.bias"),
+                                qeps, add=h32, want="f32")
+        hb = lib.cast_f32_bf16(h32)
+        out = lib.gemm(hb, self._w("language_projection.weight"), self._p("language_projection.bias"), want="f32")
+        return out.view(B, Qn, -1)
+
+    def _bert_attention(self, p, h32, kv_bf16, desc, B, Qn, H, dh, eps):
+        hb = lib.cast_f32_bf16(h32)
+        src = hb if kv_bf16 is None else kv_bf16
+        qq = lib.gemm(hb, self._w(p + "attention.query.weight"), self._p(p + "attention.query.bias"))
+        kk = lib.gemm(src, self._w(p + "attention.key.weight"), self._p(p + "attention.key.bias"))
+        vv = lib.gemm(src, self._w(p + "attention.value.weight"), self._p(p + "attention.value.bias"))
+        att = lib.attention(qq, kk, vv, desc, B, Qn, H, dh, dh ** -0.5, 0)
+        o = lib.gemm(att, self._w(p + "output.dense.weight"), self._p(p + "output.dense.bias"), want="f32")
+        return lib.layernorm(o, self._p(p + "output.LayerNorm.weight"), self._p(p + "output.LayerNorm.bias"), eps,
+                             add=h32, want="f32")
+
+    # ------------------------------------------------------------------------------------------
+    # K6: decoder input rows
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def pack_from_embeds(self, inputs_embeds, attention_mask):
+        """[B,T,d] embeddings (+ right-padding mask) -> packed rows with OPT positions added.
+        Padded rows are kept (so logits come back as [B,T,V]) but never attended to."""
+        B, T, d = inputs_embeds.shape
+        am = attention_mask.to(torch.int64)
+        lens = am.sum(1).tolist()
+        pos = (torch.cumsum(am, 1) * am - 1).to(torch.int32).reshape(-1).contiguous()
+        rows = inputs_embeds.reshape(B * T, d).to(torch.float32).contiguous()
+        src = torch.arange(B * T, dtype=torch.int32, device=self.dev)
+        tok = torch.zeros(B * T, dtype=torch.int32, device=self.dev)
+        x = lib.embed_rows(tok, src, pos.to(self.dev), self._p("language_model.model.decoder.embed_tokens.weight"), rows,
+                           self._p("language_model.model.decoder.embed_positions.weight"))
+        desc = torch.tensor([[b * T, int(lens[b]), 0, 0, b * T, int(lens[b])] for b in range(B)], dtype=torch.int32,
+                            device=self.dev)
+        return PackedSeqs(x, [b * T for b in range(B)], [int(n) for n in lens], desc, T)
+
+    @torch.no_grad()
+    def pack_from_tokens(self, seqs, img_tokens):
+        """seqs: list of (image_index or None, token_id_list).  Each sequence becomes
+        [Q image-token rows (if any)] + token embeddings, positions 0..len-1 (blip2.py:45-52)."""
+        tok, src, pos, start, length = [], [], [], [], []
+        Qn = self.Q
+        r = 0
+        for (img, ids) in seqs:
+            start.append(r)
+            n = 0
+            if img is not None:
+                tok += [0] * Qn
+                src += list(range(img * Qn, (img + 1) * Qn))
+                pos += list(range(Qn))
+                n = Qn
+            tok += list(ids)
+            src += [-1] * len(ids)
+            pos += list(range(n, n + len(ids)))
+            n += len(ids)
+            length.append(n)
+            r += n
+        dev = self.dev
+        t_tok = torch.tensor(tok, dtype=torch.int32, device=dev)
+        t_src = torch.tensor(src, dtype=torch.int32, device=dev)
+        t_pos = torch.tensor(pos, dtype=torch.int32, device=dev)
+        rows = None if img_tokens is None else img_tokens.reshape(-1, img_tokens.shape[-1]).contiguous()
+        x = lib.embed_rows(t_tok, t_src, t_pos, self._p("language_model.model.decoder.embed_tokens.weight"), rows,
+                           self._p("language_model.model.decoder.embed_positions.weight"))
+        desc = torch.tensor([[s, n, 0, 0, s, n] for s, n in zip(start, length)], dtype=torch.int32, device=dev)
+        return PackedSeqs(x, start, length, desc, max(length))
+
+    # ------------------------------------------------------------------------------------------
+    # K7: decoder layers.  Returns the residual stream after `n_layers` full layers; when
+    # stop_before_fc2, the last processed layer stops at the fc2 input: returns (x_mid, a_bf16).
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decoder_layers(self, ps: PackedSeqs, upto_layer=None, stop_before_fc2=False):
+        t = self.t
+        d, H = t["hidden_size"], t["num_attention_heads"]
+        dh = d // H
+        x = ps.x
+        n_seq = len(ps.start)
+        last = t["num_hidden_layers"] - 1 if upto_layer is None else upto_layer
+        for i in range(last + 1):
+            p = "language_model.model.decoder.layers.%d." % i
+            h = lib.layernorm(x, self._p(p + "self_attn_layer_norm.weight"), self._p(p + "self_attn_layer_norm.bias"),
+                              LN_EPS_OPT)
+            qkv = lib.gemm(h, self.m.fused_qkv_w[str(i)], self.m.fused_qkv_b[str(i)])
+            att = lib.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], ps.desc, n_seq, ps.max_len, H, dh, dh ** -0.5,
+                                1, out=torch.zeros((x.shape[0], d), dtype=torch.bfloat16, device=self.dev))
+            lib.gemm(att, self._w(p + "self_attn.out_proj.weight"), self._p(p + "self_attn.out_proj.bias"), residual=x,
+                     out_f32=x)
+            h = lib.layernorm(x, self._p(p + "final_layer_norm.weight"), self._p(p + "final_layer_norm.bias"), LN_EPS_OPT)
+            a = lib.gemm(h, self._w(p + "fc1.weight"), self._p(p + "fc1.bias"), act=lib.ACT_RELU)
+            if stop_before_fc2 and i == last:
+                return x, a
+            lib.gemm(a, self._w(p + "fc2.weight"), self._p(p + "fc2.bias"), residual=x, out_f32=x)
+        return x, None
+
+    # K8: final LN + tied lm_head on the given rows -> fp32 logits
+    @torch.no_grad()
+    def lm_head(self, x_rows, add=None):
+        h = lib.layernorm(x_rows, self._p("language_model.model.decoder.final_layer_norm.weight"),
+                          self._p("language_model.model.decoder.final_layer_norm.bias"), LN_EPS_OPT, add=add)
+        return lib.gemm(h, self._p("language_model.model.decoder.embed_tokens.weight"), want="f32")
+
+    @torch.no_grad()
+    def full_logits(self, ps: PackedSeqs):
+        x, _ = self.decoder_layers(ps)
+        return self.lm_head(x)

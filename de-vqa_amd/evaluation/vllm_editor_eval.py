@@ -1,0 +1,220 @@
+"""VLLMEditorEvaluation: drop-in for R/evaluation/vllm_editor_eval.py:13-247 (same constructor,
+methods, result schema and JSON files).
+
+`evaluate_sequential_edit` has two execution modes with identical results:
+  * generic (any VLLMBaseEditor / BaseVLLMForEdit): the reference's call sequence through the
+    plugin API (prepare -> edit -> test -> restore per split);
+  * batched (FTvl on the native BLIP-2 wrapper, edit_n == 1, every sample a single request):
+    devqa_amd.batched.BatchedEditEval runs many independent splits concurrently on one GPU and
+    shards splits across ranks; selected automatically, `batched=False` disables.
+"""
+import json
+import os
+from collections import defaultdict
+from copy import deepcopy
+from datetime import datetime
+from time import time
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+
+class VLLMEditorEvaluation:
+    def __init__(self, editor, eval_data, evaluation_name=None, results_dir="eval_results") -> None:
+        self.editor = editor
+        self.eval_data = eval_data
+        editor_name, model_name = editor.name_of_editor_and_model()
+        t = datetime.now().strftime("%Y.%m.%d-%H.%M.%S")
+        evaluation_name = evaluation_name if evaluation_name else t
+        self.result_dir = os.path.join(results_dir, editor_name, model_name, evaluation_name)
+        print("Evaluation results directory: ", self.result_dir)
+
+    # -- helpers shared by both evaluation entry points (vllm_editor_eval.py:137-175) -----------
+    @staticmethod
+    def _argmax_last(vllm, prompt, image, target):
+        (x, vt), y, m = vllm.prompts_imgs_target_to_xym([prompt], [image], [target])
+        x["query_triple"] = (prompt, image, target)                       # dynamic-eval hook (:140)
+        x["query_range"] = (0, x["inputs_embeds"].shape[1] - m.shape[1] + 1)  # (:141)
+        logits = vllm.get_llm_outpt(x, vt).logits
+        assert len(y) == 1 and len(m) == 1
+        from .. import lib
+        L = y.shape[1]
+        rows = logits[0, -L:].to(torch.float32).contiguous()
+        pre, _, _ = lib.vocab_rows(rows)  # argmax(softmax(.)) == argmax(.)
+        return pre.to(torch.long).unsqueeze(0), y, m
+
+    @staticmethod
+    def _acc(pre_y, label_ids, label_masks):
+        return float(((pre_y == label_ids) * label_masks).sum() / label_masks.sum())
+
+    def __get_results_after_edit__(self, vllm, ed, rd):
+        tok = vllm.get_llm_tokenizer()
+        for rdr, edr in zip(rd["reliability"], ed["requests"]):
+            pre, y, m = self._argmax_last(vllm, edr["prompt"], edr["image"], edr["target_new"])
+            rdr["predict_after_edit"] = tok.decode(pre[m.to(bool)])
+            rdr["acc"] = self._acc(pre, y, m)
+        for gen_name in ed["generality"]:
+            for rdg, edg in zip(rd["generality"][gen_name], ed["generality"][gen_name]):
+                pre, y, m = self._argmax_last(vllm, edg["prompt"], edg["image"], edg["target"])
+                rdg["predict_after_edit"] = tok.decode(pre[m.to(bool)])
+                rdg["acc"] = self._acc(pre, y, m)
+        for loc_name in ed["locality"]:
+            for rdl, edl in zip(rd["locality"][loc_name], ed["locality"][loc_name]):
+                pre, _, m = self._argmax_last(vllm, edl["prompt"], edl["image"], edl["target"])
+                rdl["predict_after_edit"] = tok.decode(pre[m.to(bool)])
+                rdl["acc"] = self._acc(pre, edl["before_edit_ids"], m)  # agreement with PRE-edit argmax (:170-174)
+        return rd
+
+    # -- vllm_editor_eval.py:29-67 ------------------------------------------------------------------
+    def evaluate_single_edit(self):
+        editor = self.editor
+        print("Evaluating reliability, generality and locality for %s on %s with single editing."
+              % editor.name_of_editor_and_model())
+        eval_data = deepcopy(self.eval_data.data_with_img)
+        for ed in eval_data:
+            assert len(ed["requests"]) == 1
+        result_data = deepcopy(self.eval_data.data_with_img_path)
+        tok = editor.vllm.get_llm_tokenizer()
+        editor.restore_to_original_model()
+        results = []
+        for rd, ed in zip(result_data, eval_data):
+            rd["reliability"] = rd.pop("requests")
+            rd["reliability"][0]["target"] = rd["reliability"][0].pop("target_new")
+            for loc_name in ed["locality"].keys():
+                for rdl, edl in zip(rd["locality"][loc_name], ed["locality"][loc_name]):
+                    pre, y, m = self._argmax_last(editor.vllm, edl["prompt"], edl["image"], edl["target"])
+                    rdl["predict_before_edit"] = tok.decode(y[m.to(bool)])  # decodes the LABELS (quirk, :50)
+                    edl["before_edit_ids"] = pre
+            start_t = time()
+            editor.edit_one_piece(ed["requests"][0])
+            rd["reliability"][0]["edit_time"] = time() - start_t
+            rd = self.__get_results_after_edit__(editor.vllm, ed, rd)
+            results.append(rd)
+            editor.restore_to_original_model()
+        save_dir = os.path.join(self.result_dir, "single_edit")
+        self.save_results(os.path.join(save_dir, "results.json"), results)
+        mean_results = self.get_mean_results(results)
+        mean_results["sample_count"] = len(results)
+        self.save_results(os.path.join(save_dir, "mean_results.json"), mean_results)
+        return results
+
+    # -- vllm_editor_eval.py:69-135 -----------------------------------------------------------------
+    @staticmethod
+    def split_data(data, edit_n):
+        """Greedy groups with >= edit_n requests; an incomplete tail group is DROPPED (:74-87)."""
+        splits, ns, cur, n = [], [], [], 0
+        for d in data:
+            cur.append(d)
+            n += len(d["requests"])
+            if n >= edit_n:
+                splits.append(cur)
+                ns.append(n)
+                cur, n = [], 0
+        return splits, ns
+
+    def evaluate_sequential_edit(self, edit_n=10, random=False, seed=None, batched=None, save=True):
+        editor = self.editor
+        print("Evaluating reliability, generality and locality for %s on %s with sequential editing %s."
+              % (*editor.name_of_editor_and_model(), edit_n))
+        eval_data = deepcopy(self.eval_data.data_with_img)
+        result_data = deepcopy(self.eval_data.data_with_img_path)
+        if random:
+            seed = seed if seed is not None else np.random.randint(1, 999999)
+            np.random.default_rng(seed).shuffle(eval_data)
+            np.random.default_rng(seed).shuffle(result_data)
+        eval_data, eval_data_ns = self.split_data(eval_data, edit_n)
+        result_data, _ = self.split_data(result_data, edit_n)
+        from ..batched import BatchedEditEval
+        use_batched = BatchedEditEval.supports(editor, eval_data, edit_n) if batched is None else batched
+        if use_batched:
+            results = BatchedEditEval(editor).run(result_data, eval_data)
+        else:
+            results = self._sequential_generic(editor, result_data, eval_data)
+        if results is None:   # non-zero rank of a sharded run: rank 0 owns the files
+            return None
+        if save:
+            save_dir = os.path.join(self.result_dir, "sequential_edit_%s" % edit_n)
+            pre = "seed_%s_" % seed if random else ""
+            self.save_results(os.path.join(save_dir, "%sresults.json" % pre), results)
+            split_mean = [self.get_mean_results(sr) for sr in results]
+            for mr, n in zip(split_mean, eval_data_ns):
+                mr["sequential_edit_n"] = n
+            total_mean = self.get_mean_results([r for sr in results for r in sr])
+            total_mean["total_edit_n"] = sum(eval_data_ns)
+            mean_results = {"total_mean": total_mean, "split_mean": split_mean}
+            self.save_results(os.path.join(save_dir, "%smean_results.json" % pre), mean_results)
+        return results
+
+    def _sequential_generic(self, editor, result_data, eval_data):
+        tok = editor.vllm.get_llm_tokenizer()
+        editor.restore_to_original_model()
+        results = []
+        for split_rd, split_ed in zip(result_data, eval_data):
+            split_res = []
+            for rd, ed in zip(split_rd, split_ed):
+                rd["reliability"] = rd.pop("requests")
+                for r in rd["reliability"]:
+                    r["target"] = r.pop("target_new")
+                for loc_name in ed["locality"].keys():
+                    for rdl, edl in zip(rd["locality"][loc_name], ed["locality"][loc_name]):
+                        pre, _, m = self._argmax_last(editor.vllm, edl["prompt"], edl["image"], edl["target"])
+                        rdl["predict_before_edit"] = tok.decode(pre[m.to(bool)])
+                        edl["before_edit_ids"] = pre
+            for rd, ed in zip(split_rd, split_ed):
+                for rdr, edr in zip(rd["reliability"], ed["requests"]):
+                    start_t = time()
+                    editor.edit_one_piece(edr)
+                    rdr["edit_time"] = time() - start_t
+            for rd, ed in zip(split_rd, split_ed):
+                rd = self.__get_results_after_edit__(editor.vllm, ed, rd)
+                split_res.append(rd)
+            editor.restore_to_original_model()
+            results.append(split_res)
+        return results
+
+    # -- vllm_editor_eval.py:177-229 ------------------------------------------------------------------
+    def get_mean_results(self, results: List[Dict]):
+        mean_res = {"reliability": {}, "generality": {}, "locality": {}}
+
+        def acc(dst, item):
+            for name, value in item.items():
+                if isinstance(value, (int, float)):
+                    if name not in dst:
+                        dst[name] = [0, 0]
+                    dst[name][0] += value
+                    dst[name][1] += 1
+        for r in results:
+            for rr in r["reliability"]:
+                acc(mean_res["reliability"], rr)
+            for sec in ("generality", "locality"):
+                for sub in r[sec].keys():
+                    if sub not in mean_res[sec]:
+                        mean_res[sec][sub] = {}
+                    for sub_res in r[sec][sub]:
+                        acc(mean_res[sec][sub], sub_res)
+        for name, v in mean_res["reliability"].items():
+            mean_res["reliability"][name] = v[0] / v[1]
+        for sec in ("generality", "locality"):
+            for sub in mean_res[sec].keys():
+                for name, v in mean_res[sec][sub].items():
+                    mean_res[sec][sub][name] = v[0] / v[1]
+        return mean_res
+
+    # -- vllm_editor_eval.py:231-247 ------------------------------------------------------------------
+    def save_results(self, save_path: str, results: Dict, decimal=4):
+        def set_decimal(r):
+            if isinstance(r, list):
+                for i in range(len(r)):
+                    r[i] = set_decimal(r[i])
+            elif isinstance(r, (dict, defaultdict)):
+                for k in r.keys():
+                    r[k] = set_decimal(r[k])
+            elif isinstance(r, float):
+                r = round(r, decimal)
+            return r
+        res = set_decimal(deepcopy(results))
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        with open(save_path, "w") as f:
+            json.dump(res, f, indent=4)
+        print("save to", save_path)
