@@ -11,10 +11,30 @@
 #define ATT_KC 64     // keys per chunk
 #define ATT_MAXDH 128
 
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ q, int64_t ldq,
-                                                        const bf16_t* __restrict__ k, int64_t ldk,
-                                                        const bf16_t* __restrict__ v, int64_t ldv,
-                                                        bf16_t* __restrict__ out, int64_t ldo,
+__device__ __forceinline__ void load8(const bf16_t* p, float* o) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        o[2 * t] = bf16_to_f32(w[t] & 0xffff);
+        o[2 * t + 1] = bf16_to_f32(w[t] >> 16);
+    }
+}
+__device__ __forceinline__ void load8(const float* p, float* o) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+    o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ float ld1(const bf16_t* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, int64_t ldq,
+                                                        const T* __restrict__ k, int64_t ldk,
+                                                        const T* __restrict__ v, int64_t ldv,
+                                                        T* __restrict__ out, int64_t ldo,
                                                         const int32_t* __restrict__ seq_desc, int H, int dh, float scale,
                                                         int causal, int q_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
@@ -39,7 +59,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     for (int i = tid; i < ATT_QT * dh; i += 256) {
         const int r = i / dh, c = i % dh;
         float val = 0.f;
-        if (r < nq) val = bf16_to_f32(q[(int64_t)(q_start + q0 + r) * ldq + h * dh + c]) * scale;
+        if (r < nq) val = ld1(q + (int64_t)(q_start + q0 + r) * ldq + h * dh + c) * scale;
         Qs[r * dh + c] = val;
     }
 
@@ -68,16 +88,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
             if (r < nk) {
                 const int kidx = c0 + r;
                 const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);
-                const uint4 ku = *reinterpret_cast<const uint4*>(k + grow * ldk + h * dh + cv * 8);
-                const uint4 vu = *reinterpret_cast<const uint4*>(v + grow * ldv + h * dh + cv * 8);
-                const uint32_t kw[4] = {ku.x, ku.y, ku.z, ku.w}, vw[4] = {vu.x, vu.y, vu.z, vu.w};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    kv[2 * t] = bf16_to_f32(kw[t] & 0xffff);
-                    kv[2 * t + 1] = bf16_to_f32(kw[t] >> 16);
-                    vv[2 * t] = bf16_to_f32(vw[t] & 0xffff);
-                    vv[2 * t + 1] = bf16_to_f32(vw[t] >> 16);
-                }
+                load8(k + grow * ldk + h * dh + cv * 8, kv);
+                load8(v + grow * ldv + h * dh + cv * 8, vv);
             } else {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
@@ -146,16 +158,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         const int r = wave * 4 + j;
         if (r < nq) {
             const float inv = l_run[j] > 0.f ? 1.f / l_run[j] : 0.f;
-            bf16_t* orow = out + (int64_t)(q_start + q0 + r) * ldo + h * dh;
-            if (lane < dh) orow[lane] = f32_to_bf16(o0[j] * inv);
-            if (lane + 64 < dh) orow[lane + 64] = f32_to_bf16(o1[j] * inv);
+            T* orow = out + (int64_t)(q_start + q0 + r) * ldo + h * dh;
+            if (lane < dh) st1(orow + lane, o0[j] * inv);
+            if (lane + 64 < dh) st1(orow + lane + 64, o1[j] * inv);
         }
     }
 }
 
-extern "C" int devqa_attention(const devqa_bf16* q, int64_t ldq, const devqa_bf16* k, int64_t ldk, const devqa_bf16* v,
-                               int64_t ldv, devqa_bf16* out, int64_t ldo, const int32_t* seq_desc, int n_seq,
-                               int max_q_len, int H, int dh, float scale, int causal, void* stream) {
+template <typename T>
+static int launch_attention(const T* q, int64_t ldq, const T* k, int64_t ldk, const T* v, int64_t ldv, T* out, int64_t ldo,
+                            const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale, int causal,
+                            void* stream) {
     DEVQA_CHECK_ARG(q && k && v && out && seq_desc, "attention: null pointer");
     if (n_seq == 0 || max_q_len == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(n_seq > 0 && max_q_len > 0 && H > 0, "attention: bad dims");
@@ -169,12 +182,25 @@ extern "C" int devqa_attention(const devqa_bf16* q, int64_t ldq, const devqa_bf1
     DEVQA_CHECK_SHAPE(grid < 2147483647L, "attention: grid too large");
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(float) * (2 * ATT_KC * (ATT_MAXDH + 1) + ATT_QT * ATT_MAXDH + ATT_QT * ATT_KC)));
         attr_done = true;
     }
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, q, ldq, k, ldk, v, ldv,
-                       out, ldo, seq_desc, H, dh, scale, causal, q_tiles);
+    hipLaunchKernelGGL(attention_kernel<T>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, q, ldq, k, ldk, v,
+                       ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles);
     DEVQA_LAUNCH_CHECK("attention");
     return DEVQA_OK;
+}
+
+extern "C" int devqa_attention(const devqa_bf16* q, int64_t ldq, const devqa_bf16* k, int64_t ldk, const devqa_bf16* v,
+                               int64_t ldv, devqa_bf16* out, int64_t ldo, const int32_t* seq_desc, int n_seq,
+                               int max_q_len, int H, int dh, float scale, int causal, void* stream) {
+    return launch_attention<bf16_t>(q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, n_seq, max_q_len, H, dh, scale, causal,
+                                    stream);
+}
+extern "C" int devqa_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                   float* out, int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh,
+                                   float scale, int causal, void* stream) {
+    return launch_attention<float>(q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, n_seq, max_q_len, H, dh, scale, causal,
+                                   stream);
 }

@@ -171,7 +171,16 @@ extern "C" int devqa_layernorm_bwd_dx(const float* x, const float* gamma, const 
 // ------------------------------------------------------------------------------------------
 // im2col for the patch-embedding conv: out[b*np + (py*G+px)][(c*P+ky)*P+kx] (bf16), zero pad
 // ------------------------------------------------------------------------------------------
-__global__ void im2col_kernel(const float* __restrict__ pix, int B, int S, int P, int Kpad, bf16_t* __restrict__ out) {
+__device__ __forceinline__ void store_elem(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+__device__ __forceinline__ void store_elem(float* p, float v) { *p = v; }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+    const uint2 e = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf16_to_f32(e.x & 0xffff), bf16_to_f32(e.x >> 16), bf16_to_f32(e.y & 0xffff), bf16_to_f32(e.y >> 16));
+}
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <typename T>
+__global__ void im2col_kernel(const float* __restrict__ pix, int B, int S, int P, int Kpad, T* __restrict__ out) {
     const int G = S / P, np = G * G, Kreal = 3 * P * P;
     const int64_t total = (int64_t)B * np * Kpad;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -184,18 +193,25 @@ __global__ void im2col_kernel(const float* __restrict__ pix, int B, int S, int P
             const int y = (p / G) * P + ky, x = (p % G) * P + kx;
             v = pix[(((int64_t)b * 3 + c) * S + y) * S + x];
         }
-        out[i] = f32_to_bf16(v);
+        store_elem(out + i, v);
     }
 }
-extern "C" int devqa_im2col_patches(const float* pixels, int B, int S, int P, int Kpad, devqa_bf16* out, void* stream) {
+template <typename T>
+static int launch_im2col(const float* pixels, int B, int S, int P, int Kpad, T* out, void* stream) {
     DEVQA_CHECK_ARG(pixels && out, "im2col: null pointer");
     if (B == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(B > 0 && S > 0 && P > 0 && S % P == 0 && Kpad >= 3 * P * P && Kpad % 8 == 0, "im2col: bad shape");
     const int64_t total = (int64_t)B * (S / P) * (S / P) * Kpad;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pixels, B, S, P, Kpad, out);
+    hipLaunchKernelGGL(im2col_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pixels, B, S, P, Kpad, out);
     DEVQA_LAUNCH_CHECK("im2col");
     return DEVQA_OK;
+}
+extern "C" int devqa_im2col_patches(const float* pixels, int B, int S, int P, int Kpad, devqa_bf16* out, void* stream) {
+    return launch_im2col<bf16_t>(pixels, B, S, P, Kpad, out, stream);
+}
+extern "C" int devqa_im2col_patches_f32(const float* pixels, int B, int S, int P, int Kpad, float* out, void* stream) {
+    return launch_im2col<float>(pixels, B, S, P, Kpad, out, stream);
 }
 
 __global__ void vit_assemble_kernel(const float* __restrict__ patches, const float* __restrict__ cls,
@@ -228,9 +244,10 @@ extern "C" int devqa_vit_assemble(const float* patches, const float* cls, const 
 // ------------------------------------------------------------------------------------------
 // token embedding / image-token rows + OPT learned positions (offset 2)
 // ------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void embed_rows_kernel(const int32_t* __restrict__ token, const int32_t* __restrict__ src_row,
-                                  const int32_t* __restrict__ pos, const bf16_t* __restrict__ embed,
-                                  const float* __restrict__ rows_f32, const bf16_t* __restrict__ pos_table, int R, int D,
+                                  const int32_t* __restrict__ pos, const T* __restrict__ embed,
+                                  const float* __restrict__ rows_f32, const T* __restrict__ pos_table, int R, int D,
                                   int V, int n_rows_f32, int n_pos, float* __restrict__ out) {
     const int nv = D >> 2;
     const int64_t total = (int64_t)R * nv;
@@ -244,31 +261,39 @@ __global__ void embed_rows_kernel(const int32_t* __restrict__ token, const int32
         } else {
             int t = token[r];
             t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-            const uint2 e = reinterpret_cast<const uint2*>(embed + (int64_t)t * D)[c];
-            v = make_float4(bf16_to_f32(e.x & 0xffff), bf16_to_f32(e.x >> 16), bf16_to_f32(e.y & 0xffff),
-                            bf16_to_f32(e.y >> 16));
+            v = load4(embed + (int64_t)t * D + c * 4);
         }
         int p = pos[r] + 2;
         p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
-        const uint2 e = reinterpret_cast<const uint2*>(pos_table + (int64_t)p * D)[c];
-        v.x += bf16_to_f32(e.x & 0xffff); v.y += bf16_to_f32(e.x >> 16);
-        v.z += bf16_to_f32(e.y & 0xffff); v.w += bf16_to_f32(e.y >> 16);
+        const float4 e = load4(pos_table + (int64_t)p * D + c * 4);
+        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
         reinterpret_cast<float4*>(out)[i] = v;
     }
 }
-extern "C" int devqa_embed_rows(const int32_t* token, const int32_t* src_row, const int32_t* pos, const devqa_bf16* embed,
-                                const float* rows_f32, const devqa_bf16* pos_table, int R, int D, int V, int n_rows_f32,
-                                int n_pos, float* out, void* stream) {
+template <typename T>
+static int launch_embed_rows(const int32_t* token, const int32_t* src_row, const int32_t* pos, const T* embed,
+                             const float* rows_f32, const T* pos_table, int R, int D, int V, int n_rows_f32, int n_pos,
+                             float* out, void* stream) {
     DEVQA_CHECK_ARG(token && pos && embed && pos_table && out, "embed_rows: null pointer");
     DEVQA_CHECK_ARG(!src_row || rows_f32 || n_rows_f32 == 0, "embed_rows: src_row given without rows_f32");
     if (R == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(R > 0 && D > 0 && D % 4 == 0 && V > 0 && n_pos > 0, "embed_rows: bad shape");
     const int64_t total = (int64_t)R * (D / 4);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(embed_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, token, src_row, pos, embed,
+    hipLaunchKernelGGL(embed_rows_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, token, src_row, pos, embed,
                        rows_f32, pos_table, R, D, V, n_rows_f32, n_pos, out);
     DEVQA_LAUNCH_CHECK("embed_rows");
     return DEVQA_OK;
+}
+extern "C" int devqa_embed_rows(const int32_t* token, const int32_t* src_row, const int32_t* pos, const devqa_bf16* embed,
+                                const float* rows_f32, const devqa_bf16* pos_table, int R, int D, int V, int n_rows_f32,
+                                int n_pos, float* out, void* stream) {
+    return launch_embed_rows<bf16_t>(token, src_row, pos, embed, rows_f32, pos_table, R, D, V, n_rows_f32, n_pos, out, stream);
+}
+extern "C" int devqa_embed_rows_f32(const int32_t* token, const int32_t* src_row, const int32_t* pos, const float* embed,
+                                    const float* rows_f32, const float* pos_table, int R, int D, int V, int n_rows_f32,
+                                    int n_pos, float* out, void* stream) {
+    return launch_embed_rows<float>(token, src_row, pos, embed, rows_f32, pos_table, R, D, V, n_rows_f32, n_pos, out, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -24,10 +24,11 @@ __device__ __forceinline__ RedT red_combine(RedT a, RedT b) {
     return r;
 }
 
+template <typename T>
 __global__ __launch_bounds__(1024) void vocab_rows_kernel(const float* __restrict__ logits, int64_t ldl, int V,
                                                           const int32_t* __restrict__ labels, const float* __restrict__ coef,
                                                           int32_t* __restrict__ argmax_out, float* __restrict__ nll_out,
-                                                          bf16_t* __restrict__ dlogits, int64_t ldd) {
+                                                          T* __restrict__ dlogits, int64_t ldd) {
     __shared__ float sm_m[16], sm_s[16];
     __shared__ int sm_i[16];
     __shared__ float bc_m, bc_lse;
@@ -92,34 +93,48 @@ __global__ __launch_bounds__(1024) void vocab_rows_kernel(const float* __restric
     const float lse = bc_lse;
     const float cf = coef ? coef[r] : 1.f;
     const int lab = labels ? labels[r] : -1;
-    bf16_t* drow = dlogits + (int64_t)r * ldd;
+    T* drow = dlogits + (int64_t)r * ldd;
     for (int i = tid; i < nv; i += 1024) {
         const float4 x = reinterpret_cast<const float4*>(row)[i];
         float g[4] = {__expf(x.x - lse), __expf(x.y - lse), __expf(x.z - lse), __expf(x.w - lse)};
         const int b0 = i * 4;
         if (lab >= b0 && lab < b0 + 4) g[lab - b0] -= 1.f;
-        uint2 p;
-        p.x = pack_bf16x2(g[0] * cf, g[1] * cf);
-        p.y = pack_bf16x2(g[2] * cf, g[3] * cf);
-        reinterpret_cast<uint2*>(drow)[i] = p;
+        if constexpr (sizeof(T) == 2) {
+            uint2 p;
+            p.x = pack_bf16x2(g[0] * cf, g[1] * cf);
+            p.y = pack_bf16x2(g[2] * cf, g[3] * cf);
+            reinterpret_cast<uint2*>(drow)[i] = p;
+        } else {
+            reinterpret_cast<float4*>(drow)[i] = make_float4(g[0] * cf, g[1] * cf, g[2] * cf, g[3] * cf);
+        }
     }
     for (int i = nv * 4 + tid; i < V; i += 1024) {
         float g = __expf(row[i] - lse);
         if (i == lab) g -= 1.f;
-        drow[i] = f32_to_bf16(g * cf);
+        if constexpr (sizeof(T) == 2) drow[i] = f32_to_bf16(g * cf);
+        else drow[i] = g * cf;
     }
 }
 
-extern "C" int devqa_vocab_rows(const float* logits, int64_t ldl, int R, int V, const int32_t* labels, const float* coef,
-                                int32_t* argmax_out, float* nll_out, devqa_bf16* dlogits, int64_t ldd, void* stream) {
+template <typename T>
+static int launch_vocab_rows(const float* logits, int64_t ldl, int R, int V, const int32_t* labels, const float* coef,
+                             int32_t* argmax_out, float* nll_out, T* dlogits, int64_t ldd, void* stream) {
     DEVQA_CHECK_ARG(logits, "vocab_rows: null logits");
     DEVQA_CHECK_ARG(argmax_out || nll_out || dlogits, "vocab_rows: nothing to compute");
     DEVQA_CHECK_ARG(!(nll_out || dlogits) || labels, "vocab_rows: labels required for nll/dlogits");
     if (R == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(R > 0 && V > 0 && ldl >= V && ldl % 4 == 0, "vocab_rows: bad shape R=%d V=%d", R, V);
     DEVQA_CHECK_SHAPE(!dlogits || (ldd >= V && ldd % 4 == 0), "vocab_rows: bad dlogits stride");
-    hipLaunchKernelGGL(vocab_rows_kernel, dim3(R), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, labels, coef,
+    hipLaunchKernelGGL(vocab_rows_kernel<T>, dim3(R), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, labels, coef,
                        argmax_out, nll_out, dlogits, ldd);
     DEVQA_LAUNCH_CHECK("vocab_rows");
     return DEVQA_OK;
+}
+extern "C" int devqa_vocab_rows(const float* logits, int64_t ldl, int R, int V, const int32_t* labels, const float* coef,
+                                int32_t* argmax_out, float* nll_out, devqa_bf16* dlogits, int64_t ldd, void* stream) {
+    return launch_vocab_rows<bf16_t>(logits, ldl, R, V, labels, coef, argmax_out, nll_out, dlogits, ldd, stream);
+}
+extern "C" int devqa_vocab_rows_f32(const float* logits, int64_t ldl, int R, int V, const int32_t* labels, const float* coef,
+                                    int32_t* argmax_out, float* nll_out, float* dlogits, int64_t ldd, void* stream) {
+    return launch_vocab_rows<float>(logits, ldl, R, V, labels, coef, argmax_out, nll_out, dlogits, ldd, stream);
 }

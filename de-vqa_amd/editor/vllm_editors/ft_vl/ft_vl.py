@@ -148,7 +148,8 @@ class FTvl(VLLMBaseEditor):
                 pre_ln = (y.view(k, Dout) + resid).contiguous()
                 logits = eng.lm_head(pre_ln)
                 coef = torch.full((k,), 1.0 / k, dtype=torch.float32, device=dev)
-                _, nll, dlog = lib.vocab_rows(logits, labels, coef, want_argmax=False, want_nll=True, want_dlogits=True)
+                _, nll, dlog = lib.vocab_rows(logits, labels, coef, want_argmax=False, want_nll=True, want_dlogits=True,
+                                               dlogits_dtype=eng.adt)
                 loss = float(nll.mean().item())  # the reference syncs here too (loss.item(), ft_vl.py:129-131)
                 self.last_losses.append(loss)
                 n_items = len(chunks[ci])

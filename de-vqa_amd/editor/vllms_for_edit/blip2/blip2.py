@@ -46,13 +46,14 @@ def load_tokenizer(model_path):
 class BLIP2OPTForEdit(BaseVLLMForEdit):
     """For blip2-opt-2.7b (or any BLIP-2-OPT config directory in HF layout)."""
 
-    def __init__(self, model_path: str = None, device="cuda", model: Blip2Native = None, tokenizer=None) -> None:
+    def __init__(self, model_path: str = None, device="cuda", model: Blip2Native = None, tokenizer=None,
+                 dtype="bf16") -> None:
         if not torch.cuda.is_available():
             raise RuntimeError("BLIP2OPTForEdit (HIP path) needs a GPU; there is no CPU fallback in the product path")
         dev = "cuda:0" if device in ("cuda", "auto", 0) else (("cuda:%d" % device) if isinstance(device, int) else device)
         torch.cuda.set_device(dev)
         if model is None:
-            model = Blip2Native.from_pretrained_dir(model_path, dev)
+            model = Blip2Native.from_pretrained_dir(model_path, dev, dtype)
         self.model = model
         self.tokenizer = tokenizer if tokenizer is not None else load_tokenizer(model_path)
         self.image_processor = Blip2ImagePreprocessor(model.cfg["vision_config"]["image_size"])

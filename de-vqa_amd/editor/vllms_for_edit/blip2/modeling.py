@@ -47,8 +47,11 @@ def _attach(root, name, param):
 
 
 class Blip2Native(nn.Module):
-    def __init__(self, cfg, device="cuda"):
+    def __init__(self, cfg, device="cuda", dtype="bf16"):
         super().__init__()
+        assert dtype in ("bf16", "fp32")
+        self.compute_dtype = dtype
+        self.wdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
         self.cfg = cfg
         t = cfg["text_config"]
         self.config = SimpleNamespace(is_encoder_decoder=False, num_query_tokens=cfg["num_query_tokens"],
@@ -69,13 +72,13 @@ class Blip2Native(nn.Module):
             small_f32 = name in ("query_tokens", "vision_model.embeddings.class_embedding",
                                  "vision_model.embeddings.position_embedding",
                                  "vision_model.embeddings.patch_embedding.weight")
-            dt = torch.float32 if (is_vec or small_f32) else torch.bfloat16
+            dt = torch.float32 if (is_vec or small_f32) else self.wdtype
             if ".self_attn." in name and "decoder.layers" in name and any(
                     k in name for k in ("q_proj", "k_proj", "v_proj")):
                 layer = name.split("decoder.layers.")[1].split(".")[0]
                 slot = {"q_proj": 0, "k_proj": 1, "v_proj": 2}[name.split("self_attn.")[1].split(".")[0]]
                 if name.endswith("weight"):
-                    buf = fused_w.setdefault(layer, torch.zeros((3 * d, d), dtype=torch.bfloat16, device=dev))
+                    buf = fused_w.setdefault(layer, torch.zeros((3 * d, d), dtype=self.wdtype, device=dev))
                 else:
                     buf = fused_b.setdefault(layer, torch.zeros((3 * d,), dtype=torch.float32, device=dev))
                 data = buf[slot * d:(slot + 1) * d]
@@ -87,7 +90,7 @@ class Blip2Native(nn.Module):
         v = self.cfg["vision_config"]
         self.patch_kreal = 3 * v["patch_size"] ** 2
         self.patch_kpad = (self.patch_kreal + 31) // 32 * 32
-        self.patch_w_gemm = torch.zeros((v["hidden_size"], self.patch_kpad), dtype=torch.bfloat16, device=dev)
+        self.patch_w_gemm = torch.zeros((v["hidden_size"], self.patch_kpad), dtype=self.wdtype, device=dev)
         self.embed_T = None  # [d, V] bf16 transposed copy of the tied embedding (dH = dlogits . E)
         self._derived_version = None
 
@@ -115,15 +118,15 @@ class Blip2Native(nn.Module):
         if not force and ver == self._derived_version:
             return
         self.patch_w_gemm.zero_()
-        self.patch_w_gemm[:, :self.patch_kreal] = pw.reshape(pw.shape[0], -1).to(torch.bfloat16)
+        self.patch_w_gemm[:, :self.patch_kreal] = pw.reshape(pw.shape[0], -1).to(self.wdtype)
         self.embed_T = emb.t().contiguous()
         self._derived_version = (pw._version, emb._version)
 
     @classmethod
-    def from_pretrained_dir(cls, path, device="cuda"):
+    def from_pretrained_dir(cls, path, device="cuda", dtype="bf16"):
         from safetensors import safe_open
         cfg = json.load(open(os.path.join(path, "config.json")))
-        model = cls(cfg, device)
+        model = cls(cfg, device, dtype)
         files = [f for f in sorted(os.listdir(path)) if f.endswith(".safetensors")]
         if not files:
             raise FileNotFoundError("no *.safetensors under %s" % path)
@@ -146,9 +149,9 @@ class Blip2Native(nn.Module):
         return model
 
     @classmethod
-    def from_synth(cls, cfg, seed, style="opt", device="cuda"):
+    def from_synth(cls, cfg, seed, style="opt", device="cuda", dtype="bf16"):
         from ....synth import param_init
-        model = cls(cfg, device)
+        model = cls(cfg, device, dtype)
         model.load_named_tensors(lambda n: torch.from_numpy(param_init(n, model._shapes[n], seed, style)))
         return model
 

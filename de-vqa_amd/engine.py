@@ -38,6 +38,16 @@ class Blip2Engine:
         self.dev = model.dev
         self.edit_layer = self.t["num_hidden_layers"] - 1
         self._seq_desc_cache = {}
+        # activation dtype follows the model's compute mode: bf16 GEMM operands, or fp32 ("faithful")
+        self.adt = model.wdtype
+        self.want = "bf16" if self.adt == torch.bfloat16 else "f32"
+
+    def _act(self, x32):
+        """fp32 rows -> GEMM operand dtype"""
+        return lib.cast_f32_bf16(x32) if self.adt == torch.bfloat16 else x32
+
+    def _ln(self, x, wname, bname, eps, add=None):
+        return lib.layernorm(x, self._p(wname), self._p(bname), eps, add=add, want=self.want)
 
     # ------------------------------------------------------------------------------------------
     def _w(self, name):
@@ -70,23 +80,23 @@ class Blip2Engine:
         H = v["num_attention_heads"]
         dh = D // H
         eps = v["layer_norm_eps"]
-        cols = lib.im2col_patches(pixels.contiguous(), P, m.patch_kpad)
+        cols = lib.im2col_patches(pixels.contiguous(), P, m.patch_kpad, self.adt)
         patches = lib.gemm(cols, m.patch_w_gemm, self._p("vision_model.embeddings.patch_embedding.bias"), want="f32")
         x = lib.vit_assemble(patches, self._p("vision_model.embeddings.class_embedding"),
                              self._p("vision_model.embeddings.position_embedding"), B, G * G, D)
         desc = self._full_desc(B, N, N)
         for i in range(v["num_hidden_layers"]):
             p = "vision_model.encoder.layers.%d." % i
-            h = lib.layernorm(x, self._p(p + "layer_norm1.weight"), self._p(p + "layer_norm1.bias"), eps)
+            h = self._ln(x, p + "layer_norm1.weight", p + "layer_norm1.bias", eps)
             qkv = lib.gemm(h, self._w(p + "self_attn.qkv.weight"), self._p(p + "self_attn.qkv.bias"))
             att = lib.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], desc, B, N, H, dh, dh ** -0.5, 0)
             lib.gemm(att, self._w(p + "self_attn.projection.weight"), self._p(p + "self_attn.projection.bias"),
                      residual=x, out_f32=x)
-            h = lib.layernorm(x, self._p(p + "layer_norm2.weight"), self._p(p + "layer_norm2.bias"), eps)
+            h = self._ln(x, p + "layer_norm2.weight", p + "layer_norm2.bias", eps)
             f = lib.gemm(h, self._w(p + "mlp.fc1.weight"), self._p(p + "mlp.fc1.bias"), act=lib.ACT_GELU)
             lib.gemm(f, self._w(p + "mlp.fc2.weight"), self._p(p + "mlp.fc2.bias"), residual=x, out_f32=x)
-        img = lib.layernorm(x, self._p("vision_model.post_layernorm.weight"), self._p("vision_model.post_layernorm.bias"),
-                            eps)  # bf16 [B*N, D]: keys/values of every cross-attention
+        img = self._ln(x, "vision_model.post_layernorm.weight", "vision_model.post_layernorm.bias", eps)
+        # [B*N, D] in the operand dtype: keys/values of every cross-attention
         # ---- Q-Former ----
         dq = q["hidden_size"]
         Hq = q["num_attention_heads"]
@@ -104,18 +114,18 @@ class Blip2Engine:
             h32 = self._bert_attention(p + "attention.", h32, None, self_desc, B, Qn, Hq, dhq, qeps)
             if i % q["cross_attention_frequency"] == 0:
                 h32 = self._bert_attention(p + "crossattention.", h32, img, cross_desc, B, Qn, Hq, dhq, qeps)
-            hb = lib.cast_f32_bf16(h32)
+            hb = self._act(h32)
             f = lib.gemm(hb, self._w(p + "intermediate_query.dense.weight"), self._p(p + "intermediate_query.dense.bias"),
                          act=lib.ACT_GELU)
             o = lib.gemm(f, self._w(p + "output_query.dense.weight"), self._p(p + "output_query.dense.bias"), want="f32")
             h32 = lib.layernorm(o, self._p(p + "output_query.LayerNorm.weight"), self._p(p + "output_query.LayerNorm.bias"),
                                 qeps, add=h32, want="f32")
-        hb = lib.cast_f32_bf16(h32)
+        hb = self._act(h32)
         out = lib.gemm(hb, self._w("language_projection.weight"), self._p("language_projection.bias"), want="f32")
         return out.view(B, Qn, -1)
 
     def _bert_attention(self, p, h32, kv_bf16, desc, B, Qn, H, dh, eps):
-        hb = lib.cast_f32_bf16(h32)
+        hb = self._act(h32)
         src = hb if kv_bf16 is None else kv_bf16
         qq = lib.gemm(hb, self._w(p + "attention.query.weight"), self._p(p + "attention.query.bias"))
         kk = lib.gemm(src, self._w(p + "attention.key.weight"), self._p(p + "attention.key.bias"))
@@ -190,14 +200,13 @@ class Blip2Engine:
         last = t["num_hidden_layers"] - 1 if upto_layer is None else upto_layer
         for i in range(last + 1):
             p = "language_model.model.decoder.layers.%d." % i
-            h = lib.layernorm(x, self._p(p + "self_attn_layer_norm.weight"), self._p(p + "self_attn_layer_norm.bias"),
-                              LN_EPS_OPT)
+            h = self._ln(x, p + "self_attn_layer_norm.weight", p + "self_attn_layer_norm.bias", LN_EPS_OPT)
             qkv = lib.gemm(h, self.m.fused_qkv_w[str(i)], self.m.fused_qkv_b[str(i)])
             att = lib.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], ps.desc, n_seq, ps.max_len, H, dh, dh ** -0.5,
-                                1, out=torch.zeros((x.shape[0], d), dtype=torch.bfloat16, device=self.dev))
+                                1, out=torch.zeros((x.shape[0], d), dtype=self.adt, device=self.dev))
             lib.gemm(att, self._w(p + "self_attn.out_proj.weight"), self._p(p + "self_attn.out_proj.bias"), residual=x,
                      out_f32=x)
-            h = lib.layernorm(x, self._p(p + "final_layer_norm.weight"), self._p(p + "final_layer_norm.bias"), LN_EPS_OPT)
+            h = self._ln(x, p + "final_layer_norm.weight", p + "final_layer_norm.bias", LN_EPS_OPT)
             a = lib.gemm(h, self._w(p + "fc1.weight"), self._p(p + "fc1.bias"), act=lib.ACT_RELU)
             if stop_before_fc2 and i == last:
                 return x, a
@@ -207,8 +216,8 @@ class Blip2Engine:
     # K8: final LN + tied lm_head on the given rows -> fp32 logits
     @torch.no_grad()
     def lm_head(self, x_rows, add=None):
-        h = lib.layernorm(x_rows, self._p("language_model.model.decoder.final_layer_norm.weight"),
-                          self._p("language_model.model.decoder.final_layer_norm.bias"), LN_EPS_OPT, add=add)
+        h = self._ln(x_rows, "language_model.model.decoder.final_layer_norm.weight",
+                     "language_model.model.decoder.final_layer_norm.bias", LN_EPS_OPT, add=add)
         return lib.gemm(h, self._p("language_model.model.decoder.embed_tokens.weight"), want="f32")
 
     @torch.no_grad()

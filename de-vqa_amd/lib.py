@@ -40,7 +40,12 @@ def load():
     _sig(L.devqa_last_error, [], ctypes.c_char_p)
     _sig(L.devqa_abi_version, [])
     _sig(L.devqa_gemm_bf16, [P, I64, P, I64, P, I, I, I, F, I, P, P, P, I64, P])
+    _sig(L.devqa_gemm_f32, [P, I64, P, I64, P, I, I, I, F, I, P, P, I64, P])
     _sig(L.devqa_layernorm, [P, P, P, P, I, I, F, P, P, P])
+    _sig(L.devqa_attention_f32, [P, I64, P, I64, P, I64, P, I64, P, I, I, I, I, F, I, P])
+    _sig(L.devqa_im2col_patches_f32, [P, I, I, I, I, P, P])
+    _sig(L.devqa_embed_rows_f32, [P, P, P, P, P, P, I, I, I, I, I, P, P])
+    _sig(L.devqa_vocab_rows_f32, [P, I64, I, I, P, P, P, P, P, I64, P])
     _sig(L.devqa_attention, [P, I64, P, I64, P, I64, P, I64, P, I, I, I, I, F, I, P])
     _sig(L.devqa_im2col_patches, [P, I, I, I, I, P, P])
     _sig(L.devqa_vit_assemble, [P, P, P, I, I, I, P, P])
@@ -59,7 +64,8 @@ def load():
     return L
 
 
-EXPORTS = ["devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_layernorm", "devqa_attention",
+EXPORTS = ["devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
+           "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
            "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
            "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk"]
@@ -88,7 +94,10 @@ def _need(t, dtype, name):
 # thin typed wrappers (shape bookkeeping only; every FLOP happens in the library)
 # ---------------------------------------------------------------------------------------------
 def gemm(a, w, bias=None, alpha=1.0, act=ACT_NONE, residual=None, out_bf16=None, out_f32=None, want="bf16"):
-    """C = epi(a @ w.T). a bf16 [M,K] (row stride may exceed K), w bf16 [N,K]."""
+    """C = epi(a @ w.T). a [M,K] (row stride may exceed K), w [N,K]; both bf16 (MFMA bf16) or both
+    fp32 (exact-fp32 MFMA, "faithful" mode: fp32 output only)."""
+    if a.dtype == torch.float32:
+        return _gemm_f32(a, w, bias, alpha, act, residual, out_f32)
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_cuda and w.is_cuda
     assert a.stride(-1) == 1 and w.stride(-1) == 1 and a.dim() == 2 and w.dim() == 2
     M, K = a.shape
@@ -116,6 +125,22 @@ def gemm(a, w, bias=None, alpha=1.0, act=ACT_NONE, residual=None, out_bf16=None,
     if out_bf16 is not None and out_f32 is not None:
         return out_bf16, out_f32
     return out_bf16 if out_bf16 is not None else out_f32
+
+
+def _gemm_f32(a, w, bias, alpha, act, residual, out_f32):
+    assert w.dtype == torch.float32 and a.is_cuda and w.is_cuda and a.dim() == 2 and w.dim() == 2
+    assert a.stride(-1) == 1 and w.stride(-1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, (a.shape, w.shape)
+    if out_f32 is None:
+        out_f32 = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    for o in (out_f32, residual):
+        if o is not None:
+            assert o.shape == (M, N) and o.is_contiguous() and o.dtype == torch.float32
+    _chk(load().devqa_gemm_f32(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), M, N, K, float(alpha), int(act),
+                               _p(residual), _p(out_f32), N, _stream()), "devqa_gemm_f32")
+    return out_f32
 
 
 def layernorm(x, gamma, beta, eps, add=None, want="bf16"):
@@ -146,22 +171,25 @@ def layernorm_bwd_dx(x, gamma, dy, eps):
 def attention(q, k, v, seq_desc, n_seq, max_q_len, H, dh, scale, causal, out=None):
     """q,k,v: bf16 2-D views (rows x >=H*dh, unit inner stride). seq_desc int32 [n_seq,6] on device."""
     for t in (q, k, v):
-        assert t.dtype == torch.bfloat16 and t.is_cuda and t.dim() == 2 and t.stride(1) == 1
+        assert t.dtype == q.dtype and t.is_cuda and t.dim() == 2 and t.stride(1) == 1
+    assert q.dtype in (torch.bfloat16, torch.float32)
     assert seq_desc.dtype == torch.int32 and seq_desc.is_cuda and seq_desc.is_contiguous()
     if out is None:
-        out = torch.empty((q.shape[0], H * dh), dtype=torch.bfloat16, device=q.device)
-    _chk(load().devqa_attention(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+        out = torch.empty((q.shape[0], H * dh), dtype=q.dtype, device=q.device)
+    fn = load().devqa_attention if q.dtype == torch.bfloat16 else load().devqa_attention_f32
+    _chk(fn(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
                                 _p(seq_desc), int(n_seq), int(max_q_len), int(H), int(dh), float(scale), int(causal),
                                 _stream()), "devqa_attention")
     return out
 
 
-def im2col_patches(pixels, P, Kpad):
+def im2col_patches(pixels, P, Kpad, dtype=torch.bfloat16):
     _need(pixels, torch.float32, "im2col pixels")
     B, C, S, S2 = pixels.shape
     assert C == 3 and S == S2
-    out = torch.empty((B * (S // P) ** 2, Kpad), dtype=torch.bfloat16, device=pixels.device)
-    _chk(load().devqa_im2col_patches(_p(pixels), B, S, P, Kpad, _p(out), _stream()), "devqa_im2col_patches")
+    out = torch.empty((B * (S // P) ** 2, Kpad), dtype=dtype, device=pixels.device)
+    fn = load().devqa_im2col_patches if dtype == torch.bfloat16 else load().devqa_im2col_patches_f32
+    _chk(fn(_p(pixels), B, S, P, Kpad, _p(out), _stream()), "devqa_im2col_patches")
     return out
 
 
@@ -177,7 +205,9 @@ def embed_rows(token, src_row, pos, embed, rows_f32, pos_table):
     D = embed.shape[1]
     out = torch.empty((R, D), dtype=torch.float32, device=embed.device)
     n_rows = 0 if rows_f32 is None else rows_f32.shape[0]
-    _chk(load().devqa_embed_rows(_p(token), _p(src_row), _p(pos), _p(embed), _p(rows_f32), _p(pos_table), R, D,
+    assert embed.dtype == pos_table.dtype and embed.is_contiguous() and pos_table.is_contiguous()
+    fn = load().devqa_embed_rows if embed.dtype == torch.bfloat16 else load().devqa_embed_rows_f32
+    _chk(fn(_p(token), _p(src_row), _p(pos), _p(embed), _p(rows_f32), _p(pos_table), R, D,
                                  embed.shape[0], n_rows, pos_table.shape[0], _p(out), _stream()), "devqa_embed_rows")
     return out
 
@@ -198,14 +228,16 @@ def cast_f32_bf16(x, out=None):
     return out
 
 
-def vocab_rows(logits, labels=None, coef=None, want_argmax=True, want_nll=False, want_dlogits=False):
+def vocab_rows(logits, labels=None, coef=None, want_argmax=True, want_nll=False, want_dlogits=False,
+               dlogits_dtype=torch.bfloat16):
     _need(logits, torch.float32, "vocab_rows logits")
     R, V = logits.shape
     dev = logits.device
     am = torch.empty((R,), dtype=torch.int32, device=dev) if want_argmax else None
     nll = torch.empty((R,), dtype=torch.float32, device=dev) if want_nll else None
-    dl = torch.empty((R, V), dtype=torch.bfloat16, device=dev) if want_dlogits else None
-    _chk(load().devqa_vocab_rows(_p(logits), logits.stride(0), R, V, _p(labels), _p(coef), _p(am), _p(nll), _p(dl), V,
+    dl = torch.empty((R, V), dtype=dlogits_dtype, device=dev) if want_dlogits else None
+    fn = load().devqa_vocab_rows if dlogits_dtype == torch.bfloat16 else load().devqa_vocab_rows_f32
+    _chk(fn(_p(logits), logits.stride(0), R, V, _p(labels), _p(coef), _p(am), _p(nll), _p(dl), V,
                                  _stream()), "devqa_vocab_rows")
     return am, nll, dl
 

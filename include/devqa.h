@@ -56,6 +56,12 @@ int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64
                     int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
                     float* out_f32, int64_t ldc, void* stream);
 
+/* fp32 ("faithful") compute mode: same contract with fp32 operands on the exact-fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32).  Used to pin the HIP path to the reference's fp32 results at 1e-3;
+ * K/lda/ldw % 4 == 0. */
+int devqa_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, int M, int N, int K,
+                   float alpha, int act, const float* residual, float* out_f32, int64_t ldc, void* stream);
+
 /* ---- LayerNorm (every nn.LayerNorm on the path) --------------------------------------------
  * y = (x - mean) * rsqrt(var + eps) * gamma + beta over the last dim, fp32 statistics.
  * x fp32 [M,D]; optional add: x := x + add (fp32 [M,D], BERT-style post-LN residual,
@@ -82,12 +88,17 @@ int devqa_attention(const devqa_bf16* q, int64_t ldq, const devqa_bf16* k, int64
                     int64_t ldv, devqa_bf16* out, int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len,
                     int H, int dh, float scale, int causal, void* stream);
 
+int devqa_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out,
+                        int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale,
+                        int causal, void* stream);
+
 /* ---- K2 patch-embed staging ---------------------------------------------------------------
  * im2col for Conv2d(3->D, k=P, s=P): pixels fp32 [B,3,S,S] -> bf16 [B*(S/P)^2, Kpad] with
  * column (c*P+py)*P+px, zero padded to Kpad (Kpad % 8 == 0).  HF Blip2VisionEmbeddings,
  * reached from blip2.py:25-31.
  */
 int devqa_im2col_patches(const float* pixels, int B, int S, int P, int Kpad, devqa_bf16* out, void* stream);
+int devqa_im2col_patches_f32(const float* pixels, int B, int S, int P, int Kpad, float* out, void* stream);
 /* x[b,0,:] = cls + pos[0]; x[b,1+p,:] = patches[b*np+p,:] + pos[1+p]  (fp32 [B,np+1,D]) */
 int devqa_vit_assemble(const float* patches, const float* cls, const float* pos, int B, int np, int D, float* out,
                        void* stream);
@@ -101,6 +112,9 @@ int devqa_vit_assemble(const float* patches, const float* cls, const float* pos,
 int devqa_embed_rows(const int32_t* token, const int32_t* src_row, const int32_t* pos, const devqa_bf16* embed,
                      const float* rows_f32, const devqa_bf16* pos_table, int R, int D, int V, int n_rows_f32,
                      int n_pos, float* out, void* stream);
+int devqa_embed_rows_f32(const int32_t* token, const int32_t* src_row, const int32_t* pos, const float* embed,
+                         const float* rows_f32, const float* pos_table, int R, int D, int V, int n_rows_f32, int n_pos,
+                         float* out, void* stream);
 
 /* gather rows: out[r,:] = in[idx[r],:] (fp32 or bf16 by elem_bytes 4/2) */
 int devqa_gather_rows(const void* in, const int32_t* idx, int R, int D, int elem_bytes, void* out, void* stream);
@@ -117,6 +131,8 @@ int devqa_cast_f32_bf16(const float* in, devqa_bf16* out, int64_t n, void* strea
  */
 int devqa_vocab_rows(const float* logits, int64_t ldl, int R, int V, const int32_t* labels, const float* coef,
                      int32_t* argmax_out, float* nll_out, devqa_bf16* dlogits, int64_t ldd, void* stream);
+int devqa_vocab_rows_f32(const float* logits, int64_t ldl, int R, int V, const int32_t* labels, const float* coef,
+                         int32_t* argmax_out, float* nll_out, float* dlogits, int64_t ldd, void* stream);
 
 /* LayerNorm backward w.r.t. the input only: dx from dy, for rows x fp32 [M,D] (gamma fp32 [D]). */
 int devqa_layernorm_bwd_dx(const float* x, const float* gamma, const float* dy, int M, int D, float eps, float* dx,
