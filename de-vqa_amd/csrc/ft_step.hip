@@ -141,7 +141,7 @@ extern "C" int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0
                                    void* stream) {
     DEVQA_CHECK_ARG(w && m && v && w0 && a && dy && y && do_update && adam_t, "ft_adamw_step: null pointer");
     if (E == 0) return DEVQA_OK;
-    DEVQA_CHECK_SHAPE(E > 0 && Lmax >= 1 && Lmax <= 8, "ft_adamw_step: Lmax=%d unsupported (1..8)", Lmax);
+    DEVQA_CHECK_SHAPE(E > 0 && Lmax >= 1 && Lmax <= 16, "ft_adamw_step: Lmax=%d unsupported (1..16)", Lmax);
     DEVQA_CHECK_SHAPE(Dout > 0 && Din > 0 && Din % 4 == 0, "ft_adamw_step: bad matrix dims %dx%d", Dout, Din);
     DEVQA_CHECK_SHAPE((long)E * ((Dout + 1) / 2) < 2147483647L, "ft_adamw_step: grid too large");
     hipStream_t st = (hipStream_t)stream;
@@ -149,7 +149,8 @@ extern "C" int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0
     if (Lmax <= 1) return launch_adamw<1, 4>(ARGS);
     if (Lmax <= 2) return launch_adamw<2, 4>(ARGS);
     if (Lmax <= 4) return launch_adamw<4, 2>(ARGS);
-    return launch_adamw<8, 2>(ARGS);
+    if (Lmax <= 8) return launch_adamw<8, 2>(ARGS);
+    return launch_adamw<16, 1>(ARGS);
 #undef ARGS
 }
 
@@ -211,7 +212,7 @@ extern "C" int devqa_rows_matvec_f32(const float* w, int64_t w_stride_e, const f
                                      const float* resid, float* y, int E, int L, int Dout, int Din, void* stream) {
     DEVQA_CHECK_ARG(w && a && y, "rows_matvec: null pointer");
     if (E == 0 || L == 0) return DEVQA_OK;
-    DEVQA_CHECK_SHAPE(E > 0 && L >= 1 && L <= 8, "rows_matvec: L=%d unsupported (1..8)", L);
+    DEVQA_CHECK_SHAPE(E > 0 && L >= 1 && L <= 16, "rows_matvec: L=%d unsupported (1..16)", L);
     DEVQA_CHECK_SHAPE(Dout > 0 && Din > 0 && Din % 4 == 0, "rows_matvec: bad matrix dims");
     hipStream_t st = (hipStream_t)stream;
     constexpr int ROWS = 4;
@@ -223,8 +224,11 @@ extern "C" int devqa_rows_matvec_f32(const float* w, int64_t w_stride_e, const f
     else if (L <= 4)
         hipLaunchKernelGGL((rows_matvec_kernel<4, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, a, bias,
                            resid, y, L, Dout, Din, row_blocks);
-    else
+    else if (L <= 8)
         hipLaunchKernelGGL((rows_matvec_kernel<8, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, a, bias,
+                           resid, y, L, Dout, Din, row_blocks);
+    else
+        hipLaunchKernelGGL((rows_matvec_kernel<16, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, a, bias,
                            resid, y, L, Dout, Din, row_blocks);
     DEVQA_LAUNCH_CHECK("rows_matvec");
     return DEVQA_OK;

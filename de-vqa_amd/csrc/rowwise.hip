@@ -96,7 +96,8 @@ extern "C" int devqa_layernorm(const float* x, const float* add, const float* ga
 // LayerNorm backward w.r.t. input:  xhat=(x-mean)*rstd, gy=dy*gamma,
 //   dx = rstd * (gy - mean(gy) - xhat*mean(gy*xhat))
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                               const float* __restrict__ gamma,
                                                                const float* __restrict__ dy, int M, int D, float eps,
                                                                float* __restrict__ dx) {
     const int lane = threadIdx.x & 63;
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
     const int nv = D >> 2;
     const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
     const float4* dr = reinterpret_cast<const float4*>(dy + (int64_t)row * D);
+    const float4* ar = add ? reinterpret_cast<const float4*>(add + (int64_t)row * D) : nullptr;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     float4 v[LN_MAXV], gy[LN_MAXV];
     float s = 0.f;
@@ -113,6 +115,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
         const int c = i * 64 + lane;
         if (c < nv) {
             v[i] = xr[c];
+            if (ar) {
+                const float4 u = ar[c];
+                v[i].x += u.x; v[i].y += u.y; v[i].z += u.z; v[i].w += u.w;
+            }
             const float4 d = dr[c], g = g4[c];
             gy[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -157,13 +163,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
     }
 }
 
-extern "C" int devqa_layernorm_bwd_dx(const float* x, const float* gamma, const float* dy, int M, int D, float eps,
-                                      float* dx, void* stream) {
+extern "C" int devqa_layernorm_bwd_dx(const float* x, const float* add, const float* gamma, const float* dy, int M, int D,
+                                      float eps, float* dx, void* stream) {
     DEVQA_CHECK_ARG(x && gamma && dy && dx, "layernorm_bwd_dx: null pointer");
     if (M == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "layernorm_bwd_dx: D=%d unsupported", D);
-    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, M, D,
-                       eps, dx);
+    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, gamma, dy, M,
+                       D, eps, dx);
     DEVQA_LAUNCH_CHECK("layernorm_bwd_dx");
     return DEVQA_OK;
 }

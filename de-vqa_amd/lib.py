@@ -53,7 +53,7 @@ def load():
     _sig(L.devqa_gather_rows, [P, P, I, I, I, P, P])
     _sig(L.devqa_cast_f32_bf16, [P, P, I64, P])
     _sig(L.devqa_vocab_rows, [P, I64, I, I, P, P, P, P, P, I64, P])
-    _sig(L.devqa_layernorm_bwd_dx, [P, P, P, I, I, F, P, P])
+    _sig(L.devqa_layernorm_bwd_dx, [P, P, P, P, I, I, F, P, P])
     _sig(L.devqa_ft_adamw_step, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, P])
     _sig(L.devqa_rows_matvec_f32, [P, I64, P, P, P, P, I, I, I, I, P])
     _sig(L.devqa_delta_op, [I, P, P, P, I64, P])
@@ -158,12 +158,15 @@ def layernorm(x, gamma, beta, eps, add=None, want="bf16"):
     return ob if ob is not None else of
 
 
-def layernorm_bwd_dx(x, gamma, dy, eps):
+def layernorm_bwd_dx(x, gamma, dy, eps, add=None):
     _need(x, torch.float32, "ln_bwd x")
     _need(dy, torch.float32, "ln_bwd dy")
     M, D = x.shape
     dx = torch.empty_like(x)
-    _chk(load().devqa_layernorm_bwd_dx(_p(x), _p(gamma), _p(dy), M, D, float(eps), _p(dx), _stream()),
+    if add is not None:
+        _need(add, torch.float32, "ln_bwd add")
+        assert add.shape == x.shape
+    _chk(load().devqa_layernorm_bwd_dx(_p(x), _p(add), _p(gamma), _p(dy), M, D, float(eps), _p(dx), _stream()),
          "devqa_layernorm_bwd_dx")
     return dx
 

@@ -134,9 +134,9 @@ int devqa_vocab_rows(const float* logits, int64_t ldl, int R, int V, const int32
 int devqa_vocab_rows_f32(const float* logits, int64_t ldl, int R, int V, const int32_t* labels, const float* coef,
                          int32_t* argmax_out, float* nll_out, float* dlogits, int64_t ldd, void* stream);
 
-/* LayerNorm backward w.r.t. the input only: dx from dy, for rows x fp32 [M,D] (gamma fp32 [D]). */
-int devqa_layernorm_bwd_dx(const float* x, const float* gamma, const float* dy, int M, int D, float eps, float* dx,
-                           void* stream);
+/* LayerNorm backward w.r.t. the input only: dx from dy, for rows (x [+ add]) fp32 [M,D], gamma fp32 [D]. */
+int devqa_layernorm_bwd_dx(const float* x, const float* add, const float* gamma, const float* dy, int M, int D, float eps,
+                           float* dx, void* stream);
 
 /* ---- K10/K11/K12: fused FT_VL inner step on the edited matrix ---------------------------------
  * One launch per optimiser step, batched over E concurrent edits that each own a private
@@ -154,7 +154,7 @@ int devqa_layernorm_bwd_dx(const float* x, const float* gamma, const float* dy, 
  *   w,m,v : fp32 [E][Dout][Din]      w0 : fp32 [Dout][Din]
  *   a     : fp32 [E][Lmax][Din]      dy : fp32 [E][Lmax][Dout]     y : fp32 [E][Lmax][Dout]
  *   do_update, adam_t : int32 [E] (device, from devqa_ft_step_control)
- *   clamp_eps < 0 disables the clamp.  1 <= Lmax <= 8, Din % 4 == 0.
+ *   clamp_eps < 0 disables the clamp.  1 <= Lmax <= 16, Din % 4 == 0.
  */
 int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
                         const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,

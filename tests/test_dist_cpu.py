@@ -1,0 +1,66 @@
+"""world_size-2 gloo (CPU) test of the N>1 path: contiguous split sharding and the single gather of
+per-cycle score rows (device collective) + result dicts (host gather)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fake_result(i):
+    acc = (i % 5) / 4.0
+    loc = {n: [{"acc": acc, "predict_after_edit": "p%d" % i, "predict_before_edit": "b%d" % i}]
+           for n in ["text_loc", "t3i3", "t1i4", "t2i4", "t1i2", "t1i3", "t2i1", "t2i2", "t3i1"]}
+    return {"reliability": [{"acc": acc, "edit_time": 0.01 * i, "predict_after_edit": "r%d" % i}],
+            "generality": {"text_rephrase": [{"acc": acc}], "image_rephrase": [{"acc": 1 - acc}]}, "locality": loc}
+
+
+def _worker(rank, world, n, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import devqa_amd  # noqa: F401
+    from devqa_amd.batched import BatchedEditEval, shard_range
+    from devqa_amd.dist import gather_results, init_from_env
+    r, w = init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    lo, hi = shard_range(n, rank, world)
+    local = [_fake_result(i) for i in range(lo, hi)]
+    rows = BatchedEditEval.score_rows(local, [(25, 0.5)] * len(local), lo)
+    allres = gather_results(local, rows, n, rank, world, torch.device("cpu"))
+    if rank == 0:
+        q.put([r_["reliability"][0]["predict_after_edit"] for r_ in allres])
+    else:
+        assert allres is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 8, 1])
+def test_shard_and_gather_world2(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + n) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, n, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out == ["r%d" % i for i in range(n)]  # concatenation in rank order == reference sample order
+
+
+def test_shard_range_partitions():
+    from devqa_amd.batched import shard_range
+    for n in (0, 1, 7, 8, 1000):
+        for w in (1, 2, 4, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
