@@ -41,6 +41,16 @@ def shard_range(n, rank, world):
     return (rank * n) // world, ((rank + 1) * n) // world
 
 
+def copy_sample(d):
+    """Structural copy of a sample dict that keeps leaf objects (image tensors / paths, token lists)
+    shared -- the evaluator's deepcopy of result data without cloning device tensors."""
+    if isinstance(d, dict):
+        return {k: copy_sample(v) for k, v in d.items()}
+    if isinstance(d, list) and d and isinstance(d[0], dict):
+        return [copy_sample(v) for v in d]
+    return d
+
+
 class _Probe:
     __slots__ = ("kind", "name", "seq", "L", "labels", "mask", "row0", "rd", "ed", "before_ids")
 
@@ -120,7 +130,18 @@ class BatchedEditEval:
         return self.vllm.tokenizer(s)["input_ids"]
 
     def _probe_seq(self, prompt, target):
-        """xym bookkeeping for one (prompt, target): -> (token ids, labels [L], mask [L])."""
+        """xym bookkeeping for one (prompt, target): -> (token ids, labels [L], mask [L]).
+        Pre-tokenised inputs (lists of ids; synthetic benchmark data) follow the same rule as
+        R/editor/vllms_for_edit/base.py:97-108: labels = roll(ids,-1), mask[len(prompt)-1:-1] = 1,
+        both cropped to [len(prompt)-1:]."""
+        if isinstance(prompt, (list, tuple)):
+            ids = list(prompt) + list(target)
+            n_p = len(prompt)
+            lab = ids[1:] + ids[:1]
+            msk = [0] * len(ids)
+            for j in range(n_p - 1, len(ids) - 1):
+                msk[j] = 1
+            return ids, lab[n_p - 1:], msk[n_p - 1:]
         strs, y, m, _ = self.vllm.xym_token_bookkeeping([prompt], [target])
         return self._tok(strs[0]), y[0].tolist(), m[0].tolist()
 
@@ -139,7 +160,7 @@ class BatchedEditEval:
         def img_id(path):
             if path is None:
                 return None
-            key = path if isinstance(path, str) else id(path)
+            key = path if isinstance(path, str) else ("obj", id(path))
             if key not in img_index:
                 img_index[key] = len(img_list)
                 img_list.append(path)
@@ -175,7 +196,9 @@ class BatchedEditEval:
             probes.append(plist)
             # the edit request (ft_vl.py:72-75: a leading space is forced on the target)
             req = ed["requests"][0]
-            tgt = req["target_new"] if req["target_new"][0] == " " else " " + req["target_new"]
+            tgt = req["target_new"]
+            if isinstance(tgt, str) and tgt[0] != " ":
+                tgt = " " + tgt
             ids, y, m = self._probe_seq(req["prompt"], tgt)
             rows = [j for j in range(len(y)) if m[j] != 0]
             edits.append((seq_id(img_id(req["image"]), ids), len(y), rows, [y[j] for j in rows]))
@@ -184,8 +207,11 @@ class BatchedEditEval:
             raise NotImplementedError("batched FT_VL supports <= 16 target tokens per edit (got %d)" % kmax)
         # pixels (host decode, as the reference) -> device
         if img_list:
-            pix = np.stack([vllm.load_pixels(p) for p in img_list])
-            pix = torch.from_numpy(pix).to(dev, non_blocking=True)
+            if all(isinstance(p, torch.Tensor) for p in img_list):
+                pix = torch.stack(img_list)   # already-preprocessed pixel_values resident in HBM
+            else:
+                pix = np.stack([vllm.load_pixels(p) for p in img_list])
+                pix = torch.from_numpy(pix).to(dev, non_blocking=True)
         t1 = time.time()
         self.stats["t_host"] += t1 - t0
         # ---- 2. vision ---------------------------------------------------------------------------

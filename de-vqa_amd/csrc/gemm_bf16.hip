@@ -154,6 +154,51 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(
     }
 }
 
+// ---- optional per-launch timing for bench.py's roofline (HIP events on the launch stream) ----------
+#include <vector>
+#define PROF_VARIANTS 4
+#define PROF_MAX_PAIRS 49152
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_prof_ev;       // pairs: start, stop
+static std::vector<int> g_prof_variant;
+static std::vector<double> g_prof_flops;
+static size_t g_prof_used = 0;
+
+extern "C" int devqa_profile_gemm(int enable) {
+    if (enable) {
+        if (g_prof_ev.empty()) {
+            g_prof_ev.resize(2 * PROF_MAX_PAIRS);
+            for (auto& e : g_prof_ev)
+                if (hipEventCreate(&e) != hipSuccess) return devqa_fail(DEVQA_E_HIP, "profile: hipEventCreate failed");
+            g_prof_variant.resize(PROF_MAX_PAIRS);
+            g_prof_flops.resize(PROF_MAX_PAIRS);
+        }
+        g_prof_used = 0;
+    }
+    g_prof_on = enable != 0;
+    return DEVQA_OK;
+}
+// Synchronises on the recorded events.  Arrays of PROF_VARIANTS entries: variant 0 = 32x128 tile,
+// 1 = 64x128, 2 = 128x128 (kernel names gemm_bf16_tn_kernel<BM,BN,..>).
+extern "C" int devqa_profile_gemm_read(double* ms, double* flops, int64_t* launches) {
+    for (int i = 0; i < PROF_VARIANTS; ++i) {
+        ms[i] = 0.0;
+        flops[i] = 0.0;
+        launches[i] = 0;
+    }
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess) return devqa_fail(DEVQA_E_HIP, "profile: event sync");
+        if (hipEventElapsedTime(&t, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess)
+            return devqa_fail(DEVQA_E_HIP, "profile: elapsed");
+        const int v = g_prof_variant[i];
+        ms[v] += t;
+        flops[v] += g_prof_flops[i];
+        launches[v] += 1;
+    }
+    return DEVQA_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N,
                        int K, float alpha, int act, const float* residual, bf16_t* out_bf16, float* out_f32,
@@ -166,8 +211,16 @@ static int launch_gemm(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ld
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
+    const bool prof = g_prof_on && g_prof_used < PROF_MAX_PAIRS;
+    if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_used], st);
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, st, A, lda, W, ldw, bias, M, N, K, alpha, act,
                        residual, out_bf16, out_f32, ldc, tiles_m, tiles_n);
+    if (prof) {
+        (void)hipEventRecord(g_prof_ev[2 * g_prof_used + 1], st);
+        g_prof_variant[g_prof_used] = BM == 32 ? 0 : (BM == 64 ? 1 : 2);
+        g_prof_flops[g_prof_used] = 2.0 * (double)M * (double)N * (double)K;
+        ++g_prof_used;
+    }
     DEVQA_LAUNCH_CHECK("gemm_bf16");
     return DEVQA_OK;
 }

@@ -102,13 +102,14 @@ class Blip2Native(nn.Module):
 
     # -- loading --------------------------------------------------------------------------------
     @torch.no_grad()
-    def load_named_tensors(self, get_tensor, names=None):
+    def load_named_tensors(self, get_tensor, names=None, refresh=True):
         """get_tensor(name) -> CPU/GPU tensor (any float dtype) for each HF name."""
         for name in (names or self._shapes.keys()):
             src = get_tensor(name)
             dst = self.get(name)
             dst.copy_(src.to(dst.device).reshape(dst.shape).to(dst.dtype))
-        self.refresh_derived(force=True)
+        if refresh:
+            self.refresh_derived(force=True)
 
     @torch.no_grad()
     def refresh_derived(self, force=False):

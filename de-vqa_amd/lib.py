@@ -41,6 +41,8 @@ def load():
     _sig(L.devqa_abi_version, [])
     _sig(L.devqa_gemm_bf16, [P, I64, P, I64, P, I, I, I, F, I, P, P, P, I64, P])
     _sig(L.devqa_gemm_f32, [P, I64, P, I64, P, I, I, I, F, I, P, P, I64, P])
+    _sig(L.devqa_profile_gemm, [I])
+    _sig(L.devqa_profile_gemm_read, [P, P, P])
     _sig(L.devqa_layernorm, [P, P, P, P, I, I, F, P, P, P])
     _sig(L.devqa_attention_f32, [P, I64, P, I64, P, I64, P, I64, P, I, I, I, I, F, I, P])
     _sig(L.devqa_im2col_patches_f32, [P, I, I, I, I, P, P])
@@ -64,11 +66,24 @@ def load():
     return L
 
 
-EXPORTS = ["devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
+EXPORTS = ["devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
            "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
            "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk"]
+
+
+def profile_gemm(enable):
+    _chk(load().devqa_profile_gemm(int(enable)), "devqa_profile_gemm")
+
+
+def profile_gemm_read():
+    """-> list of (ms, flops, launches) per tile variant [32x128, 64x128, 128x128, -]"""
+    ms = (ctypes.c_double * 4)()
+    fl = (ctypes.c_double * 4)()
+    ln = (ctypes.c_int64 * 4)()
+    _chk(load().devqa_profile_gemm_read(ms, fl, ln), "devqa_profile_gemm_read")
+    return [(ms[i], fl[i], ln[i]) for i in range(4)]
 
 
 def _chk(rc, name):

@@ -46,3 +46,66 @@ def param_init(name: str, shape, seed: int = 20251121, style: str = "unit") -> n
         fan_in = int(np.prod(shape[1:]))
         return (0.8 / np.sqrt(fan_in) * z).astype(np.float32)
     return (0.02 * z).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# EVQA-shaped synthetic cycles (SURVEY.md 8(d) "Synthetic inputs")
+# ---------------------------------------------------------------------------------------------
+class IdTokenizer:
+    """Stand-in tokenizer for pre-tokenised synthetic data (there is no 50272-entry vocabulary
+    offline): prompts/targets are lists of token ids; decode prints the ids."""
+    pad_token_id = 1
+    eos_token_id = 2
+    padding_side = "right"
+
+    def decode(self, ids):
+        return " ".join(str(int(i)) for i in ids)
+
+
+def evqa_cycles(n, vocab=50272, seed=20251121, image_of=None):
+    """n synthetic samples with the probe structure of R/dataset/vllm.py:121-254.
+    Prompts/targets are token-id lists (prompt incl. the BOS id 2 and the 4-token ' The answer is:'
+    suffix; text_loc one more for '?').  `image_of(sample, tag)` supplies the image object for tag in
+    {i1, ir, i2, i3} (default: the string key 's<k>_<tag>').  Returns a list of dicts in the
+    `BaseVLLMEditData` layout (requests / generality / locality)."""
+    rng = np.random.default_rng(seed)
+    SUFFIX = [int(t) for t in rng.integers(4, vocab, 4)]  # one fixed 4-token suffix, like ' The answer is:'
+    QMARK = int(rng.integers(4, vocab))
+
+    def prompt(extra=0):
+        ln = int(np.clip(np.round(rng.normal(14, 3)), 8, 28))
+        body = [int(t) for t in rng.integers(4, vocab, max(ln - 5, 1))]
+        return [2] + body + SUFFIX + ([QMARK] if extra else [])
+
+    def target(k):
+        return [int(t) for t in rng.integers(4, vocab, k)]
+    out = []
+    for s in range(n):
+        img = (lambda tag: image_of(s, tag)) if image_of else (lambda tag: "s%d_%s" % (s, tag))
+        P1, P2, P4, P5, P6 = prompt(), prompt(), prompt(), prompt(1), prompt()
+        P3 = [2] + [int(t) for t in rng.integers(4, vocab, 12)] + SUFFIX  # an image path used as text
+        A = target(int(rng.choice([1, 2, 3], p=[0.7, 0.2, 0.1])))
+        B = target(int(rng.choice([1, 2, 3], p=[0.7, 0.2, 0.1])))
+        C = target(int(np.clip(rng.geometric(0.3), 1, 16)))
+        i1, ir, i2, i3 = img("i1"), img("ir"), img("i2"), img("i3")
+        out.append({
+            "requests": [{"image": i1, "prompt": P1, "target_new": A}],
+            "generality": {"text_rephrase": [{"image": i1, "prompt": P4, "target": A}],
+                           "image_rephrase": [{"image": ir, "prompt": P1, "target": A}]},
+            "locality": {"text_loc": [{"image": None, "prompt": P5, "target": C}],
+                         "t3i3": [{"image": i3, "prompt": P6, "target": B}],
+                         "t1i4": [{"image": None, "prompt": P1, "target": A}],
+                         "t2i4": [{"image": None, "prompt": P2, "target": A}],
+                         "t1i2": [{"image": i2, "prompt": P1, "target": A}],
+                         "t1i3": [{"image": i3, "prompt": P1, "target": A}],
+                         "t2i1": [{"image": i1, "prompt": P2, "target": A}],
+                         "t2i2": [{"image": i2, "prompt": P2, "target": A}],
+                         "t3i1": [{"image": i1, "prompt": P3, "target": B}]},
+        })
+    return out
+
+
+def synth_image_u8(sample, tag, size=224, seed=20251121):
+    """uint8 [size,size,3] i.i.d. U{0..255} image for (sample, tag)."""
+    rng = np.random.default_rng([seed, sample, zlib.crc32(tag.encode())])
+    return rng.integers(0, 256, size=(size, size, 3), dtype=np.uint8)

@@ -56,6 +56,13 @@ int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64
                     int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
                     float* out_f32, int64_t ldc, void* stream);
 
+/* Measurement hook for bench.py's roofline: when enabled, every devqa_gemm_bf16 launch is bracketed by
+ * HIP events on its own stream (up to 49152 launches).  _read synchronises on them and returns, per tile
+ * variant (0: 32x128, 1: 64x128, 2: 128x128; arrays of 4), the summed kernel time (ms), the summed useful
+ * FLOPs (2*M*N*K) and the launch count.  Not part of the data path. */
+int devqa_profile_gemm(int enable);
+int devqa_profile_gemm_read(double* ms, double* flops, int64_t* launches);
+
 /* fp32 ("faithful") compute mode: same contract with fp32 operands on the exact-fp32 MFMA
  * (v_mfma_f32_16x16x4_f32).  Used to pin the HIP path to the reference's fp32 results at 1e-3;
  * K/lda/ldw % 4 == 0. */

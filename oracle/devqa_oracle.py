@@ -59,8 +59,8 @@ def _lin(x, w, b=None):
 class OracleBlip2:
     """BLIP-2-OPT forward on a flat {hf_param_name: tensor} dict (fp32, CPU)."""
 
-    def __init__(self, weights, cfg, tokenizer):
-        self.w = {k: v.detach().to(torch.float32).clone() for k, v in weights.items()}
+    def __init__(self, weights, cfg, tokenizer, copy=True):
+        self.w = {k: (v.detach().to(torch.float32).clone() if copy else v) for k, v in weights.items()}
         self.cfg = cfg
         self.tok = tokenizer
         v, q, t = cfg["vision_config"], cfg["qformer_config"], cfg["text_config"]
