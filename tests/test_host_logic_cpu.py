@@ -1,0 +1,110 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no HIP compute)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import devqa_amd  # noqa: F401
+
+
+def test_config_surface_matches_reference_yaml():
+    from devqa_amd.editor.vllm_editors.ft_vl.ft_vl import FTvlConfig
+    from devqa_amd.utils import get_editor_config_path, get_full_model_name
+    assert get_full_model_name("BLIP2") == "blip2-opt-2.7b"
+    cfg = FTvlConfig.from_yaml(get_editor_config_path("FT_VL", "blip2"))
+    # values of R/configs/ft_vl/blip2-opt-2.7b.yaml:1-8
+    assert cfg.to_dict() == {"edit_model_name": "blip2-opt-2.7b", "rewrite_module_tmp": "language_model.model.decoder.layers.{}.fc2.weight",
+                             "layers": [31], "num_steps": 25, "lr": 1e-3, "weight_decay": 0, "norm_constraint": False,
+                             "batch_size": 1}
+    assert type(cfg.norm_constraint) is not float  # YAML `false` disables the clamp (ft_vl.py:135)
+
+
+def test_param_names_match_hf_blip2(gold_dir):
+    """The HF parameter-name contract: our spec enumerates exactly the tensors of the reference-saved checkpoint."""
+    from safetensors import safe_open
+    from devqa_amd.blip2_spec import param_shapes
+    cfg = json.load(open(os.path.join(gold_dir, "tiny_blip2", "config.json")))
+    shapes = param_shapes(cfg)
+    with safe_open(os.path.join(gold_dir, "tiny_blip2", "model.safetensors"), framework="pt") as f:
+        keys = {k: tuple(f.get_slice(k).get_shape()) for k in f.keys()}
+    keys.pop("language_model.lm_head.weight", None)
+    assert {k: tuple(v) for k, v in shapes.items()} == keys
+
+
+def test_split_data_drops_incomplete_tail():
+    from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation
+    data = [{"requests": [0]} for _ in range(7)]
+    s, ns = VLLMEditorEvaluation.split_data(data, 3)
+    assert [len(x) for x in s] == [3, 3] and ns == [3, 3]
+    s, ns = VLLMEditorEvaluation.split_data(data, 1)
+    assert len(s) == 7
+
+
+def test_probe_builder_and_evqa_suffixes(gold_dir):
+    from devqa_amd.dataset.vllm import build_probes, SUFFIX
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))
+    raw, gold = rec["raw"], rec["records"]
+    n = len(raw)
+    retrieved = [([raw[(i + 1) % n]["src"], raw[(i + 1) % n]["alt"]], gold[i]["locality"]["t1i2"][0]["image"]) for i in range(n)]
+    probes = build_probes(raw, "", retrieved)
+    for p, g, d in zip(probes, gold, raw):
+        assert list(p["locality"].keys()) == list(g["locality"].keys())
+        assert p["locality"]["t3i1"][0]["prompt"] == d["m_loc"]            # image path used as text
+        assert p["requests"][0]["prompt"] + SUFFIX == g["requests"][0]["prompt"]
+        for name in g["locality"]:
+            want = g["locality"][name][0]["prompt"]
+            got = p["locality"][name][0]["prompt"] + SUFFIX + ("?" if name == "text_loc" else "")
+            assert got == want and p["locality"][name][0]["target"] == g["locality"][name][0]["target"]
+
+
+def test_pretokenised_probe_rule_matches_string_rule(gold_dir):
+    """BatchedEditEval._probe_seq on id lists == the roll/mask/crop rule pinned by golden G1."""
+    from devqa_amd.batched import BatchedEditEval
+    j = json.load(open(os.path.join(gold_dir, "tiny_goldens.json")))
+    from tokenizers import Tokenizer
+    tk = Tokenizer.from_file(os.path.join(gold_dir, "tiny_blip2", "tokenizer.json"))
+    be = BatchedEditEval.__new__(BatchedEditEval)
+    for g in j["g1"]:
+        p, t = g["prompt"], g["target"]
+        if p[-1] not in " \n" and t[0] not in " \n":
+            t = " " + t
+        pid = tk.encode(p).ids
+        full = tk.encode(p + t).ids
+        if full[:len(pid)] != pid:
+            continue  # BPE merge across the boundary: rule is defined on strings only
+        ids, y, m = be._probe_seq(pid, full[len(pid):])
+        assert ids == full and [y] == g["label_ids"] and [m] == g["label_masks"]
+
+
+def test_synth_cycles_shape():
+    from devqa_amd.synth import evqa_cycles
+    cyc = evqa_cycles(50, seed=3)
+    ks = [len(c["requests"][0]["target_new"]) for c in cyc]
+    assert set(ks) <= {1, 2, 3} and ks.count(1) > 25
+    for c in cyc:
+        assert len(c["locality"]) == 9 and len(c["generality"]) == 2
+        assert 8 <= len(c["requests"][0]["prompt"]) <= 28 and c["requests"][0]["prompt"][0] == 2
+        assert c["locality"]["text_loc"][0]["image"] is None and c["locality"]["t1i4"][0]["image"] is None
+        assert c["locality"]["t2i1"][0]["image"] == c["requests"][0]["image"]
+
+
+def test_product_never_imports_oracle():
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(root, "de-vqa_amd")):
+        for f in fs:
+            if f.endswith(".py") and f != "smoke.py":
+                src = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle", src, re.M):
+                    bad.append(f)
+    assert bad == []
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from devqa_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(lib.DevqaError):
+        lib.load()
