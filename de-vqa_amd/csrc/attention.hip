@@ -5,6 +5,7 @@
 // 4 waves x 4 query rows.  Keys/values stream through LDS in 64-key chunks (bf16 -> fp32, row
 // stride dh+1 so that lane=key reads are bank-conflict free); scores use lane = key, the PV
 // product uses lane = output channel; online softmax in fp32 (running max / sum per query row).
+#include <stdlib.h>
 #include "common.h"
 
 #define ATT_QT 16     // query rows per workgroup
@@ -165,6 +166,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
     }
 }
 
+static inline bool h_aligned(int H, int dh) { (void)H; return (dh * 2) % 16 == 0; }
+
 template <typename T>
 static int launch_attention(const T* q, int64_t ldq, const T* k, int64_t ldk, const T* v, int64_t ldv, T* out, int64_t ldo,
                             const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale, int causal,
@@ -192,11 +195,29 @@ static int launch_attention(const T* q, int64_t ldq, const T* k, int64_t ldk, co
     return DEVQA_OK;
 }
 
+int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t ldk, const bf16_t* v, int64_t ldv, bf16_t* out,
+                          int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale,
+                          int causal, void* stream);  // attention_mfma.hip
+
+// bf16: MFMA flash attention (attention_mfma.hip).  DEVQA_ATTENTION_VALU=1 selects the v1 VALU kernel
+// (kept as an in-library cross-check; same results up to fp reassociation).
 extern "C" int devqa_attention(const devqa_bf16* q, int64_t ldq, const devqa_bf16* k, int64_t ldk, const devqa_bf16* v,
                                int64_t ldv, devqa_bf16* out, int64_t ldo, const int32_t* seq_desc, int n_seq,
                                int max_q_len, int H, int dh, float scale, int causal, void* stream) {
-    return launch_attention<bf16_t>(q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, n_seq, max_q_len, H, dh, scale, causal,
-                                    stream);
+    static const bool use_valu = getenv("DEVQA_ATTENTION_VALU") != nullptr;
+    if (use_valu)
+        return launch_attention<bf16_t>(q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, n_seq, max_q_len, H, dh, scale, causal,
+                                        stream);
+    DEVQA_CHECK_ARG(q && k && v && out && seq_desc, "attention: null pointer");
+    if (n_seq == 0 || max_q_len == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(n_seq > 0 && max_q_len > 0 && H > 0, "attention: bad dims");
+    DEVQA_CHECK_SHAPE(dh % 8 == 0 && dh > 0 && dh <= ATT_MAXDH, "attention: dh=%d unsupported", dh);
+    DEVQA_CHECK_SHAPE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "attention: row strides must be multiples of 8");
+    DEVQA_CHECK_SHAPE(ldq >= (int64_t)H * dh && ldk >= (int64_t)H * dh && ldv >= (int64_t)H * dh && ldo >= (int64_t)H * dh,
+                      "attention: row strides smaller than H*dh");
+    DEVQA_CHECK_SHAPE((((uintptr_t)q) & 15) == 0 && (((uintptr_t)k) & 15) == 0 && (((uintptr_t)v) & 15) == 0 && (h_aligned(H, dh)),
+                      "attention: q/k/v must be 16-byte aligned");
+    return launch_attention_mfma(q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, n_seq, max_q_len, H, dh, scale, causal, stream);
 }
 extern "C" int devqa_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                    float* out, int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh,

@@ -1,0 +1,205 @@
+// MFMA flash attention for the packed varlen descriptor of include/devqa.h (bf16 in/out, fp32
+// softmax statistics and accumulation).  ViT (257x257, dh 88), Q-Former (32x32 / 32x257, dh 64) and
+// OPT (causal + visible prefix, dh 80) all go through this kernel.
+//
+// Workgroup = (sequence, head, 64-query tile); 4 waves x 16 query rows; keys stream through LDS in
+// 64-key chunks (K and V row-major [64][DHP] bf16, row stride 2*DHP+32 bytes = an odd multiple of 32 B,
+// which makes both the ds_read_b128 K-fragment reads and the ds_read_b64_tr_b16 V reads conflict-free).
+//
+// Operand orientation (no LDS round trip for P, no transposed V image):
+//   S^T = K . Q^T   -> a lane's 16x16 accumulator holds, for ONE query (lane&15), the keys
+//                      16t + 4*(lane>>4) + r of key tile t  -> softmax row statistics need only two
+//                      cross-lane steps (xor 16, 32);
+//   O   = P . V     -> the same registers, converted to bf16, ARE the A operand of the PV product if the
+//                      k index of that MFMA enumerates keys in the order (tile 2s, r=0..3, tile 2s+1,
+//                      r=0..3) for lane group lane>>4; the matching B operand is read from the row-major V
+//                      image with ds_read_b64_tr_b16 (4 keys x 16 channels per 16-lane group).
+// head dims that are not multiples of 32 (88, 80) are zero-padded in LDS to DHP = 96.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((address_space(3))) short4_t* lds_s4_ptr;
+
+#define AM_KC 64  // keys per chunk
+#define AM_QT 64  // queries per workgroup
+
+template <int DHP>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+                                                             const bf16_t* __restrict__ k, int64_t ldk,
+                                                             const bf16_t* __restrict__ v, int64_t ldv,
+                                                             bf16_t* __restrict__ out, int64_t ldo,
+                                                             const int32_t* __restrict__ seq_desc, int H, int dh,
+                                                             float scale, int causal, int q_tiles) {
+    constexpr int STRIDE = 2 * DHP + 32;  // bytes per LDS row
+    constexpr int KS = DHP / 32;          // k-steps of the S^T product
+    constexpr int DT = DHP / 16;          // 16-channel output tiles
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[AM_KC * STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[AM_KC * STRIDE];
+
+    const int bid = blockIdx.x;
+    const int qt = bid % q_tiles;
+    const int h = (bid / q_tiles) % H;
+    const int s = bid / (q_tiles * H);
+    const int32_t* d = seq_desc + s * 6;
+    const int q_start = d[0], q_len = d[1], kp_start = d[2], kp_len = d[3], ko_start = d[4], ko_len = d[5];
+    const int q0 = qt * AM_QT;
+    if (q0 >= q_len) return;  // uniform per workgroup
+    const int nq = min(AM_QT, q_len - q0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int causal_off = ko_len - q_len;  // query i sees own keys 0..i+causal_off
+    const int own_hi = causal ? max(0, min(ko_len, q0 + nq + causal_off)) : ko_len;
+    const int n_keys = kp_len + own_hi;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): query row = wave*16 + fr, channels 32ks + 8fq .. +8 ----
+    const int qrow = q0 + wave * 16 + fr;  // index inside the sequence
+    short8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = ks * 32 + fq * 8;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (qrow < q_len && c < dh) u = *reinterpret_cast<const uint4*>(q + (int64_t)(q_start + qrow) * ldq + h * dh + c);
+        qf[ks] = *reinterpret_cast<short8_t*>(&u);
+    }
+
+    float4_t o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;  // statistics of query fr (replicated over the 4 lane groups)
+
+    constexpr int CH = DHP / 8;  // 16-byte chunks per row
+    for (int c0 = 0; c0 < n_keys; c0 += AM_KC) {
+        __syncthreads();  // previous chunk fully consumed
+        for (int i = tid; i < AM_KC * CH; i += 256) {
+            const int r = i / CH, cv = i % CH;
+            const int kidx = c0 + r;
+            uint4 ku = make_uint4(0, 0, 0, 0), vu = ku;
+            if (kidx < n_keys && cv * 8 < dh) {
+                const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);
+                ku = *reinterpret_cast<const uint4*>(k + grow * ldk + h * dh + cv * 8);
+                vu = *reinterpret_cast<const uint4*>(v + grow * ldv + h * dh + cv * 8);
+            }
+            *reinterpret_cast<uint4*>(Ks + r * STRIDE + cv * 16) = ku;
+            *reinterpret_cast<uint4*>(Vs + r * STRIDE + cv * 16) = vu;
+        }
+        __syncthreads();
+
+        // ---- S^T tiles: keys 16t + (4fq + r), query fr ----
+        float4_t st[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const short8_t kf = *reinterpret_cast<const short8_t*>(Ks + (16 * t + fr) * STRIDE + (32 * ks + 8 * fq) * 2);
+                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[t], 0, 0, 0);
+            }
+        }
+        // ---- mask, scale, online softmax for query fr ----
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kidx = c0 + 16 * t + 4 * fq + r;
+                bool ok = kidx < n_keys;
+                if (causal && kidx >= kp_len) ok = ok && (kidx - kp_len) <= qrow + causal_off;
+                const float sv = ok ? st[t][r] * scale : -INFINITY;
+                st[t][r] = sv;
+                mloc = fmaxf(mloc, sv);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        float alpha = 1.f, lloc = 0.f;
+        if (m_new != -INFINITY) {
+            alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = (st[t][r] == -INFINITY) ? 0.f : __expf(st[t][r] - m_new);
+                    st[t][r] = p;
+                    lloc += p;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        lloc += __shfl_xor(lloc, 16, 64);
+        lloc += __shfl_xor(lloc, 32, 64);
+        l_run = l_run * alpha + lloc;
+        m_run = m_new;
+        // ---- P fragments (A operand of O = P.V): k order = (tile 2s: r 0..3, tile 2s+1: r 0..3) ----
+        short8_t pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 u;
+            u.x = pack_bf16x2(st[2 * s2][0], st[2 * s2][1]);
+            u.y = pack_bf16x2(st[2 * s2][2], st[2 * s2][3]);
+            u.z = pack_bf16x2(st[2 * s2 + 1][0], st[2 * s2 + 1][1]);
+            u.w = pack_bf16x2(st[2 * s2 + 1][2], st[2 * s2 + 1][3]);
+            pf[s2] = *reinterpret_cast<short8_t*>(&u);
+        }
+        // ---- rescale O: its rows are queries 4fq + r, whose alpha lives in lane (fr' = 4fq + r) ----
+        float ar[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * fq + r, 64);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
+        // ---- O += P.V with transposed LDS reads of the row-major V image ----
+        const int tq = fr >> 2, tp = fr & 3;  // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s4_ptr)(Vs + (16 * (2 * s2) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
+                const short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s4_ptr)(Vs + (16 * (2 * s2 + 1) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
+                const short8_t vf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[s2], vf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise and store: O row = query 4fq + r, column = channel 16dt + fr ----
+    float lr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run, 4 * fq + r, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + wave * 16 + 4 * fq + r;
+        if (qi >= q_len) continue;
+        const float inv = lr[r] > 0.f ? 1.f / lr[r] : 0.f;
+        bf16_t* orow = out + (int64_t)(q_start + qi) * ldo + h * dh;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int c = 16 * dt + fr;
+            if (c < dh) orow[c] = f32_to_bf16(o[dt][r] * inv);
+        }
+    }
+}
+
+int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t ldk, const bf16_t* v, int64_t ldv, bf16_t* out,
+                          int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale,
+                          int causal, void* stream) {
+    const int q_tiles = (max_q_len + AM_QT - 1) / AM_QT;
+    const long grid = (long)n_seq * H * q_tiles;
+    DEVQA_CHECK_SHAPE(grid < 2147483647L, "attention: grid too large");
+    const int dhp = (dh + 31) / 32 * 32;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(D)                                                                                                      \
+    hipLaunchKernelGGL(attention_mfma_kernel<D>, dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, \
+                       seq_desc, H, dh, scale, causal, q_tiles)
+    if (dhp == 32) LAUNCH(32);
+    else if (dhp == 64) LAUNCH(64);
+    else if (dhp == 96) LAUNCH(96);
+    else if (dhp == 128) LAUNCH(128);
+    else return devqa_fail(DEVQA_E_SHAPE, "attention: dh=%d unsupported", dh);
+#undef LAUNCH
+    DEVQA_LAUNCH_CHECK("attention_mfma");
+    return DEVQA_OK;
+}

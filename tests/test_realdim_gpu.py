@@ -72,5 +72,21 @@ def test_realdim_ft(rd, in_gold_dir):
             rs = d.double().sum(1).cpu().numpy()
             rel_rs = np.linalg.norm(rs - z["g4_delta_rowsum_%d" % i]) / np.linalg.norm(z["g4_delta_rowsum_%d" % i])
             print("   delta sample rel_l2 %.3g rowsum rel %.3g l2 %.5g vs %.5g" % (rel, rel_rs, float(d.norm()), g["delta_l2"]))
-            assert rel < vllm.tol["delta"] and rel_rs < vllm.tol["delta"]
+            # AdamW gives every element a +-lr step whatever the gradient magnitude, so in bf16 mode elements
+            # whose gradient is at rounding-noise level may take the other sign: the elementwise bar is fp32-only;
+            # bf16 is held to the delta's norm, its row sums and its EFFECT (post-edit logits below).
+            if strict:
+                assert rel < vllm.tol["delta"]
+            assert rel_rs < vllm.tol["delta"]
             assert abs(float(d.norm()) - g["delta_l2"]) < vllm.tol["delta"] * g["delta_l2"]
+        # post-edit logits on the edit prompt's label rows (the reference applied the same edit)
+        ed.edit_one_piece(g["request"])
+        (x, vt), y, m = vllm.prompts_imgs_target_to_xym([g["request"]["prompt"]], [g["request"]["image"]],
+                                                        [g["request"]["target_new"]])
+        post = vllm.get_llm_outpt(x, vt).logits[:, -y.shape[1]:].cpu().numpy()
+        ed.restore_to_original_model()
+        gold = z["g4_post_logits_%d" % i]
+        perr = np.abs(post - gold).max() / np.abs(gold).max()
+        print("   post-edit logits rel err %.3g, argmax agree %s" % (perr, (post.argmax(-1) == gold.argmax(-1)).all()))
+        assert perr < (2e-3 if strict else 3e-2)
+        assert (post.argmax(-1) == gold.argmax(-1)).all()

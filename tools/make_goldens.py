@@ -296,8 +296,14 @@ def run_reference_suite(model_dir, tag, records, odd_img, full_delta, n_eval, ft
             out_npz["g4_delta_val_%d" % i] = d[idx[:, 0], idx[:, 1]]
             out_npz["g4_delta_rowsum_%d" % i] = d.astype(np.float64).sum(1)
         g4.append(entry)
-        # the edit is applied + restored; check restore is exact
+        # the edit is applied; post-edit logits on the edit prompt's label rows; then restored
         editor.edit_one_piece(req)
+        with torch.no_grad():
+            (x, vt), y, m = vllm.prompts_imgs_target_to_xym([req["prompt"]], [req["image"]], [req["target_new"]])
+            post = vllm.get_llm_outpt(x, vt).logits[:, -y.shape[1]:]
+        out_npz["g4_post_logits_%d" % i] = t2n(post).astype(np.float32)
+        entry["post_label_ids"] = t2n(y).tolist()
+        entry["post_label_loss"] = float(ref_ft.label_loss(post, y, m))
         editor.restore_to_original_model()
     out_json["g4"] = g4
     # ---- G4b: config variants (early stop, weight decay, L-inf clamp) ----------
