@@ -61,6 +61,7 @@ class BatchedEditEval:
         self.vllm = editor.vllm
         self.eng = editor.vllm.engine
         self.E = cycles_per_batch
+        self.share_prefix = True  # pack each distinct image-token prefix once (exact; see engine._pack_shared_prefix)
         self.stats = {"cycles": 0, "steps": 0, "t_vision": 0.0, "t_decoder": 0.0, "t_ft": 0.0, "t_tail": 0.0,
                       "t_host": 0.0}
 
@@ -223,7 +224,7 @@ class BatchedEditEval:
         t2 = time.time()
         self.stats["t_vision"] += t2 - t1
         # ---- 3. frozen decoder prefix ---------------------------------------------------------------
-        ps = eng.pack_from_tokens(seqs, img_tokens)
+        ps = eng.pack_from_tokens(seqs, img_tokens, share_prefix=self.share_prefix)
         x_mid, a = eng.decoder_layers(ps, stop_before_fc2=True)
         d = x_mid.shape[1]
         b2 = eng._p("language_model.model.decoder.layers.%d.fc2.bias" % eng.edit_layer)
@@ -264,24 +265,22 @@ class BatchedEditEval:
         t3 = time.time()
         self.stats["t_decoder"] += t3 - t2
         # ---- 4. pre-edit tail (all probes share W0) ----------------------------------------------------
-        pre_argmax = self._tail_argmax(a_tail, resid_tail, w0_op, b2)
-        # ---- 5. FT loop -------------------------------------------------------------------------------
+        y_pre = lib.gemm(a_tail, w0_op, b2, residual=resid_tail, want="f32")  # fc2 rows of every probe, pristine W
+        pre_argmax = self._argmax_from_y(y_pre)
+        # ---- 5. FT loop (on the active columns of each edit) --------------------------------------------
         t4s = time.time()
-        n_steps, losses, w = self._ft_loop(w0, a_ft, resid_ft, labels, mask, E, kmax, d, cfg)
+        n_steps, losses, delta_c, idx, cnt, npad = self._ft_loop(w0, a_ft, resid_ft, labels, mask, E, kmax, d, cfg)
         torch.cuda.synchronize()
         t4 = time.time()
         self.stats["t_ft"] += t4 - t4s
-        # ---- 6. post-edit tail: per-edit matrix ----------------------------------------------------------
+        # ---- 6. post-edit tail:  y_post = y_pre + (dW_e restricted to its active columns) . a -------------
         steps_h = n_steps.cpu().numpy()
-        adam_h = self._adam_t.cpu().numpy()
         losses_h = losses.cpu().numpy()
-        y_post = torch.empty((len(row_idx), d), dtype=torch.float32, device=dev)
+        delta_op = delta_c if eng.adt == torch.float32 else lib.cast_f32_bf16(delta_c)  # [E, d, npad]
+        y_post = y_pre  # updated in place, cycle by cycle
         for e, (r0, r1) in enumerate(cyc_rows):
-            if adam_h[e] > 0:
-                w_op = w[e] if eng.adt == torch.float32 else lib.cast_f32_bf16(w[e])
-            else:
-                w_op = w0_op
-            lib.gemm(a_tail[r0:r1], w_op, b2, residual=resid_tail[r0:r1], out_f32=y_post[r0:r1])
+            a_pc = lib.gather_cols(a_tail[r0:r1], idx[e:e + 1], cnt[e:e + 1], npad, per_edit=False)[0]
+            lib.gemm(a_pc, delta_op[e], residual=y_post[r0:r1], out_f32=y_post[r0:r1])
         post_argmax = self._argmax_from_y(y_post)
         pre_h = pre_argmax.cpu().numpy()
         post_h = post_argmax.cpu().numpy()
@@ -321,17 +320,28 @@ class BatchedEditEval:
         am, _, _ = lib.vocab_rows(logits)
         return am
 
-    def _tail_argmax(self, a_tail, resid_tail, w_op, b2):
-        y = lib.gemm(a_tail, w_op, b2, residual=resid_tail, want="f32")
-        return self._argmax_from_y(y)
-
     def _ft_loop(self, w0, a_ft, resid_ft, labels, mask, E, kmax, d, cfg):
+        """Device-side FT_VL loop for E concurrent edits.  Returns (n_steps, losses, delta_c, idx, cnt, npad):
+        delta_c fp32 [E, Dout, npad] is each edit's weight delta on its ACTIVE columns idx[e,:cnt[e]]
+        (exactly zero elsewhere; csrc/ft_compact.hip).  With weight decay every column moves, so the
+        compaction is bypassed (idx = all columns)."""
         eng = self.eng
         dev = eng.dev
         Dout, Din = w0.shape
-        w = torch.empty((E, Dout, Din), dtype=torch.float32, device=dev)
+        if cfg.weight_decay == 0:
+            idx, cnt = lib.active_columns(a_ft)
+            npad = max(8, (int(cnt.max().item()) + 7) // 8 * 8)   # one small sync per batch: sizes the state
+        else:
+            idx = torch.arange(Din, dtype=torch.int32, device=dev).repeat(E, 1).contiguous()
+            cnt = torch.full((E,), Din, dtype=torch.int32, device=dev)
+            npad = Din
+        w0c = lib.gather_cols(w0, idx, cnt, npad, per_edit=False)        # [E, Dout, npad] pristine columns
+        a_ft = lib.gather_cols(a_ft, idx, cnt, npad, per_edit=True)      # [E, kmax, npad]
+        w0 = w0c
+        w = w0c.clone()
         mom = torch.empty_like(w)
         var = torch.empty_like(w)
+        self.stats["npad_sum"] = self.stats.get("npad_sum", 0) + npad * E
         t_lab = torch.from_numpy(labels.reshape(-1)).to(dev)
         t_mask = torch.from_numpy(mask).to(dev)
         coef = (t_mask / t_mask.sum(1, keepdim=True)).reshape(-1).contiguous()
@@ -342,7 +352,7 @@ class BatchedEditEval:
         losses = torch.zeros((E, cfg.num_steps), dtype=torch.float32, device=dev)
         gamma = eng._p("language_model.model.decoder.final_layer_norm.weight")
         clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else -1.0
-        y = lib.rows_matvec(w0, a_ft, shared=True)  # step-0 fc2 rows with the pristine matrix
+        y = lib.rows_matvec(w0, a_ft)  # step-0 fc2 rows with the pristine matrix (active columns carry all of W.a)
         dl_dtype = eng.adt
         for it in range(cfg.num_steps):
             y2 = y.view(E * kmax, Dout)
@@ -355,4 +365,5 @@ class BatchedEditEval:
             lib.ft_adamw_step(w, mom, var, w0, a_ft, dy, y, do_update, adam_t, cfg.lr, 0.9, 0.999, 1e-8, cfg.weight_decay,
                               clamp)
         self._adam_t = adam_t
-        return n_steps, losses, w
+        lib.delta_op(0, w, w0, mom)  # mom := w - w0 (reuse the buffer): the compacted delta
+        return n_steps, losses, mom, idx, cnt, npad

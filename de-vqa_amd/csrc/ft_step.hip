@@ -20,15 +20,16 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
                                                             float* __restrict__ y, const int32_t* __restrict__ do_update,
                                                             const int32_t* __restrict__ adam_t, int Lmax, int Dout, int Din,
                                                             float lr, float beta1, float beta2, float eps, float wd,
-                                                            float clamp_eps, int row_blocks) {
+                                                            float clamp_eps, int row_blocks, int64_t w0_stride_e) {
     __shared__ float red[4][ROWS * L];
     const int e = blockIdx.x / row_blocks;
     const int rb = blockIdx.x % row_blocks;
     if (!do_update[e]) return;  // uniform
+    w0 += (int64_t)e * w0_stride_e;
     const int t = adam_t[e];
     const bool first = (t <= 1);
-    const float bc1 = 1.f - powf(beta1, (float)t);
-    const float bc2 = 1.f - powf(beta2, (float)t);
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)t));
+    const float bc2 = (float)(1.0 - pow((double)beta2, (double)t));
     const float step_size = lr / bc1;
     const float bc2_sqrt = sqrtf(bc2);
     const float decay = 1.f - lr * wd;
@@ -127,10 +128,10 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
 template <int L, int ROWS>
 static int launch_adamw(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
                         const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din, float lr,
-                        float beta1, float beta2, float eps, float wd, float clamp_eps, hipStream_t st) {
+                        float beta1, float beta2, float eps, float wd, float clamp_eps, int64_t w0_stride_e, hipStream_t st) {
     const int row_blocks = (Dout + ROWS - 1) / ROWS;
     hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
-                       do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks);
+                       do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
     DEVQA_LAUNCH_CHECK("ft_adamw_step");
     return DEVQA_OK;
 }
@@ -138,14 +139,14 @@ static int launch_adamw(float* w, float* m, float* v, const float* w0, const flo
 extern "C" int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
                                    const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
                                    float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
-                                   void* stream) {
+                                   int64_t w0_stride_e, void* stream) {
     DEVQA_CHECK_ARG(w && m && v && w0 && a && dy && y && do_update && adam_t, "ft_adamw_step: null pointer");
     if (E == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(E > 0 && Lmax >= 1 && Lmax <= 16, "ft_adamw_step: Lmax=%d unsupported (1..16)", Lmax);
     DEVQA_CHECK_SHAPE(Dout > 0 && Din > 0 && Din % 4 == 0, "ft_adamw_step: bad matrix dims %dx%d", Dout, Din);
     DEVQA_CHECK_SHAPE((long)E * ((Dout + 1) / 2) < 2147483647L, "ft_adamw_step: grid too large");
     hipStream_t st = (hipStream_t)stream;
-#define ARGS w, m, v, w0, a, dy, y, do_update, adam_t, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps, st
+#define ARGS w, m, v, w0, a, dy, y, do_update, adam_t, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps, w0_stride_e, st
     if (Lmax <= 1) return launch_adamw<1, 4>(ARGS);
     if (Lmax <= 2) return launch_adamw<2, 4>(ARGS);
     if (Lmax <= 4) return launch_adamw<4, 2>(ARGS);

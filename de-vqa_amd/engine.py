@@ -156,9 +156,11 @@ class Blip2Engine:
         return PackedSeqs(x, [b * T for b in range(B)], [int(n) for n in lens], desc, T)
 
     @torch.no_grad()
-    def pack_from_tokens(self, seqs, img_tokens):
+    def pack_from_tokens(self, seqs, img_tokens, share_prefix=False):
         """seqs: list of (image_index or None, token_id_list).  Each sequence becomes
         [Q image-token rows (if any)] + token embeddings, positions 0..len-1 (blip2.py:45-52)."""
+        if share_prefix:
+            return self._pack_shared_prefix(seqs, img_tokens)
         tok, src, pos, start, length = [], [], [], [], []
         Qn = self.Q
         r = 0
@@ -186,6 +188,44 @@ class Blip2Engine:
         desc = torch.tensor([[s, n, 0, 0, s, n] for s, n in zip(start, length)], dtype=torch.int32, device=dev)
         return PackedSeqs(x, start, length, desc, max(length))
 
+    def _pack_shared_prefix(self, seqs, img_tokens):
+        """Same sequences, but the Q image-token rows of every distinct image are packed ONCE: a prefix
+        sequence (causal among itself) that all texts on that image attend to through the descriptor's
+        visible-prefix range.  Image tokens come first and attention is causal, so their hidden states and
+        K/V do not depend on the text: results equal the unshared packing (SURVEY 8(d) A_min).
+        start/length of the returned PackedSeqs describe the TEXT part of each input sequence."""
+        Qn = self.Q
+        tok, src, pos, desc = [], [], [], []
+        prefix_start = {}
+        r = 0
+        for img in sorted({s[0] for s in seqs if s[0] is not None}):
+            prefix_start[img] = r
+            tok += [0] * Qn
+            src += list(range(img * Qn, (img + 1) * Qn))
+            pos += list(range(Qn))
+            desc.append([r, Qn, 0, 0, r, Qn])
+            r += Qn
+        start, length = [], []
+        for (img, ids) in seqs:
+            n = len(ids)
+            off = 0 if img is None else Qn
+            start.append(r)
+            length.append(n)
+            tok += list(ids)
+            src += [-1] * n
+            pos += list(range(off, off + n))
+            desc.append([r, n, prefix_start[img], Qn, r, n] if img is not None else [r, n, 0, 0, r, n])
+            r += n
+        dev = self.dev
+        rows = None if img_tokens is None else img_tokens.reshape(-1, img_tokens.shape[-1]).contiguous()
+        x = lib.embed_rows(torch.tensor(tok, dtype=torch.int32, device=dev), torch.tensor(src, dtype=torch.int32, device=dev),
+                           torch.tensor(pos, dtype=torch.int32, device=dev),
+                           self._p("language_model.model.decoder.embed_tokens.weight"), rows,
+                           self._p("language_model.model.decoder.embed_positions.weight"))
+        ps = PackedSeqs(x, start, length, torch.tensor(desc, dtype=torch.int32, device=dev), max(max(length), Qn))
+        ps.n_seq = len(desc)
+        return ps
+
     # ------------------------------------------------------------------------------------------
     # K7: decoder layers.  Returns the residual stream after `n_layers` full layers; when
     # stop_before_fc2, the last processed layer stops at the fc2 input: returns (x_mid, a_bf16).
@@ -196,7 +236,7 @@ class Blip2Engine:
         d, H = t["hidden_size"], t["num_attention_heads"]
         dh = d // H
         x = ps.x
-        n_seq = len(ps.start)
+        n_seq = ps.desc.shape[0]
         last = t["num_hidden_layers"] - 1 if upto_layer is None else upto_layer
         for i in range(last + 1):
             p = "language_model.model.decoder.layers.%d." % i

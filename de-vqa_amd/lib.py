@@ -56,7 +56,11 @@ def load():
     _sig(L.devqa_cast_f32_bf16, [P, P, I64, P])
     _sig(L.devqa_vocab_rows, [P, I64, I, I, P, P, P, P, P, I64, P])
     _sig(L.devqa_layernorm_bwd_dx, [P, P, P, P, I, I, F, P, P])
-    _sig(L.devqa_ft_adamw_step, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, P])
+    _sig(L.devqa_ft_adamw_step, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I64, P])
+    _sig(L.devqa_active_columns, [P, I, I, I, P, P, P])
+    _sig(L.devqa_gather_cols_f32, [P, I64, I64, I, P, I64, P, I, I, P, P])
+    _sig(L.devqa_gather_cols_bf16, [P, I64, I64, I, P, I64, P, I, I, P, P])
+    _sig(L.devqa_scatter_cols_add_f32, [P, I, P, P, I, P, I64, P])
     _sig(L.devqa_rows_matvec_f32, [P, I64, P, P, P, P, I, I, I, I, P])
     _sig(L.devqa_delta_op, [I, P, P, P, I64, P])
     _sig(L.devqa_ft_step_control, [P, P, I, I, I, I, F, P, P, P, P, P, P])
@@ -66,7 +70,8 @@ def load():
     return L
 
 
-EXPORTS = ["devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
+EXPORTS = ["devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
+           "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
            "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
            "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
@@ -266,11 +271,42 @@ def ft_adamw_step(w, m, v, w0, a, dy, y, do_update, adam_t, lr, beta1, beta2, ep
     for t, n in ((w, "w"), (m, "m"), (v, "v"), (w0, "w0"), (a, "a"), (dy, "dy"), (y, "y")):
         _need(t, torch.float32, "ft_adamw_step " + n)
     assert a.shape == (E, Lmax, Din) and dy.shape == (E, Lmax, Dout) and y.shape == (E, Lmax, Dout)
-    assert w0.shape == (Dout, Din) and m.shape == w.shape and v.shape == w.shape
+    assert w0.shape in ((Dout, Din), (E, Dout, Din)) and m.shape == w.shape and v.shape == w.shape
     assert do_update.dtype == torch.int32 and adam_t.dtype == torch.int32
+    w0_stride = Dout * Din if w0.dim() == 3 else 0
     _chk(load().devqa_ft_adamw_step(_p(w), _p(m), _p(v), _p(w0), _p(a), _p(dy), _p(y), _p(do_update), _p(adam_t), E, Lmax,
                                     Dout, Din, float(lr), float(beta1), float(beta2), float(eps), float(wd),
-                                    float(clamp_eps), _stream()), "devqa_ft_adamw_step")
+                                    float(clamp_eps), w0_stride, _stream()), "devqa_ft_adamw_step")
+
+
+def active_columns(a):
+    """a fp32 [E,L,Din] -> (idx int32 [E,Din] ascending active columns, count int32 [E])"""
+    _need(a, torch.float32, "active_columns a")
+    E, L, Din = a.shape
+    idx = torch.empty((E, Din), dtype=torch.int32, device=a.device)
+    cnt = torch.empty((E,), dtype=torch.int32, device=a.device)
+    _chk(load().devqa_active_columns(_p(a), E, L, Din, _p(idx), _p(cnt), _stream()), "devqa_active_columns")
+    return idx, cnt
+
+
+def gather_cols(src, idx, count, npad, per_edit):
+    """out[e,row,c] = src[(e,) row, idx[e,c]] for c < count[e] else 0.  src [rows,Din] (shared) or [E,rows,Din];
+    idx int32 [E,Din'], count int32 [E]."""
+    assert src.is_contiguous() and idx.dtype == torch.int32 and count.dtype == torch.int32
+    E = idx.shape[0]
+    rows, ld = src.shape[-2], src.shape[-1]
+    out = torch.empty((E, rows, npad), dtype=src.dtype, device=src.device)
+    fn = load().devqa_gather_cols_f32 if src.dtype == torch.float32 else load().devqa_gather_cols_bf16
+    _chk(fn(_p(src), rows * ld if per_edit else 0, ld, rows, _p(idx), idx.stride(0), _p(count), E, int(npad), _p(out), _stream()),
+         "devqa_gather_cols")
+    return out
+
+
+def scatter_cols_add(comp, idx_e, count_e, dense):
+    """dense[:, idx_e[c]] += comp[:, c] for c < count_e (one edit)."""
+    rows, npad = comp.shape
+    _chk(load().devqa_scatter_cols_add_f32(_p(comp), rows, _p(idx_e), _p(count_e), npad, _p(dense), dense.stride(0),
+                                           _stream()), "devqa_scatter_cols_add_f32")
 
 
 def rows_matvec(w, a, bias=None, resid=None, shared=False):

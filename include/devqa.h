@@ -158,7 +158,7 @@ int devqa_layernorm_bwd_dx(const float* x, const float* add, const float* gamma,
  * w,m,v = 6*4*Dout*Din bytes (the reference additionally round-trips g: 7 tensors, 734 MB at
  * 2560x10240).
  * Replaces loss.backward() onto the weight + opt.step() + clamp (ft_vl.py:131-141).
- *   w,m,v : fp32 [E][Dout][Din]      w0 : fp32 [Dout][Din]
+ *   w,m,v : fp32 [E][Dout][Din]      w0 : fp32 [Dout][Din] shared (w0_stride_e = 0) or per edit (= Dout*Din)
  *   a     : fp32 [E][Lmax][Din]      dy : fp32 [E][Lmax][Dout]     y : fp32 [E][Lmax][Dout]
  *   do_update, adam_t : int32 [E] (device, from devqa_ft_step_control)
  *   clamp_eps < 0 disables the clamp.  1 <= Lmax <= 16, Din % 4 == 0.
@@ -166,7 +166,23 @@ int devqa_layernorm_bwd_dx(const float* x, const float* add, const float* gamma,
 int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
                         const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
                         float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
-                        void* stream);
+                        int64_t w0_stride_e, void* stream);
+
+/* ---- column compaction of the FT loop (csrc/ft_compact.hip) ------------------------------------------
+ * With a = relu(.) constant over the loop, a column j of the edited matrix whose a[e,r,j] == 0 for every
+ * loss row r has zero gradient, zero moments and zero update at every step (weight_decay == 0), so the loop
+ * only carries the active columns of each edit.  devqa_active_columns lists them (ascending) per edit;
+ * devqa_gather_cols_* builds out[e,row,c] = c < count[e] ? src[e*src_stride_e + row*ld_src + idx[e*idx_stride_e + c]] : 0;
+ * devqa_scatter_cols_add_f32 adds a compacted [rows,npad] block back into a dense matrix (one edit).
+ * devqa_ft_adamw_step then runs on [E,Dout,npad] with w0_stride_e = Dout*npad.
+ */
+int devqa_active_columns(const float* a, int E, int L, int Din, int32_t* idx, int32_t* count, void* stream);
+int devqa_gather_cols_f32(const float* src, int64_t src_stride_e, int64_t ld_src, int rows, const int32_t* idx,
+                          int64_t idx_stride_e, const int32_t* count, int E, int npad, float* out, void* stream);
+int devqa_gather_cols_bf16(const devqa_bf16* src, int64_t src_stride_e, int64_t ld_src, int rows, const int32_t* idx,
+                           int64_t idx_stride_e, const int32_t* count, int E, int npad, devqa_bf16* out, void* stream);
+int devqa_scatter_cols_add_f32(const float* comp, int rows, const int32_t* idx, const int32_t* count, int npad, float* dense,
+                               int64_t ld_dense, void* stream);
 
 /* y[e,r,:] = W[e or shared] . a[e,r,:] (+ bias) (+ resid[e,r,:]) : fc2 on a few cached rows with an
  * fp32 matrix (pre-/post-edit probe tails, step-0 forward).  w_stride_e = 0 shares one matrix. */

@@ -304,3 +304,38 @@ def test_cosine_topk_exact_indices(L, N, Q, D, k):
     ridx2, _ = O.cosine_topk(c, q, k, False, False)
     idx2, _ = L.cosine_topk(dev(torch.from_numpy(c)), dev(torch.from_numpy(q)), k, False, False)
     np.testing.assert_array_equal(idx2.cpu().numpy(), ridx2)
+
+
+def test_column_compaction(L):
+    g = torch.Generator().manual_seed(21)
+    E, Lr, Din, Dout = 3, 2, 10240, 24
+    a = torch.relu(torch.randn(E, Lr, Din, generator=g) - 1.8)  # ~3.6% active
+    a[1] = 0
+    a[1, 0, 5] = 1.0
+    a[1, 1, 10239] = 2.0
+    idx, cnt = L.active_columns(dev(a))
+    for e in range(E):
+        ref = torch.nonzero((a[e] != 0).any(0))[:, 0]
+        assert int(cnt[e]) == len(ref)
+        np.testing.assert_array_equal(idx[e, :len(ref)].cpu().numpy(), ref.numpy())
+    npad = (int(cnt.max()) + 7) // 8 * 8
+    w = torch.randn(Dout, Din, generator=g)
+    wc = L.gather_cols(dev(w), idx, cnt, npad, per_edit=False).cpu()
+    ac = L.gather_cols(dev(a), idx, cnt, npad, per_edit=True).cpu()
+    for e in range(E):
+        n = int(cnt[e])
+        j = idx[e, :n].cpu().long()
+        np.testing.assert_array_equal(wc[e, :, :n].numpy(), w[:, j].numpy())
+        assert float(wc[e, :, n:].abs().sum()) == 0.0
+        np.testing.assert_array_equal(ac[e, :, :n].numpy(), a[e][:, j].numpy())
+        # the compacted product carries all of W.a
+        np.testing.assert_allclose((ac[e] @ wc[e].T).numpy(), (a[e] @ w.T).numpy(), atol=1e-4, rtol=1e-4)
+    ab = dev(a[0]).to(torch.bfloat16).contiguous()
+    gb = L.gather_cols(ab, idx[0:1], cnt[0:1], npad, per_edit=False)[0].float().cpu()
+    n0 = int(cnt[0])
+    np.testing.assert_array_equal(gb[:, :n0].numpy(), ab.float().cpu()[:, idx[0, :n0].cpu().long()].numpy())
+    dense = torch.zeros(Dout, Din, device="cuda")
+    L.scatter_cols_add(dev(wc[0].contiguous()), idx[0], cnt[0:1], dense)
+    ref = torch.zeros(Dout, Din)
+    ref[:, idx[0, :n0].cpu().long()] = w[:, idx[0, :n0].cpu().long()]
+    np.testing.assert_array_equal(dense.cpu().numpy(), ref.numpy())
