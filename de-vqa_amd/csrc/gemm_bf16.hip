@@ -10,6 +10,7 @@
 // Block = 256 threads = 4 waves arranged WM x WN; wave tile (BM/WM) x (BN/WN) of 16x16 MFMA tiles.
 // blockIdx -> tile mapping is XCD-aware: consecutive tile ids (which share the same W panel)
 // are dealt to the same XCD so a panel is fetched into one L2 instead of eight.
+#include <stdlib.h>
 #include "common.h"
 
 #define BK 64
@@ -199,6 +200,21 @@ extern "C" int devqa_profile_gemm_read(double* ms, double* flops, int64_t* launc
     return DEVQA_OK;
 }
 
+static int g_gemm_mode = -1;
+extern "C" int devqa_gemm_set_mode(int mode) {
+    if (mode < 0 || mode > 2) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: mode must be 0, 1 or 2");
+    g_gemm_mode = mode;
+    return DEVQA_OK;
+}
+
+// LDS-DMA staged variants (gemm_bf16_glds.hip)
+int launch_gemm_glds_64x128(const bf16_t*, int64_t, const bf16_t*, int64_t, const float*, int, int, int, float, int, const float*,
+                            bf16_t*, float*, int64_t, hipStream_t);
+int launch_gemm_glds_128x128(const bf16_t*, int64_t, const bf16_t*, int64_t, const float*, int, int, int, float, int, const float*,
+                             bf16_t*, float*, int64_t, hipStream_t);
+int launch_gemm_glds_256x128(const bf16_t*, int64_t, const bf16_t*, int64_t, const float*, int, int, int, float, int, const float*,
+                             bf16_t*, float*, int64_t, hipStream_t);
+
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N,
                        int K, float alpha, int act, const float* residual, bf16_t* out_bf16, float* out_f32,
@@ -239,10 +255,34 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     DEVQA_CHECK_SHAPE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (M <= 32) return launch_gemm<32, 128, 1, 4>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
-    if (M <= 64) return launch_gemm<64, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
-    // mid-size problems: prefer more, smaller tiles when the 128x128 grid would not fill 256 CUs
+    // mode 0: LDS-DMA staging when K % 64 == 0 (default); 1: force the register-staged kernels;
+    // 2: as 0 but 256x128 tiles for large problems (A/B testing via devqa_gemm_set_mode / DEVQA_GEMM)
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("DEVQA_GEMM");
+        g_gemm_mode = e ? atoi(e) : 0;
+    }
+    const bool glds = (K % 64 == 0) && g_gemm_mode != 1;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (t128 < 384)
-        return launch_gemm<64, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
-    return launch_gemm<128, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    int variant;  // 1: 64x128, 2: 128x128, 3: 256x128
+    if (M <= 64 || t128 < 384) variant = 1;
+    else if (glds && g_gemm_mode == 2 && t128 >= 1024) variant = 3;
+    else variant = 2;
+    if (!glds) {
+        if (variant == 1)
+            return launch_gemm<64, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+        return launch_gemm<128, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    }
+    const bool prof = g_prof_on && g_prof_used < PROF_MAX_PAIRS;
+    if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_used], st);
+    int rc;
+    if (variant == 1) rc = launch_gemm_glds_64x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    else if (variant == 2) rc = launch_gemm_glds_128x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    else rc = launch_gemm_glds_256x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    if (prof) {
+        (void)hipEventRecord(g_prof_ev[2 * g_prof_used + 1], st);
+        g_prof_variant[g_prof_used] = variant;
+        g_prof_flops[g_prof_used] = 2.0 * (double)M * (double)N * (double)K;
+        ++g_prof_used;
+    }
+    return rc;
 }

@@ -41,6 +41,7 @@ def load():
     _sig(L.devqa_abi_version, [])
     _sig(L.devqa_gemm_bf16, [P, I64, P, I64, P, I, I, I, F, I, P, P, P, I64, P])
     _sig(L.devqa_gemm_f32, [P, I64, P, I64, P, I, I, I, F, I, P, P, I64, P])
+    _sig(L.devqa_gemm_set_mode, [I])
     _sig(L.devqa_profile_gemm, [I])
     _sig(L.devqa_profile_gemm_read, [P, P, P])
     _sig(L.devqa_layernorm, [P, P, P, P, I, I, F, P, P, P])
@@ -70,12 +71,16 @@ def load():
     return L
 
 
-EXPORTS = ["devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
+EXPORTS = ["devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
            "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
            "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk"]
+
+
+def gemm_set_mode(mode):
+    _chk(load().devqa_gemm_set_mode(int(mode)), "devqa_gemm_set_mode")
 
 
 def profile_gemm(enable):

@@ -56,6 +56,11 @@ int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64
                     int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
                     float* out_f32, int64_t ldc, void* stream);
 
+/* Kernel selection for A/B measurements: 0 = default (LDS-DMA staged tiles when K % 64 == 0, register-staged
+ * otherwise), 1 = always register-staged, 2 = default + 256x128 tiles for large problems.  Results are the
+ * same up to fp32 summation order inside a 64-deep K step (identical: same MFMA sequence per output). */
+int devqa_gemm_set_mode(int mode);
+
 /* Measurement hook for bench.py's roofline: when enabled, every devqa_gemm_bf16 launch is bracketed by
  * HIP events on its own stream (up to 49152 launches).  _read synchronises on them and returns, per tile
  * variant (0: 32x128, 1: 64x128, 2: 128x128; arrays of 4), the summed kernel time (ms), the summed useful

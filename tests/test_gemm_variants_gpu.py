@@ -1,0 +1,44 @@
+"""Every GEMM kernel variant (register-staged / LDS-DMA staged, 64x128 / 128x128 / 256x128 tiles)
+against fp32 PyTorch on the same bf16-rounded operands, incl. ragged M/N edges and fused epilogues."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import devqa_amd  # noqa: F401
+    from devqa_amd import lib
+    lib.load()
+    yield lib
+    lib.gemm_set_mode(0)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (4099, 4224, 1408, 0, False),     # 128x128 (mode 0/1) or 256x128 (mode 2); ragged M
+    (16448, 1408, 6144, 0, True),     # ViT fc2 shape, in-place residual
+    (2500, 10240, 2560, 1, False),    # OPT fc1 + ReLU
+    (1000, 2568, 640, 2, False),      # ragged N (not a multiple of the tile), GELU
+    (70, 2560, 2560, 0, True),        # 64x128 variant
+])
+def test_gemm_variants(L, mode, M, N, K, act, res):
+    L.gemm_set_mode(mode)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if res else None
+    ref = a.float() @ w.float().T + b
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    rd = r.cuda() if res else None
+    if res:
+        ref = ref + r
+    out = L.gemm(a.cuda(), w.cuda(), b.cuda(), 1.0, act, rd, out_f32=rd if res else None, want="f32")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=3e-4, rtol=3e-4)
