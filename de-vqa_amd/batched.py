@@ -360,7 +360,7 @@ class BatchedEditEval:
             _, nll, dlog = lib.vocab_rows(logits, t_lab, coef, want_argmax=False, want_nll=True, want_dlogits=True,
                                           dlogits_dtype=dl_dtype)
             lib.ft_step_control(nll, t_mask, it, cfg.num_steps, 1e-2, active, do_update, n_steps, adam_t, losses)
-            dH = lib.gemm(dlog, self.vllm.model.embed_T, want="f32")
+            dH = lib.gemm_rows_longk(dlog, self.vllm.model.embed_T)
             dy = lib.layernorm_bwd_dx(y2, gamma, dH, 1e-5, add=resid_ft).view(E, kmax, Dout)
             lib.ft_adamw_step(w, mom, var, w0, a_ft, dy, y, do_update, adam_t, cfg.lr, 0.9, 0.999, 1e-8, cfg.weight_decay,
                               clamp)

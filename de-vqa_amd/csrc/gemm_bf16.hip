@@ -19,7 +19,7 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
     const float* __restrict__ bias, int M, int N, int K, float alpha, int act, const float* residual,
-    bf16_t* out_bf16, float* out_f32, int64_t ldc, int tiles_m, int tiles_n) {
+    bf16_t* out_bf16, float* out_f32, int64_t ldc, int tiles_m, int tiles_n, int steps_per_split) {
     constexpr int TM = BM / WM / 16;  // 16-row MFMA tiles per wave along M
     constexpr int TN = BN / WN / 16;
     constexpr int A_CHUNKS = BM * (BK / 8) / 256;  // 16-byte chunks per thread per tile
@@ -57,7 +57,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(
         for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[A_CHUNKS], rb[B_CHUNKS];
-    const int nk = (K + BK - 1) / BK;
+    // split-K: blockIdx.y owns K steps [kb, nk) and writes a raw fp32 partial slab (steps_per_split > 0)
+    const int nk_all = (K + BK - 1) / BK;
+    const int kb = steps_per_split > 0 ? (int)blockIdx.y * steps_per_split : 0;
+    const int nk = steps_per_split > 0 ? min(nk_all, kb + steps_per_split) : nk_all;
+    if (steps_per_split > 0) out_f32 += (int64_t)blockIdx.y * M * ldc;
 
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
@@ -97,12 +101,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(
         }
     };
 
-    gload(0);
+    gload(kb);
     lstore(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kb; kt < nk; ++kt) {
+        const int cur = (kt - kb) & 1;
         if (kt + 1 < nk) gload(kt + 1);
         const unsigned char* sa = smem + cur * STAGE_BYTES;
         const unsigned char* sb = sa + A_BYTES;
@@ -200,6 +204,42 @@ extern "C" int devqa_profile_gemm_read(double* ms, double* flops, int64_t* launc
     return DEVQA_OK;
 }
 
+// ---- split-K for skinny problems with a very long K (dH = dlogits . E: M <= 64, N = 2560, K = 50272) ----
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn4, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 s = reinterpret_cast<const float4*>(part)[i];
+        for (int k = 1; k < splits; ++k) {
+            const float4 p = reinterpret_cast<const float4*>(part)[(int64_t)k * mn4 + i];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+
+extern "C" int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64_t ldw, int M, int N, int K,
+                                      int splits, float* partial_ws, float* out_f32, void* stream) {
+    DEVQA_CHECK_ARG(A && W && partial_ws && out_f32, "gemm_splitk: null pointer");
+    if (M == 0 || N == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(M > 0 && M <= 64 && N > 0 && N % 4 == 0 && K > 0, "gemm_splitk: needs 0 < M <= 64, N %% 4 == 0");
+    DEVQA_CHECK_SHAPE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "gemm_splitk: bad K / leading dims");
+    DEVQA_CHECK_SHAPE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm_splitk: operands must be 16-byte aligned");
+    const int nk = (K + BK - 1) / BK;
+    DEVQA_CHECK_SHAPE(splits >= 1 && splits <= nk && splits <= 1024, "gemm_splitk: bad split count %d", splits);
+    const int steps = (nk + splits - 1) / splits;
+    const int used = (nk + steps - 1) / steps;  // every launched split owns >= 1 step
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_n = (N + 127) / 128;
+    auto kern = gemm_bf16_tn_kernel<64, 128, 2, 2>;
+    hipLaunchKernelGGL(kern, dim3(tiles_n, used), dim3(256), 2 * (64 + 128) * BK * 2, st, A, lda, W, ldw, (const float*)nullptr, M,
+                       N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, partial_ws, (int64_t)N, 1, tiles_n, steps);
+    DEVQA_LAUNCH_CHECK("gemm_splitk");
+    const int64_t mn4 = (int64_t)M * N / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256 < 1024 ? (mn4 + 255) / 256 : 1024)), dim3(256), 0, st,
+                       partial_ws, used, mn4, out_f32);
+    DEVQA_LAUNCH_CHECK("splitk_reduce");
+    return DEVQA_OK;
+}
+
 static int g_gemm_mode = -1;
 extern "C" int devqa_gemm_set_mode(int mode) {
     if (mode < 0 || mode > 2) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: mode must be 0, 1 or 2");
@@ -230,7 +270,7 @@ static int launch_gemm(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ld
     const bool prof = g_prof_on && g_prof_used < PROF_MAX_PAIRS;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_used], st);
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, st, A, lda, W, ldw, bias, M, N, K, alpha, act,
-                       residual, out_bf16, out_f32, ldc, tiles_m, tiles_n);
+                       residual, out_bf16, out_f32, ldc, tiles_m, tiles_n, 0);
     if (prof) {
         (void)hipEventRecord(g_prof_ev[2 * g_prof_used + 1], st);
         g_prof_variant[g_prof_used] = BM == 32 ? 0 : (BM == 64 ? 1 : 2);

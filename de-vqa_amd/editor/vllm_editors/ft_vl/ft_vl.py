@@ -156,7 +156,7 @@ class FTvl(VLLMBaseEditor):
                 loss_sum += loss * n_items
                 cnt += n_items
                 if loss >= LOSS_FLOOR:
-                    dH = lib.gemm(dlog, self.vllm.model.embed_T, want="f32")
+                    dH = lib.gemm_rows_longk(dlog, self.vllm.model.embed_T)
                     dy = lib.layernorm_bwd_dx(pre_ln, gamma, dH, 1e-5).view(1, k, Dout)
                     adam_t += 1
                     y_next = torch.empty((1, k, Dout), dtype=torch.float32, device=dev)

@@ -42,6 +42,7 @@ def load():
     _sig(L.devqa_gemm_bf16, [P, I64, P, I64, P, I, I, I, F, I, P, P, P, I64, P])
     _sig(L.devqa_gemm_f32, [P, I64, P, I64, P, I, I, I, F, I, P, P, I64, P])
     _sig(L.devqa_gemm_set_mode, [I])
+    _sig(L.devqa_gemm_bf16_splitk, [P, I64, P, I64, I, I, I, I, P, P, P])
     _sig(L.devqa_profile_gemm, [I])
     _sig(L.devqa_profile_gemm_read, [P, P, P])
     _sig(L.devqa_layernorm, [P, P, P, P, I, I, F, P, P, P])
@@ -71,12 +72,28 @@ def load():
     return L
 
 
-EXPORTS = ["devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
+EXPORTS = ["devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
            "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
            "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk"]
+
+
+def gemm_rows_longk(a, w):
+    """fp32 [M,N] = a[M,K] @ w[N,K].T for a few rows and a very long K (dH = dlogits . E): split-K on the
+    bf16 MFMA kernel when M <= 64, else the plain GEMM (fp32 operands: exact-fp32 GEMM)."""
+    if a.dtype != torch.bfloat16 or a.shape[0] > 64:
+        return gemm(a, w, want="f32")
+    M, K = a.shape
+    N = w.shape[0]
+    nk = (K + 63) // 64
+    splits = max(1, min(nk, 640 // max(1, (N + 127) // 128)))
+    ws = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _chk(load().devqa_gemm_bf16_splitk(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, splits, _p(ws), _p(out), _stream()),
+         "devqa_gemm_bf16_splitk")
+    return out
 
 
 def gemm_set_mode(mode):
