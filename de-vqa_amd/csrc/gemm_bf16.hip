@@ -301,7 +301,10 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
         const char* e = getenv("DEVQA_GEMM");
         g_gemm_mode = e ? atoi(e) : 0;
     }
-    const bool glds = (K % 64 == 0) && g_gemm_mode != 1;
+    // the LDS-DMA kernels use 16-byte epilogue accesses: need N, ldc multiples of 4 and 16-byte aligned pointers
+    const bool vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && ((((uintptr_t)out_f32) | ((uintptr_t)residual) | ((uintptr_t)bias)) & 15) == 0 &&
+                        (((uintptr_t)out_bf16) & 7) == 0;
+    const bool glds = (K % 64 == 0) && g_gemm_mode != 1 && vec_ok;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     int variant;  // 1: 64x128, 2: 128x128, 3: 256x128
     if (M <= 64 || t128 < 384) variant = 1;

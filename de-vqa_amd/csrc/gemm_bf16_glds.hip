@@ -109,29 +109,47 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D^T: rows = n
         }
         __syncthreads();
     }
 
+    // ---- epilogue.  Operands were fed swapped (W fragment as the MFMA A operand), so a lane's accumulator
+    // holds, for output row m = ..+fr, the 4 CONSECUTIVE columns n = ..+4*fq+0..3: 16-byte fp32 / 8-byte bf16
+    // accesses per lane instead of four scalar ones.
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + fr;
+        if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + fr;
-            if (n >= N) continue;
-            const float b = bias ? bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * (BM / WM) + i * 16 + fq * 4 + r;
-                if (m >= M) continue;
-                float v = (acc[i][j][r] + b) * alpha;
-                if (act == DEVQA_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (act == DEVQA_ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-                const int64_t o = (int64_t)m * ldc + n;
-                if (residual) v += residual[o];
-                if (out_f32) out_f32[o] = v;
-                if (out_bf16) out_bf16[o] = f32_to_bf16(v);
+            const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+            if (n >= N) continue;  // N % 4 == 0: a 4-column group is entirely in or out
+            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (bias) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + n);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+            if (act == DEVQA_ACT_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            } else if (act == DEVQA_ACT_GELU) {
+                v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752440f));
+                v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752440f));
+                v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752440f));
+                v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752440f));
+            }
+            const int64_t o = (int64_t)m * ldc + n;
+            if (residual) {
+                const float4 r = *reinterpret_cast<const float4*>(residual + o);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (out_f32) *reinterpret_cast<float4*>(out_f32 + o) = v;
+            if (out_bf16) {
+                uint2 p;
+                p.x = pack_bf16x2(v.x, v.y);
+                p.y = pack_bf16x2(v.z, v.w);
+                *reinterpret_cast<uint2*>(out_bf16 + o) = p;
             }
         }
     }
