@@ -242,11 +242,13 @@ extern "C" int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const de
 
 static int g_gemm_mode = -1;
 extern "C" int devqa_gemm_set_mode(int mode) {
-    if (mode < 0 || mode > 2) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: mode must be 0, 1 or 2");
+    if (mode < 0 || (mode > 2 && (mode < 10 || mode > 17))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
     g_gemm_mode = mode;
     return DEVQA_OK;
 }
 
+int launch_gemm_pipe(int id, const bf16_t*, int64_t, const bf16_t*, int64_t, const float*, int, int, int, float, int, const float*,
+                     bf16_t*, float*, int64_t, hipStream_t);  // gemm_bf16_pipe.hip
 // LDS-DMA staged variants (gemm_bf16_glds.hip)
 int launch_gemm_glds_64x128(const bf16_t*, int64_t, const bf16_t*, int64_t, const float*, int, int, int, float, int, const float*,
                             bf16_t*, float*, int64_t, hipStream_t);
@@ -305,6 +307,8 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     const bool vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && ((((uintptr_t)out_f32) | ((uintptr_t)residual) | ((uintptr_t)bias)) & 15) == 0 &&
                         (((uintptr_t)out_bf16) & 7) == 0;
     const bool glds = (K % 64 == 0) && g_gemm_mode != 1 && vec_ok;
+    if (glds && g_gemm_mode >= 10 && M > 64)  // experimental N-stage ring variants (gemm_bf16_pipe.hip)
+        return launch_gemm_pipe(g_gemm_mode - 10, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     int variant;  // 1: 64x128, 2: 128x128, 3: 256x128
     if (M <= 64 || t128 < 384) variant = 1;

@@ -226,56 +226,48 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds3_kernel(
         for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / GBK;
-    // fragment loads of one 32-deep k-substep ks of a stage
-    auto load_frags = [&](int stage, int ks, short8_t (&af)[TM], short8_t (&bfr)[TN]) {
-        const unsigned char* sa = smem + stage * STAGE_BYTES;
-        const unsigned char* sb = sa + BM * 128;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = wm * (BM / WM) + i * 16 + fr;
-            const int c = ks * 4 + fq;
-            af[i] = *reinterpret_cast<const short8_t*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int row = wn * (BN / WN) + j * 16 + fr;
-            const int c = ks * 4 + fq;
-            bfr[j] = *reinterpret_cast<const short8_t*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-    };
-    auto mma = [&](const short8_t (&af)[TM], const short8_t (&bfr)[TN]) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    };
-
-    // Invariant at the top of iteration kt (after the barrier): tiles kt and kt+1 have landed and are visible
-    // to every wave, the third stage is free, and (a0,b0) already hold tile kt's ks=0 fragments.
     issue(0);
-    if (nk > 1) issue(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nk > 1) {
+        issue(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");  // tile 0 landed, tile 1 in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
-    short8_t a0[TM], b0[TN], a1[TM], b1[TN];
-    load_frags(0, 0, a0, b0);
 
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int nxt = stage == 2 ? 0 : stage + 1;
-        const int nxt2 = stage == 0 ? 2 : stage - 1;  // (stage + 2) % 3: read in iteration kt-1, free since its barrier
-        if (kt + 2 < nk) issue(nxt2);
-        load_frags(stage, 1, a1, b1);        // ks=1 fragments fly while the ks=0 MFMAs run
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) load_frags(nxt, 0, a0, b0);  // next tile's ks=0 fragments (tile kt+1 is already visible)
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+2 had this whole iteration to land
+        const int nxt2 = stage == 0 ? 2 : stage - 1;  // (stage + 2) % 3
+        if (kt + 2 < nk) issue(nxt2);                 // refills the buffer read in iteration kt-1 (all waves passed its barrier)
+        const unsigned char* sa = smem + stage * STAGE_BYTES;
+        const unsigned char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < GBK / 32; ++ks) {
+            short8_t af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * (BM / WM) + i * 16 + fr;
+                const int c = ks * 4 + fq;
+                af[i] = *reinterpret_cast<const short8_t*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * (BN / WN) + j * 16 + fr;
+                const int c = ks * 4 + fq;
+                bfr[j] = *reinterpret_cast<const short8_t*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        // tile kt+1 must have landed before anyone reads it; tile kt+2 (just issued) may stay in flight
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        stage = nxt;
+        stage = stage == 2 ? 0 : stage + 1;
     }
 
 #pragma unroll
