@@ -297,8 +297,9 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     DEVQA_CHECK_SHAPE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (M <= 32) return launch_gemm<32, 128, 1, 4>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
-    // mode 0: LDS-DMA staging when K % 64 == 0 (default); 1: force the register-staged kernels;
-    // 2: as 0 but 256x128 tiles for large problems (A/B testing via devqa_gemm_set_mode / DEVQA_GEMM)
+    // mode 0: LDS-DMA staging when K % 64 == 0, 256x256 tiles for large problems (default); 1: force the
+    // register-staged kernels; 2: LDS-DMA staging but no 256x256 tiles; 10..17: experimental ring variants
+    // (A/B testing via devqa_gemm_set_mode / DEVQA_GEMM)
     if (g_gemm_mode < 0) {
         const char* e = getenv("DEVQA_GEMM");
         g_gemm_mode = e ? atoi(e) : 0;
@@ -310,9 +311,10 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     if (glds && g_gemm_mode >= 10 && M > 64)  // experimental N-stage ring variants (gemm_bf16_pipe.hip)
         return launch_gemm_pipe(g_gemm_mode - 10, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    int variant;  // 1: 64x128, 2: 128x128, 3: 256x128
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    int variant;  // 1: 64x128, 2: 128x128, 3: 256x256 (128x64 wave tiles; fewest LDS and L2 bytes per FLOP)
     if (M <= 64 || t128 < 384) variant = 1;
-    else if (glds && g_gemm_mode == 2 && t128 >= 1024) variant = 3;
+    else if (glds && g_gemm_mode != 2 && t256 >= 128) variant = 3;
     else variant = 2;
     if (!glds) {
         if (variant == 1)
@@ -324,7 +326,7 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     int rc;
     if (variant == 1) rc = launch_gemm_glds_64x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     else if (variant == 2) rc = launch_gemm_glds_128x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
-    else rc = launch_gemm_glds_256x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    else rc = launch_gemm_pipe(6, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     if (prof) {
         (void)hipEventRecord(g_prof_ev[2 * g_prof_used + 1], st);
         g_prof_variant[g_prof_used] = variant;

@@ -62,9 +62,10 @@ int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64
 int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64_t ldw, int M, int N, int K,
                            int splits, float* partial_ws, float* out_f32, void* stream);
 
-/* Kernel selection for A/B measurements: 0 = default (LDS-DMA staged tiles when K % 64 == 0, register-staged
- * otherwise), 1 = always register-staged, 2 = default + 256x128 tiles for large problems.  Results are the
- * same up to fp32 summation order inside a 64-deep K step (identical: same MFMA sequence per output). */
+/* Kernel selection for A/B measurements: 0 = default (LDS-DMA staged tiles when K % 64 == 0 -- 256x256 for
+ * large problems, 128x128 / 64x128 below -- register-staged otherwise), 1 = always register-staged,
+ * 2 = LDS-DMA staged without the 256x256 tile, 10..17 = experimental ring variants (csrc/gemm_bf16_pipe.hip).
+ * Every variant issues the same MFMA sequence per output element, so results are bit-identical. */
 int devqa_gemm_set_mode(int mode);
 
 /* Measurement hook for bench.py's roofline: when enabled, every devqa_gemm_bf16 launch is bracketed by
