@@ -184,7 +184,7 @@ def main():
         total_cycles = world * K * E
         value = total_cycles / elapsed
         names = ["gemm_bf16_tn_kernel<32,128,1,4>", "gemm_bf16_glds_kernel<64,128,2,2>", "gemm_bf16_glds_kernel<128,128,2,2>",
-                 "gemm_bf16_pipe_kernel<256,256,2,4,64,2>"]
+                 "gemm_bf16_pipe_kernel<256,256,2,4,64,2,1>"]
         dom = max(range(4), key=lambda i: prof[i][0])
         g_ms = sum(p[0] for p in prof)
         g_fl = sum(p[1] for p in prof)

@@ -242,7 +242,7 @@ extern "C" int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const de
 
 static int g_gemm_mode = -1;
 extern "C" int devqa_gemm_set_mode(int mode) {
-    if (mode < 0 || (mode > 2 && (mode < 10 || mode > 17))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
+    if (mode < 0 || (mode > 2 && (mode < 10 || mode > 19))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
     g_gemm_mode = mode;
     return DEVQA_OK;
 }
@@ -326,7 +326,7 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     int rc;
     if (variant == 1) rc = launch_gemm_glds_64x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     else if (variant == 2) rc = launch_gemm_glds_128x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
-    else rc = launch_gemm_pipe(6, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    else rc = launch_gemm_pipe(7, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     if (prof) {
         (void)hipEventRecord(g_prof_ev[2 * g_prof_used + 1], st);
         g_prof_variant[g_prof_used] = variant;

@@ -17,7 +17,7 @@ __device__ __forceinline__ int swz(int row, int c) {
     else return c ^ ((0 - (row >> 2)) & 3);
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NST>
+template <int BM, int BN, int WM, int WN, int BKT, int NST, int PRIO = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_pipe_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
     const float* __restrict__ bias, int M, int N, int K, float alpha, int act, const float* residual,
@@ -115,11 +115,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_pipe_kernel(
                 const int row = wn * (BN / WN) + j * 16 + fr;
                 bfr[j] = *reinterpret_cast<const short8_t*>(sb + row * RB + (swz<BKT>(row, ks * 4 + fq) << 4));
             }
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
         {   // tile kt+1 must have landed; tiles kt+2 .. kt+NST-1 (those that exist) may stay in flight
             const int younger = min(nk - 1, kt + NST - 1) - (kt + 1);
@@ -171,13 +173,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_pipe_kernel(
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NST>
+template <int BM, int BN, int WM, int WN, int BKT, int NST, int PRIO = 0>
 static int launch_pipe(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K,
                        float alpha, int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc,
                        hipStream_t st) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t smem = (size_t)NST * (BM + BN) * BKT * 2;
-    auto kern = gemm_bf16_pipe_kernel<BM, BN, WM, WN, BKT, NST>;
+    auto kern = gemm_bf16_pipe_kernel<BM, BN, WM, WN, BKT, NST, PRIO>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -201,7 +203,9 @@ int launch_gemm_pipe(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int6
         case 4: return launch_pipe<256, 128, 4, 2, 64, 3>(ARGS);   // 144 KiB
         case 5: return launch_pipe<128, 128, 2, 2, 64, 2>(ARGS);   // == the 2-stage kernel, raw barrier
         case 6: return launch_pipe<256, 256, 2, 4, 64, 2>(ARGS);   // 128 KiB, simple 2-stage on 256x256
-        case 7: return launch_pipe<128, 256, 2, 4, 32, 4>(ARGS);   // 96 KiB, 8 waves of 64x64
+        case 7: return launch_pipe<256, 256, 2, 4, 64, 2, 1>(ARGS);  // as 6 with s_setprio around the MFMA block
+        case 8: return launch_pipe<256, 256, 4, 2, 64, 2>(ARGS);     // 64x128 wave tiles
+        case 9: return launch_pipe<256, 256, 2, 4, 32, 3>(ARGS);     // 96 KiB ring of 32-deep steps
     }
 #undef ARGS
     return devqa_fail(DEVQA_E_ARG, "gemm_pipe: unknown variant %d", id);
