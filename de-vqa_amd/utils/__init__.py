@@ -65,11 +65,14 @@ def load_vllm_for_edit(model_name: str, device: str, dtype="bf16"):  # :111-124
 
 
 def load_vllm_editor(editor_name: str, edit_model_name: str, device, extra_devices: List[int] = [1],
-                     editor_ckpt_path=None, for_train=False, dtype="bf16"):  # :126-175
+                     editor_ckpt_path=None, for_train=False, dtype="bf16", **editor_kwargs):  # :126-175
     editor_name = editor_name.lower()
     config_path = get_editor_config_path(editor_name, edit_model_name)
     vllm = load_vllm_for_edit(edit_model_name, device, dtype)
     if editor_name == "ft_vl":
         from ..editor.vllm_editors.ft_vl.ft_vl import FTvl, FTvlConfig
         return FTvl(vllm, FTvlConfig.from_yaml(config_path), device)
+    if editor_name == "ike_vl":  # needs corpus={sentences, embeddings} and encode=callable (see ike_vl.py)
+        from ..editor.vllm_editors.ike_vl.ike_vl import IKEvl, IKEvlConfig
+        return IKEvl(vllm, IKEvlConfig.from_yaml(config_path), device, **editor_kwargs)
     raise RuntimeError("No such editor %s" % editor_name)
