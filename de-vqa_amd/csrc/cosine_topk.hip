@@ -190,6 +190,129 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
     }
 }
 
+// Register-resident selection: the query's score row (N <= 256*NPT) is loaded ONCE, NPT values per thread;
+// every thread caches its local (max, index); each of the k+8 rounds is one workgroup arg-max over the cached
+// pairs, after which only the winning thread clears its element and rescans its NPT registers.  Same
+// (score desc, id asc) order as the multi-pass kernel it replaces; candidates are re-scored in fp64 as before.
+template <int NPT>
+__global__ __launch_bounds__(256) void topk_select_reg_kernel(const float* __restrict__ scores, const float* __restrict__ corpus,
+                                                              const float* __restrict__ queries, int N, int D, int k,
+                                                              int norm_c, int norm_q, int64_t* __restrict__ out_idx,
+                                                              float* __restrict__ out_score) {
+    __shared__ float red_s[4];
+    __shared__ int red_i[4];
+    __shared__ int cand_i[CT_MAXK + CT_MARGIN];
+    __shared__ double cand_s[CT_MAXK + CT_MARGIN];
+    __shared__ int win_i;
+    const int qi = blockIdx.x;
+    const float* row = scores + (int64_t)qi * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nc = min(k + CT_MARGIN, N);
+    float v[NPT];
+    float lmax = -INFINITY;
+    int lidx = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) {
+        const int i = r * 256 + tid;  // strided: coalesced loads, ascending ids per thread
+        v[r] = i < N ? row[i] : -INFINITY;
+        if (i < N && v[r] > lmax) {
+            lmax = v[r];
+            lidx = i;
+        }
+    }
+    for (int p = 0; p < nc; ++p) {
+        float bs = lmax;
+        int bi = lidx;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float s2 = __shfl_xor(bs, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64);
+            if (s2 > bs || (s2 == bs && i2 < bi)) {
+                bs = s2;
+                bi = i2;
+            }
+        }
+        if (lane == 0) {
+            red_s[wave] = bs;
+            red_i[wave] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (red_s[w] > bs || (red_s[w] == bs && red_i[w] < bi)) {
+                    bs = red_s[w];
+                    bi = red_i[w];
+                }
+            win_i = bi;
+            cand_i[p] = bi;
+        }
+        __syncthreads();
+        const int w = win_i;
+        if (w < N && (w & 255) == tid) {  // the owner clears it and rescans its registers
+            lmax = -INFINITY;
+            lidx = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < NPT; ++r) {
+                const int i = r * 256 + tid;
+                if (i == w) v[r] = -INFINITY;
+                if (i < N && i != w && v[r] > lmax) {
+                    lmax = v[r];
+                    lidx = i;
+                }
+            }
+            if (lmax == -INFINITY) {  // exhausted (or only -inf left): keep ids increasing among the rest
+                lidx = 0x7fffffff;
+            }
+        }
+    }
+    // fp64 re-score (dot and norms), one wave per candidate round-robin
+    const float* qv = queries + (int64_t)qi * D;
+    double qn = 0.0;
+    if (norm_q) {
+        for (int c = lane; c < D; c += 64) qn += (double)qv[c] * (double)qv[c];
+        qn = wave_sum_d(qn);
+    }
+    for (int p = wave; p < nc; p += 4) {
+        const int ci = cand_i[p];
+        double dot = 0.0, cn = 0.0;
+        if (ci >= 0 && ci < N) {
+            const float* cv = corpus + (int64_t)ci * D;
+            for (int c = lane; c < D; c += 64) {
+                const double x = (double)cv[c];
+                dot += x * (double)qv[c];
+                cn += x * x;
+            }
+        }
+        dot = wave_sum_d(dot);
+        cn = wave_sum_d(cn);
+        if (lane == 0) {
+            double s = dot;
+            if (norm_c) s = cn > 0.0 ? s / sqrt(cn) : 0.0;
+            if (norm_q) s = qn > 0.0 ? s / sqrt(qn) : 0.0;
+            cand_s[p] = (ci >= 0 && ci < N) ? s : -INFINITY;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int a = 1; a < nc; ++a) {
+            const double s = cand_s[a];
+            const int id = cand_i[a];
+            int b = a - 1;
+            while (b >= 0 && (cand_s[b] < s || (cand_s[b] == s && cand_i[b] > id))) {
+                cand_s[b + 1] = cand_s[b];
+                cand_i[b + 1] = cand_i[b];
+                --b;
+            }
+            cand_s[b + 1] = s;
+            cand_i[b + 1] = id;
+        }
+        for (int a = 0; a < k; ++a) {
+            out_idx[(int64_t)qi * k + a] = a < nc ? (int64_t)cand_i[a] : (int64_t)-1;
+            out_score[(int64_t)qi * k + a] = a < nc ? (float)cand_s[a] : -INFINITY;
+        }
+    }
+}
+
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 extern "C" int64_t devqa_cosine_topk_workspace(int N, int Q, int k) {
@@ -221,8 +344,15 @@ extern "C" int devqa_cosine_topk(const float* corpus, const float* queries, int 
     hipLaunchKernelGGL(score_tile_kernel, dim3((N + 63) / 64, (Q + 63) / 64), dim3(256), 0, st, corpus, queries, N, Q, D,
                        normalize_corpus ? inv_c : nullptr, normalize_queries ? inv_q : nullptr, scores);
     DEVQA_LAUNCH_CHECK("score_tile");
-    hipLaunchKernelGGL(topk_select_kernel, dim3(Q), dim3(256), 0, st, scores, corpus, queries, N, D, k, normalize_corpus,
-                       normalize_queries, out_idx, out_score);
+    if (N <= 256 * 16)
+        hipLaunchKernelGGL(topk_select_reg_kernel<16>, dim3(Q), dim3(256), 0, st, scores, corpus, queries, N, D, k,
+                           normalize_corpus, normalize_queries, out_idx, out_score);
+    else if (N <= 256 * 80)
+        hipLaunchKernelGGL(topk_select_reg_kernel<80>, dim3(Q), dim3(256), 0, st, scores, corpus, queries, N, D, k,
+                           normalize_corpus, normalize_queries, out_idx, out_score);
+    else
+        hipLaunchKernelGGL(topk_select_kernel, dim3(Q), dim3(256), 0, st, scores, corpus, queries, N, D, k, normalize_corpus,
+                           normalize_queries, out_idx, out_score);
     DEVQA_LAUNCH_CHECK("topk_select");
     return DEVQA_OK;
 }
