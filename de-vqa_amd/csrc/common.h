@@ -54,3 +54,17 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// fused GEMM epilogue activations (DEVQA_ACT_*)
+__device__ __forceinline__ float devqa_act(float v, int act) {
+    if (act == DEVQA_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DEVQA_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (act == DEVQA_ACT_QUICK_GELU) return v / (1.f + __expf(-1.702f * v));  // x * sigmoid(1.702 x), CLIP
+    return v;
+}
+__device__ __forceinline__ float4 devqa_act4(float4 v, int act) {
+    if (act != DEVQA_ACT_NONE) {
+        v.x = devqa_act(v.x, act); v.y = devqa_act(v.y, act); v.z = devqa_act(v.z, act); v.w = devqa_act(v.w, act);
+    }
+    return v;
+}

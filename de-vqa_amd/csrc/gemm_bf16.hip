@@ -148,8 +148,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(
                 const int m = m0 + wm * (BM / WM) + i * 16 + fq * 4 + r;
                 if (m >= M) continue;
                 float v = (acc[i][j][r] + b) * alpha;
-                if (act == DEVQA_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (act == DEVQA_ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+                v = devqa_act(v, act);
                 const int64_t o = (int64_t)m * ldc + n;
                 if (residual) v += residual[o];
                 if (out_f32) out_f32[o] = v;
@@ -288,7 +287,7 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
                                float* out_f32, int64_t ldc, void* stream) {
     DEVQA_CHECK_ARG(A && W, "gemm: null operand");
     DEVQA_CHECK_ARG(out_bf16 || out_f32, "gemm: no output");
-    DEVQA_CHECK_ARG(act >= 0 && act <= 2, "gemm: bad act %d", act);
+    DEVQA_CHECK_ARG(act >= 0 && act <= 3, "gemm: bad act %d", act);
     if (M == 0 || N == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "gemm: bad dims %d %d %d", M, N, K);
     DEVQA_CHECK_SHAPE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K/lda/ldw must be multiples of 8 (K=%d lda=%lld ldw=%lld)",

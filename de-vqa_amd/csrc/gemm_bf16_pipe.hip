@@ -149,14 +149,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_pipe_kernel(
                 v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
             }
             v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
-            if (act == DEVQA_ACT_RELU) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            } else if (act == DEVQA_ACT_GELU) {
-                v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752440f));
-                v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752440f));
-                v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752440f));
-                v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752440f));
-            }
+            v = devqa_act4(v, act);
             const int64_t o = (int64_t)m * ldc + n;
             if (residual) {
                 const float4 r = *reinterpret_cast<const float4*>(residual + o);

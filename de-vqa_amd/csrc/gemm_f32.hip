@@ -77,8 +77,7 @@ __global__ __launch_bounds__(256) void gemm_f32_tn_kernel(const float* __restric
             const int m = m0 + wave * 16 + fq * 4 + r;
             if (m >= M) continue;
             float v = (acc[j][r] + b) * alpha;
-            if (act == DEVQA_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (act == DEVQA_ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+            v = devqa_act(v, act);
             const int64_t o = (int64_t)m * ldc + n;
             if (residual) v += residual[o];
             out_f32[o] = v;
@@ -90,7 +89,7 @@ extern "C" int devqa_gemm_f32(const float* A, int64_t lda, const float* W, int64
                               int K, float alpha, int act, const float* residual, float* out_f32, int64_t ldc,
                               void* stream) {
     DEVQA_CHECK_ARG(A && W && out_f32, "gemm_f32: null pointer");
-    DEVQA_CHECK_ARG(act >= 0 && act <= 2, "gemm_f32: bad act %d", act);
+    DEVQA_CHECK_ARG(act >= 0 && act <= 3, "gemm_f32: bad act %d", act);
     if (M == 0 || N == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "gemm_f32: bad dims %d %d %d", M, N, K);
     DEVQA_CHECK_SHAPE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm_f32: K/lda/ldw must be multiples of 4");

@@ -1,0 +1,196 @@
+// LLaMA-family row kernels for the LLaVA / Vicuna decoder (BASELINE config #3):
+// RMSNorm forward / backward-dx, rotary position embedding, SwiGLU gate.  HBM-bound: 16-byte accesses,
+// one wave per row for the reductions (wavefront shuffles, row held in registers).
+#include "common.h"
+
+#define RN_MAXV 16
+
+// y = x * rsqrt(mean(x^2) + eps) * w      (HF LlamaRMSNorm: statistics and scaling in fp32)
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                      const float* __restrict__ w, int M, int D, float eps,
+                                                      bf16_t* __restrict__ out_bf16, float* __restrict__ out_f32) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    const float4* ar = add ? reinterpret_cast<const float4*>(add + (int64_t)row * D) : nullptr;
+    float4 v[RN_MAXV];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < RN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            float4 t = xr[c];
+            if (ar) {
+                const float4 u = ar[c];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            v[i] = t;
+            q += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float r = rsqrtf(wave_sum(q) / (float)D + eps);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+#pragma unroll
+    for (int i = 0; i < RN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            const float4 g = w4[c];
+            float4 o;
+            o.x = v[i].x * r * g.x; o.y = v[i].y * r * g.y; o.z = v[i].z * r * g.z; o.w = v[i].w * r * g.w;
+            if (out_f32) reinterpret_cast<float4*>(out_f32 + (int64_t)row * D)[c] = o;
+            if (out_bf16) {
+                uint2 p;
+                p.x = pack_bf16x2(o.x, o.y);
+                p.y = pack_bf16x2(o.z, o.w);
+                reinterpret_cast<uint2*>(out_bf16 + (int64_t)row * D)[c] = p;
+            }
+        }
+    }
+}
+
+extern "C" int devqa_rmsnorm(const float* x, const float* add, const float* w, int M, int D, float eps, devqa_bf16* out_bf16,
+                             float* out_f32, void* stream) {
+    DEVQA_CHECK_ARG(x && w && (out_bf16 || out_f32), "rmsnorm: null pointer");
+    if (M == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * RN_MAXV, "rmsnorm: D=%d unsupported", D);
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, w, M, D, eps, out_bf16,
+                       out_f32);
+    DEVQA_LAUNCH_CHECK("rmsnorm");
+    return DEVQA_OK;
+}
+
+// g = dy*w, r = rsqrt(mean(x^2)+eps):  dx = r*g - x * r^3 * mean(g*x)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                             const float* __restrict__ w, const float* __restrict__ dy, int M,
+                                                             int D, float eps, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    const float4* ar = add ? reinterpret_cast<const float4*>(add + (int64_t)row * D) : nullptr;
+    const float4* dr = reinterpret_cast<const float4*>(dy + (int64_t)row * D);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    float4 v[RN_MAXV], g[RN_MAXV];
+    float q = 0.f, s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            float4 t = xr[c];
+            if (ar) {
+                const float4 u = ar[c];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            const float4 d = dr[c], ww = w4[c];
+            v[i] = t;
+            g[i] = make_float4(d.x * ww.x, d.y * ww.y, d.z * ww.z, d.w * ww.w);
+            q += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+            s += (g[i].x * t.x + g[i].y * t.y) + (g[i].z * t.z + g[i].w * t.w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            g[i] = v[i];
+        }
+    }
+    const float r = rsqrtf(wave_sum(q) / (float)D + eps);
+    const float k = r * r * r * (wave_sum(s) / (float)D);
+#pragma unroll
+    for (int i = 0; i < RN_MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            float4 o;
+            o.x = r * g[i].x - v[i].x * k; o.y = r * g[i].y - v[i].y * k;
+            o.z = r * g[i].z - v[i].z * k; o.w = r * g[i].w - v[i].w * k;
+            reinterpret_cast<float4*>(dx + (int64_t)row * D)[c] = o;
+        }
+    }
+}
+
+extern "C" int devqa_rmsnorm_bwd_dx(const float* x, const float* add, const float* w, const float* dy, int M, int D, float eps,
+                                    float* dx, void* stream) {
+    DEVQA_CHECK_ARG(x && w && dy && dx, "rmsnorm_bwd_dx: null pointer");
+    if (M == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * RN_MAXV, "rmsnorm_bwd_dx: D=%d unsupported", D);
+    hipLaunchKernelGGL(rmsnorm_bwd_dx_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, w, dy, M, D, eps, dx);
+    DEVQA_LAUNCH_CHECK("rmsnorm_bwd_dx");
+    return DEVQA_OK;
+}
+
+// ---- rotary embedding, HF "rotate_half" convention, applied in place to n_heads heads of head dim dh that start
+// at column 0 of each row (q heads followed by k heads in the fused QKV buffer):
+//   for j < dh/2:  (x[j], x[j+dh/2]) <- (x[j]*c - x[j+dh/2]*s,  x[j+dh/2]*c + x[j]*s),  angle = pos * theta^(-2j/dh)
+__device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+
+template <typename T>
+__global__ void rope_kernel(T* __restrict__ x, int64_t ld, int R, const int32_t* __restrict__ pos, int n_heads, int dh,
+                            float log2_theta) {
+    const int half = dh >> 1;
+    const int64_t total = (int64_t)R * n_heads * half;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % half);
+        const int h = (int)((i / half) % n_heads);
+        const int64_t r = i / ((int64_t)half * n_heads);
+        const float inv_freq = exp2f(-log2_theta * (2.0f * (float)j / (float)dh));
+        const float ang = (float)pos[r] * inv_freq;
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        T* p = x + r * ld + (int64_t)h * dh + j;
+        const float a = ldf(p), b = ldf(p + half);
+        stf(p, a * cs - b * sn);
+        stf(p + half, b * cs + a * sn);
+    }
+}
+
+template <typename T>
+static int launch_rope(T* x, int64_t ld, int R, const int32_t* pos, int n_heads, int dh, float theta, void* stream) {
+    DEVQA_CHECK_ARG(x && pos, "rope: null pointer");
+    if (R == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(R > 0 && n_heads > 0 && dh > 0 && dh % 2 == 0 && ld >= (int64_t)n_heads * dh && theta > 1.f, "rope: bad dims");
+    const int64_t total = (int64_t)R * n_heads * (dh / 2);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(rope_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ld, R, pos, n_heads, dh, log2f(theta));
+    DEVQA_LAUNCH_CHECK("rope");
+    return DEVQA_OK;
+}
+extern "C" int devqa_rope_bf16(devqa_bf16* x, int64_t ld, int R, const int32_t* pos, int n_heads, int dh, float theta, void* stream) {
+    return launch_rope<bf16_t>(x, ld, R, pos, n_heads, dh, theta, stream);
+}
+extern "C" int devqa_rope_f32(float* x, int64_t ld, int R, const int32_t* pos, int n_heads, int dh, float theta, void* stream) {
+    return launch_rope<float>(x, ld, R, pos, n_heads, dh, theta, stream);
+}
+
+// ---- SwiGLU: out[r, j] = silu(gu[r, j]) * gu[r, F + j]  for the fused [gate | up] GEMM output [R, 2F]
+template <typename T>
+__global__ void swiglu_kernel(const T* __restrict__ gu, int R, int F, T* __restrict__ out) {
+    const int64_t total = (int64_t)R * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % F);
+        const int64_t r = i / F;
+        const float g = ldf(gu + r * 2 * F + j), u = ldf(gu + r * 2 * F + F + j);
+        stf(out + i, g / (1.f + __expf(-g)) * u);
+    }
+}
+template <typename T>
+static int launch_swiglu(const T* gu, int R, int F, T* out, void* stream) {
+    DEVQA_CHECK_ARG(gu && out, "swiglu: null pointer");
+    if (R == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(R > 0 && F > 0, "swiglu: bad dims");
+    const int64_t total = (int64_t)R * F;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(swiglu_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gu, R, F, out);
+    DEVQA_LAUNCH_CHECK("swiglu");
+    return DEVQA_OK;
+}
+extern "C" int devqa_swiglu_bf16(const devqa_bf16* gu, int R, int F, devqa_bf16* out, void* stream) {
+    return launch_swiglu<bf16_t>(gu, R, F, out, stream);
+}
+extern "C" int devqa_swiglu_f32(const float* gu, int R, int F, float* out, void* stream) {
+    return launch_swiglu<float>(gu, R, F, out, stream);
+}

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdevqa_hip.so")
 
-ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 
 class DevqaError(RuntimeError):
@@ -41,6 +41,12 @@ def load():
     _sig(L.devqa_abi_version, [])
     _sig(L.devqa_gemm_bf16, [P, I64, P, I64, P, I, I, I, F, I, P, P, P, I64, P])
     _sig(L.devqa_gemm_f32, [P, I64, P, I64, P, I, I, I, F, I, P, P, I64, P])
+    _sig(L.devqa_rmsnorm, [P, P, P, I, I, F, P, P, P])
+    _sig(L.devqa_rmsnorm_bwd_dx, [P, P, P, P, I, I, F, P, P])
+    _sig(L.devqa_rope_bf16, [P, I64, I, P, I, I, F, P])
+    _sig(L.devqa_rope_f32, [P, I64, I, P, I, I, F, P])
+    _sig(L.devqa_swiglu_bf16, [P, I, I, P, P])
+    _sig(L.devqa_swiglu_f32, [P, I, I, P, P])
     _sig(L.devqa_gemm_set_mode, [I])
     _sig(L.devqa_gemm_bf16_splitk, [P, I64, P, I64, I, I, I, I, P, P, P])
     _sig(L.devqa_profile_gemm, [I])
@@ -72,7 +78,8 @@ def load():
     return L
 
 
-EXPORTS = ["devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
+EXPORTS = ["devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
+           "devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
            "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
@@ -198,6 +205,50 @@ def layernorm(x, gamma, beta, eps, add=None, want="bf16"):
     if want == "both":
         return ob, of
     return ob if ob is not None else of
+
+
+def rmsnorm(x, w, eps, add=None, want="bf16"):
+    _need(x, torch.float32, "rmsnorm x")
+    M, D = x.shape
+    ob = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if want in ("bf16", "both") else None
+    of = torch.empty((M, D), dtype=torch.float32, device=x.device) if want in ("f32", "both") else None
+    if add is not None:
+        _need(add, torch.float32, "rmsnorm add")
+        assert add.shape == x.shape
+    _chk(load().devqa_rmsnorm(_p(x), _p(add), _p(w), M, D, float(eps), _p(ob), _p(of), _stream()), "devqa_rmsnorm")
+    if want == "both":
+        return ob, of
+    return ob if ob is not None else of
+
+
+def rmsnorm_bwd_dx(x, w, dy, eps, add=None):
+    _need(x, torch.float32, "rmsnorm_bwd x")
+    _need(dy, torch.float32, "rmsnorm_bwd dy")
+    M, D = x.shape
+    dx = torch.empty_like(x)
+    if add is not None:
+        _need(add, torch.float32, "rmsnorm_bwd add")
+    _chk(load().devqa_rmsnorm_bwd_dx(_p(x), _p(add), _p(w), _p(dy), M, D, float(eps), _p(dx), _stream()),
+         "devqa_rmsnorm_bwd_dx")
+    return dx
+
+
+def rope_(x, pos, n_heads, dh, theta):
+    """In-place rotary embedding on the first n_heads*dh columns of the 2-D (possibly strided) view x."""
+    assert x.dim() == 2 and x.stride(1) == 1 and pos.dtype == torch.int32 and pos.numel() == x.shape[0]
+    fn = load().devqa_rope_bf16 if x.dtype == torch.bfloat16 else load().devqa_rope_f32
+    _chk(fn(_p(x), x.stride(0), x.shape[0], _p(pos), int(n_heads), int(dh), float(theta), _stream()), "devqa_rope")
+    return x
+
+
+def swiglu(gu):
+    """gu [R, 2F] contiguous (gate | up) -> silu(gate) * up [R, F]"""
+    assert gu.dim() == 2 and gu.is_contiguous() and gu.shape[1] % 2 == 0
+    R, F2 = gu.shape
+    out = torch.empty((R, F2 // 2), dtype=gu.dtype, device=gu.device)
+    fn = load().devqa_swiglu_bf16 if gu.dtype == torch.bfloat16 else load().devqa_swiglu_f32
+    _chk(fn(_p(gu), R, F2 // 2, _p(out), _stream()), "devqa_swiglu")
+    return out
 
 
 def layernorm_bwd_dx(x, gamma, dy, eps, add=None):

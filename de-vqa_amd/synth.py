@@ -27,6 +27,18 @@ def param_init(name: str, shape, seed: int = 20251121, style: str = "unit") -> n
     is_ln = ("layer_norm" in low or "layernorm" in low)
     if is_ln and name.endswith("weight"):
         return (1.0 + 0.05 * z).astype(np.float32)
+    if style == "llava":  # CLIP ViT + LLaMA naming (de-vqa_amd/llava_spec.py)
+        if "norm" in low and name.endswith("weight") and len(shape) == 1:   # RMSNorm / pre_layrnorm / norm
+            return (1.0 + 0.05 * z).astype(np.float32)
+        if "class_embedding" in low:
+            return (0.5 * z).astype(np.float32)
+        if "position_embedding" in low:
+            return (0.02 * z).astype(np.float32)
+        if "embed_tokens" in low:
+            return (0.05 * z).astype(np.float32)
+        if name.endswith("mlp.up_proj.weight") and shape[0] > 1024:
+            # full-size models only: small SwiGLU activations so FT_VL (lr 1e-3) needs ~20 steps, as with "opt"
+            return (0.02 / np.sqrt(shape[1]) * z).astype(np.float32)
     if style == "opt":
         if "decoder.layers" in low and name.endswith("fc1.bias"):
             return (-0.3 + 0.02 * z).astype(np.float32)

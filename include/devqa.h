@@ -52,6 +52,7 @@ int devqa_abi_version(void);
 #define DEVQA_ACT_NONE 0
 #define DEVQA_ACT_RELU 1
 #define DEVQA_ACT_GELU 2 /* exact erf GELU (HF "gelu") */
+#define DEVQA_ACT_QUICK_GELU 3 /* x * sigmoid(1.702 x) (HF "quick_gelu", CLIP ViT in LLaVA) */
 int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64_t ldw, const float* bias,
                     int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
                     float* out_f32, int64_t ldc, void* stream);
@@ -88,6 +89,22 @@ int devqa_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, con
  */
 int devqa_layernorm(const float* x, const float* add, const float* gamma, const float* beta, int M, int D, float eps,
                     devqa_bf16* out_bf16, float* out_f32, void* stream);
+
+/* ---- LLaMA-family row ops (LLaVA / Vicuna decoder; csrc/llama_ops.hip) -----------------------
+ * devqa_rmsnorm        : y = (x [+ add]) * rsqrt(mean((x+add)^2) + eps) * w   (HF LlamaRMSNorm), bf16 and/or fp32 out
+ * devqa_rmsnorm_bwd_dx : gradient of the above w.r.t. its input
+ * devqa_rope_*         : rotary embedding (HF rotate_half convention, angle = pos * theta^(-2j/dh)), in place on the
+ *                        first n_heads*dh columns of each row (q heads then k heads of a fused QKV buffer)
+ * devqa_swiglu_*       : out[r,j] = silu(gu[r,j]) * gu[r,F+j] for the fused [gate|up] projection output [R,2F]
+ */
+int devqa_rmsnorm(const float* x, const float* add, const float* w, int M, int D, float eps, devqa_bf16* out_bf16,
+                  float* out_f32, void* stream);
+int devqa_rmsnorm_bwd_dx(const float* x, const float* add, const float* w, const float* dy, int M, int D, float eps, float* dx,
+                         void* stream);
+int devqa_rope_bf16(devqa_bf16* x, int64_t ld, int R, const int32_t* pos, int n_heads, int dh, float theta, void* stream);
+int devqa_rope_f32(float* x, int64_t ld, int R, const int32_t* pos, int n_heads, int dh, float theta, void* stream);
+int devqa_swiglu_bf16(const devqa_bf16* gu, int R, int F, devqa_bf16* out, void* stream);
+int devqa_swiglu_f32(const float* gu, int R, int F, float* out, void* stream);
 
 /* ---- attention (K3 ViT self-attn, K4 Q-Former self/cross-attn, K7 OPT causal attn) ----------
  * Packed varlen softmax attention: for sequence s (0..n_seq), query rows
