@@ -69,10 +69,9 @@ class BatchedEditEval:
     def supports(editor, eval_data, edit_n):
         try:
             from .editor.vllm_editors.ft_vl.ft_vl import FTvl
-            from .editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
         except Exception:
             return False
-        if not (isinstance(editor, FTvl) and isinstance(editor.vllm, BLIP2OPTForEdit)):
+        if not (isinstance(editor, FTvl) and hasattr(editor.vllm, "engine") and hasattr(editor.vllm.engine, "pack_from_tokens")):
             return False
         if edit_n != 1 or editor.cfg.batch_size != 1:
             return False
@@ -127,10 +126,13 @@ class BatchedEditEval:
         return rows
 
     # ------------------------------------------------------------------------------------------
-    def _tok(self, s):
+    def _tok(self, s, has_image=False):
+        # wrappers whose text carries an image placeholder (LLaVA: '<image>\n' auto-prefix) tokenise the full string
+        if hasattr(self.vllm, "batched_token_ids"):
+            return self.vllm.batched_token_ids(s, has_image)
         return self.vllm.tokenizer(s)["input_ids"]
 
-    def _probe_seq(self, prompt, target):
+    def _probe_seq(self, prompt, target, has_image=False):
         """xym bookkeeping for one (prompt, target): -> (token ids, labels [L], mask [L]).
         Pre-tokenised inputs (lists of ids; synthetic benchmark data) follow the same rule as
         R/editor/vllms_for_edit/base.py:97-108: labels = roll(ids,-1), mask[len(prompt)-1:-1] = 1,
@@ -144,7 +146,7 @@ class BatchedEditEval:
                 msk[j] = 1
             return ids, lab[n_p - 1:], msk[n_p - 1:]
         strs, y, m, _ = self.vllm.xym_token_bookkeeping([prompt], [target])
-        return self._tok(strs[0]), y[0].tolist(), m[0].tolist()
+        return self._tok(strs[0], has_image), y[0].tolist(), m[0].tolist()
 
     @torch.no_grad()
     def run_batch(self, rds: List[Dict], eds: List[Dict]):
@@ -183,7 +185,7 @@ class BatchedEditEval:
             plist = []
 
             def add(kind, name, item_ed, item_rd, target_key):
-                ids, y, m = self._probe_seq(item_ed["prompt"], item_ed[target_key])
+                ids, y, m = self._probe_seq(item_ed["prompt"], item_ed[target_key], item_ed["image"] is not None)
                 p = _Probe()
                 p.kind, p.name, p.rd, p.ed = kind, name, item_rd, item_ed
                 p.seq = seq_id(img_id(item_ed["image"]), ids)
@@ -200,7 +202,7 @@ class BatchedEditEval:
             tgt = req["target_new"]
             if isinstance(tgt, str) and tgt[0] != " ":
                 tgt = " " + tgt
-            ids, y, m = self._probe_seq(req["prompt"], tgt)
+            ids, y, m = self._probe_seq(req["prompt"], tgt, req["image"] is not None)
             rows = [j for j in range(len(y)) if m[j] != 0]
             edits.append((seq_id(img_id(req["image"]), ids), len(y), rows, [y[j] for j in rows]))
         kmax = max(len(e[2]) for e in edits)
@@ -227,7 +229,7 @@ class BatchedEditEval:
         ps = eng.pack_from_tokens(seqs, img_tokens, share_prefix=self.share_prefix)
         x_mid, a = eng.decoder_layers(ps, stop_before_fc2=True)
         d = x_mid.shape[1]
-        b2 = eng._p("language_model.model.decoder.layers.%d.fc2.bias" % eng.edit_layer)
+        b2 = eng.edit_bias()   # None for LLaMA-family decoders
         wname = self.editor._edit_target()
         w0 = self.vllm.model.get(wname)               # fp32 master [d, ffn]
         w0_op = self.vllm.model.weight_for_gemm(wname)  # GEMM operand (bf16 shadow, or the master in fp32 mode)
@@ -259,7 +261,9 @@ class BatchedEditEval:
         fidx = torch.tensor(ft_idx, dtype=torch.int32, device=dev)
         a_ft = lib.gather_rows(a, fidx).to(torch.float32).view(E, kmax, -1).contiguous()
         a_ft = a_ft * torch.from_numpy(mask).to(dev).unsqueeze(-1)   # zero the padding rows (plumbing)
-        resid_ft = (lib.gather_rows(x_mid, fidx) + b2).contiguous()  # [E*kmax, d] incl. fc2 bias
+        resid_ft = lib.gather_rows(x_mid, fidx)                      # [E*kmax, d] (+ fc2 bias when the model has one)
+        if b2 is not None:
+            resid_ft = (resid_ft + b2).contiguous()
         del a, x_mid
         torch.cuda.synchronize()
         t3 = time.time()
@@ -350,7 +354,6 @@ class BatchedEditEval:
         n_steps = torch.zeros(E, dtype=torch.int32, device=dev)
         adam_t = torch.zeros(E, dtype=torch.int32, device=dev)
         losses = torch.zeros((E, cfg.num_steps), dtype=torch.float32, device=dev)
-        gamma = eng._p("language_model.model.decoder.final_layer_norm.weight")
         clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else -1.0
         y = lib.rows_matvec(w0, a_ft)  # step-0 fc2 rows with the pristine matrix (active columns carry all of W.a)
         dl_dtype = eng.adt
@@ -361,7 +364,7 @@ class BatchedEditEval:
                                           dlogits_dtype=dl_dtype)
             lib.ft_step_control(nll, t_mask, it, cfg.num_steps, 1e-2, active, do_update, n_steps, adam_t, losses)
             dH = lib.gemm_rows_longk(dlog, self.vllm.model.embed_T)
-            dy = lib.layernorm_bwd_dx(y2, gamma, dH, 1e-5, add=resid_ft).view(E, kmax, Dout)
+            dy = eng.final_norm_bwd(y2, dH, add=resid_ft).view(E, kmax, Dout)
             lib.ft_adamw_step(w, mom, var, w0, a_ft, dy, y, do_update, adam_t, cfg.lr, 0.9, 0.999, 1e-8, cfg.weight_decay,
                               clamp)
         self._adam_t = adam_t

@@ -12,8 +12,9 @@ w - w0, model restored, delta then added in place).  What changes is how a step 
   * gradient + AdamW + the next forward's fc2 rows are ONE HBM sweep over the matrix
     (devqa_ft_adamw_step), the rank-L gradient is never materialised.
 
-Supported edit target on this path: `...decoder.layers.<last>.fc2.weight` (what every shipped
-FT_VL config selects: R/configs/ft_vl/blip2-opt-2.7b.yaml:2,8).  Other targets would need a full
+Supported edit target on this path: the LAST decoder layer's FFN output matrix (`...decoder.layers.<last>.fc2.weight`
+for BLIP-2-OPT, `language_model.model.layers.<last>.mlp.down_proj.weight` for LLaVA -- what every shipped FT_VL
+config selects: R/configs/ft_vl/{blip2-opt-2.7b,llava-v1.5-7b}.yaml:2,8).  Other targets would need a full
 backward pass through the network and raise NotImplementedError.
 """
 from copy import deepcopy
@@ -83,8 +84,7 @@ class FTvl(VLLMBaseEditor):
     # ---------------------------------------------------------------------------------------
     def _edit_target(self):
         names = self._selected_names()
-        t = self.vllm.model.cfg["text_config"]
-        want = "language_model.model.decoder.layers.%d.fc2.weight" % (t["num_hidden_layers"] - 1)
+        want = self.vllm.engine.edit_target()
         if names != [want]:
             raise NotImplementedError("native FT_VL edits %s only; config selects %s" % (want, names))
         return want
@@ -109,7 +109,8 @@ class FTvl(VLLMBaseEditor):
         idx = torch.tensor(rows, dtype=torch.int32, device=eng.dev)
         a_rows = lib.gather_rows(a, idx).to(torch.float32).unsqueeze(0).contiguous()
         resid = lib.gather_rows(x_mid, idx)
-        resid = resid + eng._p("language_model.model.decoder.layers.%d.fc2.bias" % eng.edit_layer)
+        if eng.edit_bias() is not None:
+            resid = resid + eng.edit_bias()
         return a_rows, resid.contiguous(), torch.tensor(labels, dtype=torch.int32, device=eng.dev)
 
     def execute_ft(self, requests: List[Dict]) -> Dict[str, torch.Tensor]:
@@ -133,7 +134,6 @@ class FTvl(VLLMBaseEditor):
         one = torch.ones(1, dtype=torch.int32, device=dev)
         adam_t = torch.zeros(1, dtype=torch.int32, device=dev)
         clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else -1.0  # ft_vl.py:135
-        gamma = eng._p("language_model.model.decoder.final_layer_norm.weight")
         updated = False
         y_next = None
         self.last_losses = []
@@ -157,7 +157,7 @@ class FTvl(VLLMBaseEditor):
                 cnt += n_items
                 if loss >= LOSS_FLOOR:
                     dH = lib.gemm_rows_longk(dlog, self.vllm.model.embed_T)
-                    dy = lib.layernorm_bwd_dx(pre_ln, gamma, dH, 1e-5).view(1, k, Dout)
+                    dy = eng.final_norm_bwd(pre_ln, dH).view(1, k, Dout)
                     adam_t += 1
                     y_next = torch.empty((1, k, Dout), dtype=torch.float32, device=dev)
                     lib.ft_adamw_step(w, mom, var, w0, a_rows, dy.contiguous(), y_next, one, adam_t, cfg.lr, 0.9, 0.999,

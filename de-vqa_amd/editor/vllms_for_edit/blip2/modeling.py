@@ -63,35 +63,51 @@ class Blip2Native(nn.Module):
         self._build()
 
     # -- construction -------------------------------------------------------------------------
+    def _small_f32_names(self):
+        return ("query_tokens", "vision_model.embeddings.class_embedding", "vision_model.embeddings.position_embedding",
+                "vision_model.embeddings.patch_embedding.weight")
+
+    def _fused_slot(self, name):
+        """-> (group key, slot, n_slots) when `name` is a row block of a fused GEMM operand, else None.
+        BLIP-2: the OPT q/k/v projections of a layer share one [3d, d] buffer (+ one [3d] bias)."""
+        if ".self_attn." in name and "decoder.layers" in name:
+            kind = name.split("self_attn.")[1].split(".")[0]
+            if kind in ("q_proj", "k_proj", "v_proj"):
+                layer = name.split("decoder.layers.")[1].split(".")[0]
+                return ("dec_qkv." + layer, {"q_proj": 0, "k_proj": 1, "v_proj": 2}[kind], 3)
+        return None
+
     def _build(self):
         dev = self.dev
-        d = self.cfg["text_config"]["hidden_size"]
-        fused_w, fused_b = {}, {}
+        self.fused_w, self.fused_b = {}, {}
+        small = set(self._small_f32_names())
         for name, shape in self._shapes.items():
             is_vec = len(shape) == 1
-            small_f32 = name in ("query_tokens", "vision_model.embeddings.class_embedding",
-                                 "vision_model.embeddings.position_embedding",
-                                 "vision_model.embeddings.patch_embedding.weight")
-            dt = torch.float32 if (is_vec or small_f32) else self.wdtype
-            if ".self_attn." in name and "decoder.layers" in name and any(
-                    k in name for k in ("q_proj", "k_proj", "v_proj")):
-                layer = name.split("decoder.layers.")[1].split(".")[0]
-                slot = {"q_proj": 0, "k_proj": 1, "v_proj": 2}[name.split("self_attn.")[1].split(".")[0]]
-                if name.endswith("weight"):
-                    buf = fused_w.setdefault(layer, torch.zeros((3 * d, d), dtype=self.wdtype, device=dev))
+            dt = torch.float32 if (is_vec or name in small) else self.wdtype
+            fs = self._fused_slot(name)
+            if fs is not None:
+                key, slot, nslots = fs
+                rows = shape[0]
+                if not is_vec:
+                    buf = self.fused_w.setdefault(key, torch.zeros((nslots * rows, shape[1]), dtype=self.wdtype, device=dev))
                 else:
-                    buf = fused_b.setdefault(layer, torch.zeros((3 * d,), dtype=torch.float32, device=dev))
-                data = buf[slot * d:(slot + 1) * d]
+                    buf = self.fused_b.setdefault(key, torch.zeros((nslots * rows,), dtype=torch.float32, device=dev))
+                data = buf[slot * rows:(slot + 1) * rows]
             else:
                 data = torch.zeros(shape, dtype=dt, device=dev)
             _attach(self, name, nn.Parameter(data, requires_grad=False))
-        self.fused_qkv_w = fused_w
-        self.fused_qkv_b = fused_b
+        # legacy views used by the BLIP-2 engine: per-layer fused OPT qkv
+        self.fused_qkv_w = {k.split(".", 1)[1]: v for k, v in self.fused_w.items() if k.startswith("dec_qkv.")}
+        self.fused_qkv_b = {k.split(".", 1)[1]: v for k, v in self.fused_b.items() if k.startswith("dec_qkv.")}
+        self._build_derived()
+
+    def _build_derived(self):
+        dev = self.dev
         v = self.cfg["vision_config"]
         self.patch_kreal = 3 * v["patch_size"] ** 2
-        self.patch_kpad = (self.patch_kreal + 31) // 32 * 32
+        self.patch_kpad = (self.patch_kreal + 63) // 64 * 64   # K % 64 == 0: LDS-DMA staged GEMM path
         self.patch_w_gemm = torch.zeros((v["hidden_size"], self.patch_kpad), dtype=self.wdtype, device=dev)
-        self.embed_T = None  # [d, V] bf16 transposed copy of the tied embedding (dH = dlogits . E)
+        self.embed_T = None  # [d, V] transposed copy of the (tied) output embedding (dH = dlogits . E)
         self._derived_version = None
 
     def get(self, name):

@@ -260,6 +260,20 @@ class Blip2Engine:
                      "language_model.model.decoder.final_layer_norm.bias", LN_EPS_OPT, add=add)
         return lib.gemm(h, self._p("language_model.model.decoder.embed_tokens.weight"), want="f32")
 
+    # ---- what an FT_VL-style editor needs to know about the edited layer (shared with LlavaEngine) ----
+    def edit_target(self):
+        return "language_model.model.decoder.layers.%d.fc2.weight" % self.edit_layer
+
+    def edit_bias(self):
+        return self._p("language_model.model.decoder.layers.%d.fc2.bias" % self.edit_layer)
+
+    def final_norm_bwd(self, x_rows, dH, add=None):
+        return lib.layernorm_bwd_dx(x_rows, self._p("language_model.model.decoder.final_layer_norm.weight"), dH, LN_EPS_OPT,
+                                    add=add)
+
+    def embed_table(self):
+        return self._p("language_model.model.decoder.embed_tokens.weight")
+
     @torch.no_grad()
     def full_logits(self, ps: PackedSeqs):
         x, _ = self.decoder_layers(ps)
