@@ -96,6 +96,23 @@ def cpu_baseline(cfg, seed, threads, arrays=None):
                       % (t_enc, t_dec, t_step, cyc), "weight_gen_s": round(gen_s, 1)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE and
+    WRITE_SIZE are collected in separate profiler runs of this same command, so the figure is read from the newest
+    profiles/*pmc_traffic.json rather than measured inside the timed run).  None when no pass covers the kernel."""
+    import glob
+    key = kernel.replace(" ", "")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            for r in json.load(open(f))["kernels"]:
+                if r["kernel"].replace(" ", "").startswith(key):
+                    return {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "read": r["read_bytes_per_launch"],
+                            "write": r["write_bytes_per_launch"], "source": os.path.basename(f)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,7 +201,7 @@ def main():
         total_cycles = world * K * E
         value = total_cycles / elapsed
         names = ["gemm_bf16_tn_kernel<32,128,1,4>", "gemm_bf16_glds_kernel<64,128,2,2>", "gemm_bf16_glds_kernel<128,128,2,2>",
-                 "gemm_bf16_pipe_kernel<256,256,2,4,64,2,1>"]
+                 "gemm_bf16_pp_kernel"]
         dom = max(range(4), key=lambda i: prof[i][0])
         g_ms = sum(p[0] for p in prof)
         g_fl = sum(p[1] for p in prof)
@@ -195,6 +212,7 @@ def main():
         exec_per_cycle = g_fl / (K * E) / 1e12
         alg_scale = min(1.0, A_MIN_TFLOP_PER_CYCLE / exec_per_cycle) if exec_per_cycle > 0 else 0.0
         achieved = (dfl * alg_scale / 1e12) / (dms / 1e3) if dms > 0 else 0.0
+        traffic = pmc_traffic(names[dom])
         out = {
             "metric": "edit+eval cycles/sec, BLIP-2 FT_VL EVQA", "value": round(value, 3), "unit": "cycles/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 2),
@@ -205,7 +223,7 @@ def main():
                        "cycles_per_step": E, "cycles_total": total_cycles, "mean_ft_steps": round(steps_mean, 2),
                        "layers": "39/12/32" if layers is None else args.layers, "sharding": "splits block-partitioned, 1 gather"},
             "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_us": round(1e3 * dms / max(dn, 1), 2), "launches": int(dn),
                          "executed_tflops": round((dfl / 1e12) / (dms / 1e3), 1) if dms > 0 else 0.0,
                          "all_gemm_executed_tflops": round((g_fl / 1e12) / (g_ms / 1e3), 1) if g_ms > 0 else 0.0,

@@ -220,7 +220,10 @@ class BatchedEditEval:
         # ---- 2. vision ---------------------------------------------------------------------------
         img_tokens = None
         if img_list:
-            chunks = [eng.encode_images(pix[i:i + 32]) for i in range(0, len(img_list), 32)]
+            chunks, i0 = [], 0
+            for c in eng.image_chunks(len(img_list)):
+                chunks.append(eng.encode_images(pix[i0:i0 + c]))
+                i0 += c
             img_tokens = torch.cat(chunks) if len(chunks) > 1 else chunks[0]
         torch.cuda.synchronize()
         t2 = time.time()

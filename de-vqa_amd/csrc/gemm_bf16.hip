@@ -241,13 +241,15 @@ extern "C" int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const de
 
 static int g_gemm_mode = -1;
 extern "C" int devqa_gemm_set_mode(int mode) {
-    if (mode < 0 || (mode > 2 && (mode < 10 || mode > 19))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
+    if (mode < 0 || (mode > 3 && (mode < 10 || mode > 23))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
     g_gemm_mode = mode;
     return DEVQA_OK;
 }
 
 int launch_gemm_pipe(int id, const bf16_t*, int64_t, const bf16_t*, int64_t, const float*, int, int, int, float, int, const float*,
                      bf16_t*, float*, int64_t, hipStream_t);  // gemm_bf16_pipe.hip
+int launch_gemm_pp(int id, const bf16_t*, int64_t, const bf16_t*, int64_t, const float*, int, int, int, float, int, const float*,
+                   bf16_t*, float*, int64_t, hipStream_t);    // gemm_bf16_pp.hip
 // LDS-DMA staged variants (gemm_bf16_glds.hip)
 int launch_gemm_glds_64x128(const bf16_t*, int64_t, const bf16_t*, int64_t, const float*, int, int, int, float, int, const float*,
                             bf16_t*, float*, int64_t, hipStream_t);
@@ -307,11 +309,13 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     const bool vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && ((((uintptr_t)out_f32) | ((uintptr_t)residual) | ((uintptr_t)bias)) & 15) == 0 &&
                         (((uintptr_t)out_bf16) & 7) == 0;
     const bool glds = (K % 64 == 0) && g_gemm_mode != 1 && vec_ok;
+    if (glds && g_gemm_mode >= 20 && M > 64)  // 256x256 ping-pong variants (gemm_bf16_pp.hip)
+        return launch_gemm_pp(g_gemm_mode - 20, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     if (glds && g_gemm_mode >= 10 && M > 64)  // experimental N-stage ring variants (gemm_bf16_pipe.hip)
         return launch_gemm_pipe(g_gemm_mode - 10, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    int variant;  // 1: 64x128, 2: 128x128, 3: 256x256 (128x64 wave tiles; fewest LDS and L2 bytes per FLOP)
+    int variant;  // 1: 64x128, 2: 128x128, 3: 256x256 ping-pong (gemm_bf16_pp.hip; mode 3 = the simple 2-stage 256x256 ring)
     if (M <= 64 || t128 < 384) variant = 1;
     else if (glds && g_gemm_mode != 2 && t256 >= 128) variant = 3;
     else variant = 2;
@@ -325,7 +329,9 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     int rc;
     if (variant == 1) rc = launch_gemm_glds_64x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     else if (variant == 2) rc = launch_gemm_glds_128x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
-    else rc = launch_gemm_pipe(7, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    else if (g_gemm_mode == 3 || (int64_t)M * lda * 2 >= (1ll << 32) || (int64_t)N * ldw * 2 >= (1ll << 32))  // mode 3: previous default
+        rc = launch_gemm_pipe(7, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+    else rc = launch_gemm_pp(2, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     if (prof) {
         (void)hipEventRecord(g_prof_ev[2 * g_prof_used + 1], st);
         g_prof_variant[g_prof_used] = variant;

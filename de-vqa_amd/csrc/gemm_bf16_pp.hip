@@ -1,0 +1,311 @@
+// bf16 TN GEMM, 256x256x64 tiles, 8 waves (2 x 4, 128x64 per wave), two wave groups running half a phase apart
+// ("ping-pong"): while waves 0-3 issue MFMAs, waves 4-7 (their SIMD partners) read LDS fragments and issue the
+// LDS-DMA prefetch, and vice versa.  A K-tile is computed in 4 phases (one 64x32 quadrant of the wave tile x K=64,
+// 16 MFMA each); every phase prefetches one 128-row half-tile (A0/A1/B0/B1, 16 KiB) of a later K-tile.
+//
+// LDS (128 KiB): 2 K-tile buffers x [A0 | A1 | B0 | B1], each [128 rows][64] bf16.  A-half h holds rows
+// {wr*128 + h*64 + 0..63} of the block (wr = 0,1), B-half h columns {wc*64 + h*32 + 0..31} (wc = 0..3): the rows a
+// quadrant needs are one half-tile.  16-byte chunks are XOR-swizzled on the SOURCE address (LDS-DMA writes
+// lane-linear): pc = c ^ ((row >> 1) & 7), conflict-free for ds_read_b128.
+//
+// Schedule (g = 4t + p, tile t, phase p).  Phase p reads: p0 A0(t),B0(t); p1 B1(t); p2 A1(t); p3 nothing, and stages
+// slot g: p0 B1(t+1), p1 A1(t+1), p2 A0(t+2), p3 B0(t+2).  After staging, `s_waitcnt vmcnt(8)`: all but the 4
+// youngest half-tiles have landed, so a half-tile staged in phase s is readable from phase s+5 (RAW: the wait of
+// phase s+4 by EVERY wave precedes a barrier the reader has passed, also for the group running one barrier late),
+// and a region is restaged no earlier than 2 phases after its last ds_read (WAR under the stagger).  With two
+// buffers this is the deepest prefetch that satisfies both (derivation in DESIGN.md "256x256 ping-pong GEMM").
+#include "common.h"
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+namespace {
+
+constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64;
+constexpr int PP_HALF = 16384;         // bytes of one half-tile
+constexpr int PP_BUF = 4 * PP_HALF;    // bytes of one K-tile buffer
+enum { R_A0 = 0, R_A1 = 1, R_B0 = 2, R_B1 = 3 };
+
+struct PPState {
+    const char* gA;            // uniform base pointers (K-tile 0)
+    const char* gW;
+    unsigned off[4][2];        // [region][piece] byte offset of this thread's 16 bytes from gA / gW (< 4 GiB, checked on the host)
+    unsigned char* smem;
+    int dst;                   // wave * 2048: this wave's two 1-KiB pieces inside a half-tile
+    int la0, la1, lb0, lb1;    // per-lane fragment byte offsets (ks = 0/1) inside an A / B half-tile
+};
+
+template <int REGION>
+__device__ __forceinline__ void pp_stage(const PPState& s, int t) {
+    unsigned char* d = s.smem + (t & 1) * PP_BUF + REGION * PP_HALF + s.dst;
+    const char* g = (REGION < 2 ? s.gA : s.gW) + (int64_t)t * (PP_BK * 2);   // uniform: SGPR base + 32-bit lane offset
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + (uint64_t)s.off[REGION][0]), (lptr_t)d, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + (uint64_t)s.off[REGION][1]), (lptr_t)(d + 1024), 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void pp_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void pp_mfma_block(float4_t (&acc)[8][4], const short8_t (&a)[4][2], const short8_t (&b)[2][2],
+                                              const int i0, const int j0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[i0 + i][j0 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// TAIL: 0 = tiles t+1 and t+2 exist, 1 = only t+1 exists, 2 = last tile
+template <int TAIL>
+__device__ __forceinline__ void pp_tile(const PPState& s, int t, float4_t (&acc)[8][4], short8_t (&a)[4][2], short8_t (&b0)[2][2],
+                                        short8_t (&b1)[2][2]) {
+    const unsigned char* base = s.smem + (t & 1) * PP_BUF;
+    // ---- phase 0: quadrant (a0, b0)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        b0[j][0] = *reinterpret_cast<const short8_t*>(base + R_B0 * PP_HALF + j * 2048 + s.lb0);
+        b0[j][1] = *reinterpret_cast<const short8_t*>(base + R_B0 * PP_HALF + j * 2048 + s.lb1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i][0] = *reinterpret_cast<const short8_t*>(base + R_A0 * PP_HALF + i * 2048 + s.la0);
+        a[i][1] = *reinterpret_cast<const short8_t*>(base + R_A0 * PP_HALF + i * 2048 + s.la1);
+    }
+    if constexpr (TAIL <= 1) { pp_stage<R_B1>(s, t + 1); pp_vmcnt<8>(); } else { pp_vmcnt<2>(); }
+    __builtin_amdgcn_s_barrier();
+    pp_mfma_block(acc, a, b0, 0, 0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: quadrant (a0, b1)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        b1[j][0] = *reinterpret_cast<const short8_t*>(base + R_B1 * PP_HALF + j * 2048 + s.lb0);
+        b1[j][1] = *reinterpret_cast<const short8_t*>(base + R_B1 * PP_HALF + j * 2048 + s.lb1);
+    }
+    if constexpr (TAIL <= 1) { pp_stage<R_A1>(s, t + 1); pp_vmcnt<8>(); } else { pp_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+    pp_mfma_block(acc, a, b1, 0, 2);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: quadrant (a1, b1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i][0] = *reinterpret_cast<const short8_t*>(base + R_A1 * PP_HALF + i * 2048 + s.la0);
+        a[i][1] = *reinterpret_cast<const short8_t*>(base + R_A1 * PP_HALF + i * 2048 + s.la1);
+    }
+    if constexpr (TAIL == 0) { pp_stage<R_A0>(s, t + 2); pp_vmcnt<8>(); } else if constexpr (TAIL == 1) { pp_vmcnt<6>(); } else { pp_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+    pp_mfma_block(acc, a, b1, 4, 2);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: quadrant (a1, b0)
+    if constexpr (TAIL == 0) { pp_stage<R_B0>(s, t + 2); pp_vmcnt<8>(); } else if constexpr (TAIL == 1) { pp_vmcnt<4>(); } else { pp_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+    pp_mfma_block(acc, a, b0, 4, 0);
+    __builtin_amdgcn_s_barrier();
+}
+
+}  // namespace
+
+// Epilogue activation on 4 values; the bf16 kernels use a 1.5e-7-accurate erf (Abramowitz-Stegun 7.1.26) for GELU --
+// far below the bf16 rounding of the stored result (the fp32 kernels keep erff).
+template <int ACT>
+__device__ __forceinline__ float pp_act(float x) {
+    if constexpr (ACT == DEVQA_ACT_RELU) return fmaxf(x, 0.f);
+    if constexpr (ACT == DEVQA_ACT_GELU) {
+        const float z = fabsf(x) * 0.70710678118654752440f;
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+        float p = fmaf(1.061405429f, t, -1.453152027f);
+        p = fmaf(p, t, 1.421413741f);
+        p = fmaf(p, t, -0.284496736f);
+        p = fmaf(p, t, 0.254829592f);
+        const float e = p * t * __expf(-z * z);      // 1 - erf(z)
+        return 0.5f * x * (x >= 0.f ? 2.f - e : e);  // 0.5 x (1 + erf(x / sqrt 2))
+    }
+    if constexpr (ACT == DEVQA_ACT_QUICK_GELU) return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
+    return x;
+}
+
+typedef __bf16 pp_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float pp_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pp_pack2(float a, float b) {   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    pp_f32x2_t f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, pp_bf16x2_t));
+}
+
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+                                                           int64_t ldw, const float* __restrict__ bias, int M, int N, int K, float alpha,
+                                                           const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc,
+                                                           int tiles_m, int tiles_n, int group_m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {   // workgroups that share an XCD (blockIdx % 8) get a contiguous range of tile ids (bijective for any nwg)
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tile_m, tile_n;
+    {   // grouped order: consecutive ids walk group_m row-tiles of one column-tile, then the next column-tile, so the
+        // ~32 workgroups an XCD runs together share A row panels and W column panels in its L2
+        const int per_group = group_m * tiles_n;
+        const int g = bid / per_group, in_g = bid - g * per_group;
+        const int gm = min(group_m, tiles_m - g * group_m);
+        tile_m = g * group_m + in_g % gm;
+        tile_n = in_g / gm;
+    }
+    const int m0 = tile_m * PP_BM, n0 = tile_n * PP_BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    PPState s;
+    s.smem = smem;
+    s.gA = reinterpret_cast<const char*>(A);
+    s.gW = reinterpret_cast<const char*>(W);
+    s.dst = wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3);          // row inside the half-tile
+        const int sc = (lane & 7) ^ ((r >> 1) & 7);              // source chunk for LDS chunk (lane & 7)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int grow = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), M - 1);
+            const int gcol = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), N - 1);
+            s.off[h][i] = (unsigned)(((int64_t)grow * lda + sc * 8) * 2);          // R_A0 + h
+            s.off[2 + h][i] = (unsigned)(((int64_t)gcol * ldw + sc * 8) * 2);      // R_B0 + h
+        }
+    }
+    {
+        const int c0 = (fq ^ ((fr >> 1) & 7)) << 4;
+        s.la0 = wr * 8192 + fr * 128 + c0;
+        s.la1 = wr * 8192 + fr * 128 + (c0 ^ 64);
+        s.lb0 = wc * 4096 + fr * 128 + c0;
+        s.lb1 = wc * 4096 + fr * 128 + (c0 ^ 64);
+    }
+
+    float4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    short8_t a[4][2], b0[2][2], b1[2][2];
+
+    const int nk = K / PP_BK;
+    // prologue: slots -6..-1 = A0,B0,B1,A1 of tile 0 and A0,B0 of tile 1; A0(0), B0(0) must have landed
+    pp_stage<R_A0>(s, 0);
+    pp_stage<R_B0>(s, 0);
+    pp_stage<R_B1>(s, 0);
+    pp_stage<R_A1>(s, 0);
+    if (nk > 1) {
+        pp_stage<R_A0>(s, 1);
+        pp_stage<R_B0>(s, 1);
+        pp_vmcnt<8>();
+    } else {
+        pp_vmcnt<4>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier interval behind waves 0-3
+
+    int t = 0;
+    for (; t + 2 < nk; ++t) pp_tile<0>(s, t, acc, a, b0, b1);
+    if (t + 1 < nk) {
+        pp_tile<1>(s, t, acc, a, b0, b1);
+        ++t;
+    }
+    pp_tile<2>(s, t, acc, a, b0, b1);
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // match the extra barrier of waves 4-7
+
+    // ---- epilogue.  All LDS traffic of the K loop is over (last ds_read in phase 2 of the last tile, all LDS-DMA
+    // retired by the vmcnt(0) of its phases 1-3, and every wave is past two more barriers).  Each wave transposes its
+    // 128x64 accumulator tile through a PRIVATE 16-KiB LDS region, 64 rows at a time, so that global accesses are
+    // row-contiguous: a lane owns 4 consecutive columns of one row, 16 lanes cover 256 B (fp32) / 128 B (bf16) of it.
+    // MFMA operands were fed swapped: acc[i][j][e] = C[i*16 + fr][j*16 + fq*4 + e].
+    unsigned char* stg = smem + wave * 16384;
+    const int q = lane & 15;
+    const int gn = n0 + wc * 64 + q * 4;
+    const bool col_ok = gn < N;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr && col_ok) bv = *reinterpret_cast<const float4*>(bias + gn);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int gm0 = m0 + wr * 128 + half * 64 + (lane >> 4);   // + it * 4
+        float4 rv[16];
+        if (residual != nullptr) {   // all 16 loads in flight before the first store (residual may alias out_f32)
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int gm = gm0 + it * 4;
+                rv[it] = (col_ok && gm < M) ? *reinterpret_cast<const float4*>(residual + (int64_t)gm * ldc + gn)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = i * 16 + fr;
+                *reinterpret_cast<float4_t*>(stg + row * 256 + (((j * 4 + fq) ^ (row & 15)) << 4)) = acc[half * 4 + i][j];
+            }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            const float4_t sv = *reinterpret_cast<const float4_t*>(stg + row * 256 + ((q ^ (row & 15)) << 4));
+            const int gm = gm0 + it * 4;
+            float4 v = make_float4((sv[0] + bv.x) * alpha, (sv[1] + bv.y) * alpha, (sv[2] + bv.z) * alpha, (sv[3] + bv.w) * alpha);
+            v.x = pp_act<ACT>(v.x); v.y = pp_act<ACT>(v.y); v.z = pp_act<ACT>(v.z); v.w = pp_act<ACT>(v.w);
+            if (residual != nullptr) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+            if (col_ok && gm < M) {
+                const int64_t o = (int64_t)gm * ldc + gn;
+                if (out_f32) *reinterpret_cast<float4*>(out_f32 + o) = v;
+                if (out_bf16) {
+                    uint2 p;
+                    p.x = pp_pack2(v.x, v.y);
+                    p.y = pp_pack2(v.z, v.w);
+                    *reinterpret_cast<uint2*>(out_bf16 + o) = p;
+                }
+            }
+        }
+    }
+}
+
+template <int ACT>
+static int launch_pp(int group_m, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K,
+                     float alpha, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc, hipStream_t st) {
+    const int tiles_m = (M + PP_BM - 1) / PP_BM, tiles_n = (N + PP_BN - 1) / PP_BN;
+    const size_t smem = 2 * PP_BUF;
+    auto kern = gemm_bf16_pp_kernel<ACT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, A, lda, W, ldw, bias, M, N, K, alpha, residual, out_bf16,
+                       out_f32, ldc, tiles_m, tiles_n, group_m);
+    DEVQA_LAUNCH_CHECK("gemm_bf16_pp");
+    return DEVQA_OK;
+}
+
+// id: 0 group_m 8, 1 group_m 1 (plain column-major tile order), 2 group_m 4 (default), 3 group_m 16
+int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K, float alpha,
+                   int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc, hipStream_t st) {
+    static const int gms[4] = {8, 1, 4, 16};
+    if (id < 0 || id > 3) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
+    if (K % PP_BK != 0 || K < PP_BK) return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: K=%d must be a positive multiple of 64", K);
+    if ((int64_t)M * lda * 2 >= (1ll << 32) || (int64_t)N * ldw * 2 >= (1ll << 32))
+        return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: operands must span < 4 GiB (32-bit lane offsets)");
+#define ARGS gms[id], A, lda, W, ldw, bias, M, N, K, alpha, residual, out_bf16, out_f32, ldc, st
+    switch (act) {
+        case DEVQA_ACT_NONE: return launch_pp<DEVQA_ACT_NONE>(ARGS);
+        case DEVQA_ACT_RELU: return launch_pp<DEVQA_ACT_RELU>(ARGS);
+        case DEVQA_ACT_GELU: return launch_pp<DEVQA_ACT_GELU>(ARGS);
+        case DEVQA_ACT_QUICK_GELU: return launch_pp<DEVQA_ACT_QUICK_GELU>(ARGS);
+    }
+#undef ARGS
+    return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown activation %d", act);
+}

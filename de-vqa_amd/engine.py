@@ -19,6 +19,26 @@ from . import lib
 LN_EPS_OPT = 1e-5
 
 
+def plan_image_chunks(n, tokens, gemm_shapes, max_chunk=128, n_cu=256, tile=256):
+    """Partition n images into chunk sizes minimising sum over chunks and GEMMs of ceil(tiles/n_cu) * K."""
+    def cost(c):
+        tm = -(-c * tokens // tile)
+        return sum(-(-(tm * -(-N // tile)) // n_cu) * K for N, K in gemm_shapes)
+    cs = [0] + [cost(c) for c in range(1, min(n, max_chunk) + 1)]
+    best = [0] + [None] * n
+    pick = [0] * (n + 1)
+    for i in range(1, n + 1):
+        for c in range(1, min(i, max_chunk) + 1):
+            v = best[i - c] + cs[c]
+            if best[i] is None or v < best[i] or (v == best[i] and c > pick[i]):
+                best[i], pick[i] = v, c
+    out = []
+    while n > 0:
+        out.append(pick[n])
+        n -= pick[n]
+    return out
+
+
 @dataclass
 class PackedSeqs:
     """Sequences packed along rows.  Row r of sequence s sits at start[s] + r."""
@@ -65,6 +85,19 @@ class Blip2Engine:
             d = torch.tensor(rows, dtype=torch.int32, device=self.dev)
             self._seq_desc_cache[key] = d
         return d
+
+    def image_chunks(self, n, max_chunk=128):
+        """Split n images into encode_images() calls.  The ViT GEMMs run 256x256 tiles, one workgroup per CU, so a call
+        costs ceil(tiles / 256) rounds per GEMM; pick the partition of n that minimises the summed rounds x K (DP over
+        chunk sizes) instead of a fixed chunk."""
+        return plan_image_chunks(n, self._vit_tokens(), self._vit_gemm_shapes(), max_chunk)
+
+    def _vit_tokens(self):
+        return (self.v["image_size"] // self.v["patch_size"]) ** 2 + 1
+
+    def _vit_gemm_shapes(self):
+        d, f = self.v["hidden_size"], self.v["intermediate_size"]
+        return [(3 * d, d), (d, d), (f, d), (d, f)]
 
     # ------------------------------------------------------------------------------------------
     # K2-K5: images -> projected query tokens [B, Q, d_llm] (fp32)

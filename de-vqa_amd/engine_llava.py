@@ -7,7 +7,7 @@ CLS -> multi_modal_projector -> splice at the `<image>` token) and :63-68 (langu
 import torch
 
 from . import lib
-from .engine import PackedSeqs
+from .engine import PackedSeqs, plan_image_chunks
 
 
 class LlavaEngine:
@@ -43,6 +43,13 @@ class LlavaEngine:
         return d
 
     # ---- CLIP ViT (all but the last layer) + projector: [B, n_img, d_llm] fp32 -----------------------------
+    def image_chunks(self, n, max_chunk=64):
+        """See Blip2Engine.image_chunks: partition that minimises 256x256-tile rounds of the CLIP GEMMs."""
+        v = self.v
+        d, f = v["hidden_size"], v["intermediate_size"]
+        tokens = (v["image_size"] // v["patch_size"]) ** 2 + 1
+        return plan_image_chunks(n, tokens, [(3 * d, d), (d, d), (f, d), (d, f)], max_chunk)
+
     @torch.no_grad()
     def encode_images(self, pixels):
         m, v = self.m, self.v

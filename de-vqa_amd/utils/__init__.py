@@ -61,6 +61,9 @@ def load_vllm_for_edit(model_name: str, device: str, dtype="bf16"):  # :111-124
     if "blip2" in model_name:
         from ..editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
         return BLIP2OPTForEdit(model_path, device, dtype=dtype)
+    if "llava" in model_name:
+        from ..editor.vllms_for_edit.llava.llava import LlavaForEdit
+        return LlavaForEdit(model_path, device, True, dtype=dtype)
     raise BaseException("Have not write `BaseVLLMForEdit` for `%s`." % model_name)
 
 
