@@ -36,7 +36,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __res
     __shared__ __attribute__((aligned(16))) unsigned char Ks[AM_KC * STRIDE];
     __shared__ __attribute__((aligned(16))) unsigned char Vs[AM_KC * STRIDE];
 
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    {   // workgroups that share an XCD (blockIdx % 8) take a contiguous range of ids: the q tiles of one (sequence, head)
+        // then read their K/V through ONE L2 instead of up to q_tiles different ones
+        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
     const int qt = bid % q_tiles;
     const int h = (bid / q_tiles) % H;
     const int s = bid / (q_tiles * H);
@@ -68,27 +73,46 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __res
     float m_run = -INFINITY, l_run = 0.f;  // statistics of query fr (replicated over the 4 lane groups)
 
     constexpr int CH = DHP / 8;  // 16-byte chunks per row
-    for (int c0 = 0; c0 < n_keys; c0 += AM_KC) {
-        __syncthreads();  // previous chunk fully consumed
-        for (int i = tid; i < AM_KC * CH; i += 256) {
+    constexpr int LD = AM_KC * CH / 256;  // 16-byte pieces of K (and of V) per thread and chunk
+    static_assert(AM_KC * CH % 256 == 0, "chunk must split evenly over the workgroup");
+    uint4 kreg[LD], vreg[LD];
+    auto fetch = [&](int c0) {   // chunk c0 -> registers (zero beyond n_keys / dh)
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            const int i = tid + j * 256;
             const int r = i / CH, cv = i % CH;
             const int kidx = c0 + r;
-            uint4 ku = make_uint4(0, 0, 0, 0), vu = ku;
+            kreg[j] = make_uint4(0, 0, 0, 0);
+            vreg[j] = kreg[j];
             if (kidx < n_keys && cv * 8 < dh) {
                 const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);
-                ku = *reinterpret_cast<const uint4*>(k + grow * ldk + h * dh + cv * 8);
-                vu = *reinterpret_cast<const uint4*>(v + grow * ldv + h * dh + cv * 8);
+                kreg[j] = *reinterpret_cast<const uint4*>(k + grow * ldk + h * dh + cv * 8);
+                vreg[j] = *reinterpret_cast<const uint4*>(v + grow * ldv + h * dh + cv * 8);
             }
-            *reinterpret_cast<uint4*>(Ks + r * STRIDE + cv * 16) = ku;
-            *reinterpret_cast<uint4*>(Vs + r * STRIDE + cv * 16) = vu;
+        }
+    };
+    const bool wave_has_rows = q0 + wave * 16 < q_len;  // waves without a query still stage K/V and hit the barriers
+    if (n_keys > 0) fetch(0);
+    for (int c0 = 0; c0 < n_keys; c0 += AM_KC) {
+        __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            const int i = tid + j * 256;
+            const int r = i / CH, cv = i % CH;
+            *reinterpret_cast<uint4*>(Ks + r * STRIDE + cv * 16) = kreg[j];
+            *reinterpret_cast<uint4*>(Vs + r * STRIDE + cv * 16) = vreg[j];
         }
         __syncthreads();
+        if (c0 + AM_KC < n_keys) fetch(c0 + AM_KC);  // next chunk's loads fly under this chunk's MFMAs
+        if (!wave_has_rows) continue;
+        const int nt = min(4, (n_keys - c0 + 15) >> 4);  // 16-key tiles of this chunk that hold a key (uniform)
 
         // ---- S^T tiles: keys 16t + (4fq + r), query fr ----
         float4_t st[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (t >= nt) continue;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const short8_t kf = *reinterpret_cast<const short8_t*>(Ks + (16 * t + fr) * STRIDE + (32 * ks + 8 * fq) * 2);
@@ -155,6 +179,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __res
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                if (2 * s2 >= nt) continue;   // both key tiles of this k-step are past the last key (P = 0 there)
                 const short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (lds_s4_ptr)(Vs + (16 * (2 * s2) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
                 const short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
