@@ -121,3 +121,34 @@ def synth_image_u8(sample, tag, size=224, seed=20251121):
     """uint8 [size,size,3] i.i.d. U{0..255} image for (sample, tag)."""
     rng = np.random.default_rng([seed, sample, zlib.crc32(tag.encode())])
     return rng.integers(0, 256, size=(size, size, 3), dtype=np.uint8)
+
+
+def mend_aux_init(name: str, shape, seed: int = 7) -> np.ndarray:
+    """Deterministic, finite MEND hyper-network state for fixtures/benchmarks (a trained `Best` checkpoint is the real
+    source): low-rank factors of O(1/sqrt(fan_in)), mode scale ~1, normalisation buffers with positive std.  Names are
+    the state_dict keys of the reference's `aux_models` / `edit_lrs` (mend_vl.py:254-256)."""
+    rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+    shape = tuple(int(s) for s in shape)
+    z = rng.standard_normal(shape, dtype=np.float32) if len(shape) else np.float32(rng.standard_normal())
+    leaf = name.split(".")[-1]
+    if name.startswith("edit_lrs"):
+        return np.asarray(1e-2 * (1.0 + 0.1 * abs(float(z))), np.float32).reshape(shape)
+    if leaf in ("u_std", "v_std"):
+        base = 0.5 if leaf == "u_std" else 2e-3
+        return (base * (1.0 + 0.2 * np.abs(z))).astype(np.float32)
+    if leaf in ("u_mean", "v_mean"):
+        base = 0.05 if leaf == "u_mean" else 1e-4
+        return (base * z).astype(np.float32)
+    if leaf in ("u_s", "v_s"):
+        return np.abs(z).astype(np.float32)
+    if leaf == "k":
+        return np.full(shape, 100.0, np.float32)
+    if name.endswith("mode_scale.weight"):
+        return (1.0 + 0.1 * z).astype(np.float32)
+    if name.endswith("mode_shift.weight") or leaf == "bias":
+        return (0.05 * z).astype(np.float32)
+    if leaf == "u":   # [outf, rank]
+        return (0.5 / np.sqrt(shape[1]) * z).astype(np.float32)
+    if leaf == "v":   # [rank, inf]
+        return (1.0 / np.sqrt(shape[1]) * z).astype(np.float32)
+    return (0.02 * z).astype(np.float32)

@@ -212,10 +212,17 @@ class OracleBlip2:
             o = torch.matmul(a, v).transpose(1, 2).reshape(B, T, D)
             x = x + _lin(o, w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"])
             h = _ln(x, w[p + "final_layer_norm.weight"], w[p + "final_layer_norm.bias"], self.t_eps)
-            a1 = F.relu(_lin(h, w[p + "fc1.weight"], w[p + "fc1.bias"]))
+            hook = getattr(self, "module_hook", None)  # (module name, input, output) -> output; MEND-style editors
+            f1 = _lin(h, w[p + "fc1.weight"], w[p + "fc1.bias"])
+            if hook is not None:
+                f1 = hook(p + "fc1", h, f1)
+            a1 = F.relu(f1)
             if upto_layer is not None and i == upto_layer:
                 taps = (x, a1)
-            x = x + _lin(a1, w[p + "fc2.weight"], w[p + "fc2.bias"])
+            f2 = _lin(a1, w[p + "fc2.weight"], w[p + "fc2.bias"])
+            if hook is not None:
+                f2 = hook(p + "fc2", a1, f2)
+            x = x + f2
         return x, taps
 
     def get_llm_outpt(self, llm_inpt, vt_range=None):

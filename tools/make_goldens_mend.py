@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""G6 goldens for MEND_VL: runs the REFERENCE's MENDvl (editor/vllm_editors/mend_vl) on the tiny BLIP-2 fixture in this
+build container (never on the GPU box) and stores inputs/outputs only:
+
+  * tests/golden/tiny_mend_ckpt.pt  -- a `Best`-layout checkpoint (R/editor/vllm_editors/base.py:237-252) holding
+    deterministic, finite hyper-network parameters and normalisation buffers (the reference's init has u = 0, i.e. an
+    identity transform, and NaN buffers until trained -- neither would pin anything);
+  * tests/golden/tiny_mend_cfg.yaml -- the MENDvlConfig used;
+  * tests/golden/tiny_mend_goldens.{npz,json} -- per edited module: hooked input x, output gradient delta, transformed
+    factors, delta weight (single edit, 2 sequential edits = running mean, a batch of 2 requests), post-edit logits,
+    logit_KL_loss known answers, and evaluator results for 4 samples at edit_n = 1.
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_goldens as MG  # noqa: E402  (installs the import stubs, puts the reference on sys.path)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+from devqa_amd.synth import mend_aux_init  # noqa: E402
+
+GOLD = MG.GOLD
+t2n = MG.t2n
+
+
+def main():
+    from copy import deepcopy
+    from editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from editor.vllm_editors.mend_vl import mend_vl as ref_mend
+    from evaluation.vllm_editor_eval import VLLMEditorEvaluation
+    from dataset.vllm import BaseVLLMEditData
+
+    os.chdir(GOLD)
+    rec = json.load(open(os.path.join(GOLD, "evqa8_records.json")))
+    records = rec["records"]
+    cfg_d = {
+        "edit_model_name": "blip2-opt-2.7b",
+        "edit_modules": ["language_model.model.decoder.layers.0.fc1", "language_model.model.decoder.layers.0.fc2",
+                         "language_model.model.decoder.layers.1.fc1", "language_model.model.decoder.layers.1.fc2"],
+        "init_edit_lr": 1.0e-2, "edit_lr_lr": 1.0e-4, "relia_lambda": 0.1, "gen_lambda": 0.1, "loc_lambda": 0.1,
+        "aux_model": {"n_hidden": 1, "hidden_dim": None, "init": "id", "norm": True, "act": "relu", "rank": 16,
+                      "shared": True, "lr": 1.0e-6},
+    }
+    yaml.safe_dump(cfg_d, open(os.path.join(GOLD, "tiny_mend_cfg.yaml"), "w"))
+    cfg = ref_mend.MENDvlConfig.from_yaml(os.path.join(GOLD, "tiny_mend_cfg.yaml"))
+    vllm = BLIP2OPTForEdit(os.path.join(GOLD, "tiny_blip2"), "cpu")
+    ed = ref_mend.MENDvl(vllm, cfg, "cpu")
+    # deterministic finite hyper-network state
+    mods = ed.get_modules_for_training()
+    for mname, mod in mods.items():
+        sd = mod.state_dict()
+        for k in sd:
+            sd[k] = torch.from_numpy(mend_aux_init("%s.%s" % (mname, k), tuple(sd[k].shape), 7))
+        mod.load_state_dict(sd)
+    for gt in ed.aux_models.values():
+        gt.norm_init = True
+    ckpt = {"i": 1, "epoch": 1, "loss": 0.0, "ema_loss": 0.0,
+            "train_modules": {k: {n: t.clone() for n, t in v.state_dict().items()} for k, v in mods.items()},
+            "opt": None, "lr_scheduler": None}
+    torch.save(ckpt, os.path.join(GOLD, "tiny_mend_ckpt.pt"))
+
+    npz, js = {}, {"modules": cfg_d["edit_modules"], "cases": []}
+
+    def capture(tag):
+        for i, em in enumerate(ed.edit_modules):
+            npz["%s_x_%d" % (tag, i)] = t2n(em.__x__).astype(np.float32)
+            npz["%s_delta_%d" % (tag, i)] = t2n(em.__delta__).astype(np.float32)
+            xo, do = em.aux_model_weight(em.__x__, em.__delta__, em.idx)
+            npz["%s_xt_%d" % (tag, i)] = t2n(xo).astype(np.float32)
+            npz["%s_dt_%d" % (tag, i)] = t2n(do).astype(np.float32)
+            npz["%s_dw_%d" % (tag, i)] = t2n(em.__delta_weight__).astype(np.float32)
+
+    probe = records[2]["generality"]["text_rephrase"][0]
+
+    def probe_logits():
+        with torch.no_grad():
+            (x, vt), y, m = vllm.prompts_imgs_target_to_xym([probe["prompt"]], [probe["image"]], [probe["target"]])
+            return t2n(vllm.get_llm_outpt(x, vt).logits).astype(np.float32)
+
+    # case A: one edit
+    r0, r1 = deepcopy(records[0]["requests"][0]), deepcopy(records[1]["requests"][0])
+    ed.restore_to_original_model()
+    npz["pre_logits"] = probe_logits()
+    ed.edit_one_piece(deepcopy(r0))
+    capture("a")
+    npz["a_post_logits"] = probe_logits()
+    js["cases"].append({"tag": "a", "requests": [r0]})
+    # case B: a second edit on top (running mean of the delta weights, mend_vl.py:106-114)
+    ed.edit_one_piece(deepcopy(r1))
+    capture("b")
+    npz["b_post_logits"] = probe_logits()
+    js["cases"].append({"tag": "b", "requests": [r0, r1], "sequential": True})
+    # case C: a batch of two requests in one call
+    # (text-only: the reference's BLIP-2 wrapper encodes imgs[-1] only, blip2.py:54-55, so image batches cannot run)
+    t0 = {"image": None, "prompt": records[0]["locality"]["text_loc"][0]["prompt"], "target_new": "a short answer"}
+    t1 = {"image": None, "prompt": records[1]["locality"]["t1i4"][0]["prompt"], "target_new": "blue"}
+    ed.restore_to_original_model()
+    ed.edit_batch([deepcopy(t0), deepcopy(t1)])
+    capture("c")
+    npz["c_post_logits"] = probe_logits()
+    js["cases"].append({"tag": "c", "requests": [t0, t1], "sequential": False})
+    ed.restore_to_original_model()
+    npz["restored_logits"] = probe_logits()
+    js["probe"] = probe
+    # logit_KL_loss known answers (K18)
+    g = torch.Generator().manual_seed(3)
+    l1 = torch.randn(2, 7, 50, generator=g)
+    l2 = l1 + 0.3 * torch.randn(2, 7, 50, generator=g)
+    mk = torch.tensor([[1, 1, 0, 0], [0, 1, 1, 1]])
+    npz["kl_l1"], npz["kl_l2"], npz["kl_mask"] = t2n(l1), t2n(l2), t2n(mk)
+    js["kl"] = float(ref_mend.logit_KL_loss(l1, l2, mk))
+    js["kl_sum"] = float(ref_mend.logit_KL_loss(l1, l2, mk, average=False))
+
+    # evaluator, 4 samples, edit_n = 1
+    class Data(BaseVLLMEditData):
+        def dataset_name(self):
+            return "EVQA"
+    data = Data(deepcopy(records[:4]), deepcopy(records[:4]))
+    out_dir = "/tmp/devqa_mend_eval"
+    ev = VLLMEditorEvaluation(ed, data, "EVQA", out_dir)
+    res = ev.evaluate_sequential_edit(1, False, None)
+    js["results_sen1"] = res
+    np.savez_compressed(os.path.join(GOLD, "tiny_mend_goldens.npz"), **npz)
+    json.dump(js, open(os.path.join(GOLD, "tiny_mend_goldens.json"), "w"), indent=1, default=str)
+    print("mend goldens written:", len(npz), "arrays")
+
+
+if __name__ == "__main__":
+    main()
