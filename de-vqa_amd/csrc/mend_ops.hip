@@ -1,0 +1,139 @@
+// Small row-wise kernels of the MEND_VL edit path (R/editor/vllm_editors/mend_vl): ReLU backward for the hooked fc1
+// gradient, the GradientTransform input normalisation + concat (auxiliary_networks.py:138-148), the LRLinear epilogue
+// (auxiliary_networks.py:70-83) and logit_KL_loss rows (mend_vl.py:355-366).  All HBM-bound, one pass.
+#include "common.h"
+
+template <typename T> __device__ __forceinline__ float mo_ld(const T* p);
+template <> __device__ __forceinline__ float mo_ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float mo_ld<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void mo_st(T* p, float v);
+template <> __device__ __forceinline__ void mo_st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void mo_st<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// grad_in = grad_out where act_out > 0 else 0  (act_out = relu(pre): act_out > 0 <=> pre > 0)
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ act_out, const T* __restrict__ grad_out, T* __restrict__ grad_in, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        mo_st<T>(grad_in + i, mo_ld<T>(act_out + i) > 0.f ? mo_ld<T>(grad_out + i) : 0.f);
+}
+
+// out[r, 0:du] = (u[idx[r], :] - u_mean) / (u_std + eps);  out[r, du:du+dv] = (v[idx[r], :] - v_mean) / (v_std + eps)
+// (mean/std NULL: plain gather-concat, cfg.norm == False)
+__global__ void mend_normalize_concat_kernel(const float* __restrict__ u, const float* __restrict__ v, const int32_t* __restrict__ idx,
+                                             const float* __restrict__ u_mean, const float* __restrict__ u_std,
+                                             const float* __restrict__ v_mean, const float* __restrict__ v_std, float eps, int du,
+                                             int dv, float* __restrict__ out) {
+    const int r = blockIdx.x;
+    const int64_t src = idx ? idx[r] : r;
+    const int D = du + dv;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float x;
+        if (c < du) {
+            x = u[src * du + c];
+            if (u_mean) x = (x - u_mean[c]) / (u_std[c] + eps);
+        } else {
+            const int cc = c - du;
+            x = v[src * dv + cc];
+            if (v_mean) x = (x - v_mean[cc]) / (v_std[cc] + eps);
+        }
+        out[(int64_t)r * D + c] = x;
+    }
+}
+
+// out = max((pre + bias) * scale + shift, 0) + x      (LRLinear with init == 'id'; scale/shift = the mode's rows)
+__global__ void mend_lrlinear_epilogue_kernel(const float* __restrict__ pre, const float* __restrict__ bias, const float* __restrict__ scale,
+                                              const float* __restrict__ shift, const float* __restrict__ x, float* __restrict__ out,
+                                              int64_t n, int D) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        float p = pre[i] + (bias ? bias[c] : 0.f);
+        if (scale) p = p * scale[c] + shift[c];
+        out[i] = fmaxf(p, 0.f) + x[i];
+    }
+}
+
+// kl[r] = sum_v softmax(l1[r])_v * (log_softmax(l1[r])_v - log_softmax(l2[r])_v)   (one workgroup per row)
+__global__ __launch_bounds__(256) void logit_kl_rows_kernel(const float* __restrict__ l1, const float* __restrict__ l2, int64_t ld1,
+                                                            int64_t ld2, int V, float* __restrict__ kl) {
+    __shared__ float red[8];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* a = l1 + (int64_t)r * ld1;
+    const float* b = l2 + (int64_t)r * ld2;
+    auto block_max = [&](float v) {
+        v = wave_max(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    };
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    float ma = -INFINITY, mb = -INFINITY;
+    for (int c = tid; c < V; c += 256) { ma = fmaxf(ma, a[c]); mb = fmaxf(mb, b[c]); }
+    ma = block_max(ma);
+    mb = block_max(mb);
+    float sa = 0.f, sb = 0.f;
+    for (int c = tid; c < V; c += 256) { sa += expf(a[c] - ma); sb += expf(b[c] - mb); }
+    sa = block_sum(sa);
+    sb = block_sum(sb);
+    const float lza = ma + logf(sa), lzb = mb + logf(sb);
+    float acc = 0.f;
+    for (int c = tid; c < V; c += 256) {
+        const float lp1 = a[c] - lza, lp2 = b[c] - lzb;
+        acc += expf(lp1) * (lp1 - lp2);
+    }
+    acc = block_sum(acc);
+    if (tid == 0) kl[r] = acc;
+}
+
+static inline unsigned mo_grid(int64_t n) { return (unsigned)((n + 255) / 256 < 65535 * 4 ? (n + 255) / 256 : 65535 * 4); }
+
+extern "C" int devqa_relu_bwd(const devqa_bf16* act_out, const devqa_bf16* grad_out, devqa_bf16* grad_in, int64_t n, void* stream) {
+    DEVQA_CHECK_ARG(act_out && grad_out && grad_in && n > 0, "relu_bwd: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(mo_grid(n)), dim3(256), 0, (hipStream_t)stream, act_out, grad_out, grad_in, n);
+    DEVQA_LAUNCH_CHECK("relu_bwd");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_relu_bwd_f32(const float* act_out, const float* grad_out, float* grad_in, int64_t n, void* stream) {
+    DEVQA_CHECK_ARG(act_out && grad_out && grad_in && n > 0, "relu_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(mo_grid(n)), dim3(256), 0, (hipStream_t)stream, act_out, grad_out, grad_in, n);
+    DEVQA_LAUNCH_CHECK("relu_bwd_f32");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_mend_normalize_concat(const float* u, const float* v, const int32_t* idx, const float* u_mean, const float* u_std,
+                                           const float* v_mean, const float* v_std, float eps, int n_rows, int du, int dv, float* out,
+                                           void* stream) {
+    DEVQA_CHECK_ARG(u && v && out && n_rows > 0 && du > 0 && dv > 0, "mend_normalize_concat: bad arguments");
+    DEVQA_CHECK_ARG((u_mean == nullptr) == (u_std == nullptr) && (v_mean == nullptr) == (v_std == nullptr),
+                    "mend_normalize_concat: mean and std must be given together");
+    hipLaunchKernelGGL(mend_normalize_concat_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, u, v, idx, u_mean, u_std, v_mean,
+                       v_std, eps, du, dv, out);
+    DEVQA_LAUNCH_CHECK("mend_normalize_concat");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_mend_lrlinear_epilogue(const float* pre, const float* bias, const float* scale, const float* shift, const float* x,
+                                            float* out, int n_rows, int D, void* stream) {
+    DEVQA_CHECK_ARG(pre && x && out && n_rows > 0 && D > 0, "mend_lrlinear_epilogue: bad arguments");
+    DEVQA_CHECK_ARG((scale == nullptr) == (shift == nullptr), "mend_lrlinear_epilogue: scale and shift must be given together");
+    const int64_t n = (int64_t)n_rows * D;
+    hipLaunchKernelGGL(mend_lrlinear_epilogue_kernel, dim3(mo_grid(n)), dim3(256), 0, (hipStream_t)stream, pre, bias, scale, shift, x, out,
+                       n, D);
+    DEVQA_LAUNCH_CHECK("mend_lrlinear_epilogue");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_logit_kl_rows(const float* logits1, int64_t ld1, const float* logits2, int64_t ld2, int R, int V, float* kl,
+                                   void* stream) {
+    DEVQA_CHECK_ARG(logits1 && logits2 && kl && R > 0 && V > 0, "logit_kl_rows: bad arguments");
+    hipLaunchKernelGGL(logit_kl_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits1, logits2, ld1, ld2, V, kl);
+    DEVQA_LAUNCH_CHECK("logit_kl_rows");
+    return DEVQA_OK;
+}

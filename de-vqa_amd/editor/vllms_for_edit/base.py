@@ -98,8 +98,16 @@ class BaseVLLMForEdit(ABC):
         loss = torch.where(msk != 0, nll * msk, torch.zeros_like(nll)).sum()
         return loss / msk.sum() if average else loss
 
-    def logit_KL_loss(self, logits1, logits2, label_masks, average=True):  # base.py:121-132 (MEND training only)
-        raise NotImplementedError("logit_KL_loss (MEND_VL training, K18) is not part of the FT_VL hot path yet")
+    def logit_KL_loss(self, logits1, logits2, label_masks, average=True):  # base.py:121-132 (K18, MEND_VL locality loss)
+        from ... import lib
+        L = label_masks.shape[1]
+        V = logits1.shape[-1]
+        a = logits1[:, -L:].to(torch.float32).reshape(-1, V).contiguous()
+        b = logits2[:, -L:].to(torch.float32).reshape(-1, V).contiguous()
+        kl = lib.logit_kl_rows(a, b).view(label_masks.shape)
+        msk = label_masks.to(kl.device, torch.float32)
+        loss = (kl * msk).sum()
+        return loss / msk.sum() if average else loss
 
     def set_device(self, device):  # base.py:134-136
         self.device = device

@@ -264,15 +264,22 @@ class Blip2Engine:
     # stop_before_fc2, the last processed layer stops at the fc2 input: returns (x_mid, a_bf16).
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def decoder_layers(self, ps: PackedSeqs, upto_layer=None, stop_before_fc2=False):
+    def decoder_layers(self, ps: PackedSeqs, upto_layer=None, stop_before_fc2=False, save=None):
+        """save: None, or {"layers": set of layer ids}; filled with save[i] = activations the backward of layer i needs
+        (decoder_backward).  Low-rank module deltas registered in self.module_deltas (MEND_VL's forward_edit_hook,
+        mend_vl.py:73-80) are applied to the fc1 / fc2 outputs."""
         t = self.t
         d, H = t["hidden_size"], t["num_attention_heads"]
         dh = d // H
         x = ps.x
         n_seq = ps.desc.shape[0]
         last = t["num_hidden_layers"] - 1 if upto_layer is None else upto_layer
+        deltas = getattr(self, "module_deltas", None) or {}
         for i in range(last + 1):
             p = "language_model.model.decoder.layers.%d." % i
+            rec = None
+            if save is not None and i in save["layers"]:
+                rec = save[i] = {"x_in": x.clone()}
             h = self._ln(x, p + "self_attn_layer_norm.weight", p + "self_attn_layer_norm.bias", LN_EPS_OPT)
             qkv = lib.gemm(h, self.m.fused_qkv_w[str(i)], self.m.fused_qkv_b[str(i)])
             att = lib.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], ps.desc, n_seq, ps.max_len, H, dh, dh ** -0.5,
@@ -280,11 +287,73 @@ class Blip2Engine:
             lib.gemm(att, self._w(p + "self_attn.out_proj.weight"), self._p(p + "self_attn.out_proj.bias"), residual=x,
                      out_f32=x)
             h = self._ln(x, p + "final_layer_norm.weight", p + "final_layer_norm.bias", LN_EPS_OPT)
-            a = lib.gemm(h, self._w(p + "fc1.weight"), self._p(p + "fc1.bias"), act=lib.ACT_RELU)
+            if rec is not None:
+                rec.update(qkv=qkv, att=att, x_mid=x.clone(), h2=h)
+            d1 = deltas.get(p + "fc1")
+            if d1 is None:
+                a = lib.gemm(h, self._w(p + "fc1.weight"), self._p(p + "fc1.bias"), act=lib.ACT_RELU)
+            else:   # relu(h W1^T + b + (h xt^T) dt): one GEMM over the concatenated K = [d | n_pad]
+                coef = lib.gemm(h, d1["xt"])
+                a = lib.gemm(torch.cat([h, coef], 1), d1["w_cat"], self._p(p + "fc1.bias"), act=lib.ACT_RELU)
+            if rec is not None:
+                rec["a"] = a
             if stop_before_fc2 and i == last:
                 return x, a
             lib.gemm(a, self._w(p + "fc2.weight"), self._p(p + "fc2.bias"), residual=x, out_f32=x)
+            d2 = deltas.get(p + "fc2")
+            if d2 is not None:
+                lib.gemm(lib.gemm(a, d2["xt"]), d2["dtT"], residual=x, out_f32=x)
         return x, None
+
+    def _wt(self, key, getter):
+        """Transposed GEMM operand W^T [in, out] (contiguous) of a frozen weight, cached: dX = dY . W runs on the TN
+        kernels as gemm(dY, W^T)."""
+        c = self.__dict__.setdefault("_wt_cache", {})
+        if key not in c:
+            c[key] = getter().t().contiguous()
+        return c[key]
+
+    @torch.no_grad()
+    def decoder_backward(self, ps: PackedSeqs, save, dx, capture):
+        """Backward through the saved decoder layers (highest first).  dx: fp32 [R, d] gradient w.r.t. the decoder
+        output (input of the final LayerNorm).  Returns {module name: (input rows, output-gradient rows)} for the
+        fc1 / fc2 modules named in `capture` -- what MEND_VL's forward/backward hooks record (mend_vl.py:62-71) --
+        and the gradient w.r.t. the input of the lowest saved layer."""
+        t = self.t
+        d, H = t["hidden_size"], t["num_attention_heads"]
+        dh = d // H
+        n_seq = ps.desc.shape[0]
+        deltas = getattr(self, "module_deltas", None) or {}
+        out = {}
+        for i in sorted(save["layers"], reverse=True):
+            p = "language_model.model.decoder.layers.%d." % i
+            rec = save[i]
+            # gradient activations are STORED in fp32 (they are small); only GEMM operands are rounded to the compute dtype
+            dz = self._act(dx)
+            if p + "fc2" in capture:
+                out[p + "fc2"] = (rec["a"], dx.clone())
+            da = lib.gemm(dz, self._wt(p + "fc2", lambda: self._w(p + "fc2.weight")), want="f32")
+            d2 = deltas.get(p + "fc2")
+            if d2 is not None:   # the delta branch a @ dW also carries gradient to a
+                lib.gemm(lib.gemm(dz, d2["dt"]), d2["xtT"], residual=da, out_f32=da)
+            dpre = lib.relu_bwd(rec["a"].to(torch.float32), da)
+            if p + "fc1" in capture:
+                out[p + "fc1"] = (rec["h2"], dpre)
+            dpre_op = self._act(dpre)
+            dh2 = lib.gemm(dpre_op, self._wt(p + "fc1", lambda: self._w(p + "fc1.weight")), want="f32")
+            d1 = deltas.get(p + "fc1")
+            if d1 is not None:
+                lib.gemm(lib.gemm(dpre_op, d1["dt"]), d1["xtT"], residual=dh2, out_f32=dh2)
+            dy = lib.layernorm_bwd_dx(rec["x_mid"], self._p(p + "final_layer_norm.weight"), dh2, LN_EPS_OPT)
+            lib.delta_op(1, dy, None, dx)      # dy += dx (residual branch)
+            datt = lib.gemm(self._act(dy), self._wt(p + "out_proj", lambda: self._w(p + "self_attn.out_proj.weight")))
+            qkv = rec["qkv"]
+            dq, dk, dv = lib.attention_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], rec["att"], datt, ps.desc, n_seq,
+                                           ps.max_len, H, dh, dh ** -0.5, 1)
+            dh1 = lib.gemm(torch.cat([dq, dk, dv], 1), self._wt(p + "qkv", lambda: self.m.fused_qkv_w[str(i)]), want="f32")
+            dx = lib.layernorm_bwd_dx(rec["x_in"], self._p(p + "self_attn_layer_norm.weight"), dh1, LN_EPS_OPT)
+            lib.delta_op(1, dx, None, dy)
+        return out, dx
 
     # K8: final LN + tied lm_head on the given rows -> fp32 logits
     @torch.no_grad()

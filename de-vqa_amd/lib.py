@@ -74,6 +74,13 @@ def load():
     _sig(L.devqa_ft_step_control, [P, P, I, I, I, I, F, P, P, P, P, P, P])
     _sig(L.devqa_cosine_topk_workspace, [I, I, I], c_int64)
     _sig(L.devqa_cosine_topk, [P, P, I, I, I, I, I, I, P, P, P, P])
+    for fn in (L.devqa_attention_bwd, L.devqa_attention_bwd_f32):
+        _sig(fn, [P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, P])
+    _sig(L.devqa_relu_bwd, [P, P, P, I64, P])
+    _sig(L.devqa_relu_bwd_f32, [P, P, P, I64, P])
+    _sig(L.devqa_mend_normalize_concat, [P, P, P, P, P, P, P, F, I, I, I, P, P])
+    _sig(L.devqa_mend_lrlinear_epilogue, [P, P, P, P, P, P, I, I, P])
+    _sig(L.devqa_logit_kl_rows, [P, I64, P, I64, I, I, P, P])
     _lib = L
     return L
 
@@ -84,7 +91,9 @@ EXPORTS = ["devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_ro
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
            "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
            "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
-           "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk"]
+           "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk", "devqa_attention_bwd",
+           "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_mend_normalize_concat",
+           "devqa_mend_lrlinear_epilogue", "devqa_logit_kl_rows"]
 
 
 def gemm_rows_longk(a, w):
@@ -423,3 +432,55 @@ def cosine_topk(corpus, queries, k, normalize_corpus=True, normalize_queries=Tru
     _chk(load().devqa_cosine_topk(_p(corpus), _p(queries), N, Q, D, int(k), int(normalize_corpus), int(normalize_queries),
                                   _p(idx), _p(sc), c_void_p(ws.data_ptr() + off), _stream()), "devqa_cosine_topk")
     return idx, sc
+
+
+def attention_bwd(q, k, v, o, d_out, seq_desc, n_seq, max_len, H, dh, scale, causal):
+    """Gradients (dq, dk, dv) of `attention` for descriptors without a visible prefix (kp_len == 0)."""
+    for t in (q, k, v, o, d_out):
+        assert t.dtype == q.dtype and t.is_cuda and t.dim() == 2 and t.stride(1) == 1
+    assert q.dtype in (torch.bfloat16, torch.float32)
+    R = q.shape[0]
+    dq, dk, dv = (torch.zeros((R, H * dh), dtype=q.dtype, device=q.device) for _ in range(3))
+    stats = torch.empty((R * H * 2,), dtype=torch.float32, device=q.device)
+    fn = load().devqa_attention_bwd if q.dtype == torch.bfloat16 else load().devqa_attention_bwd_f32
+    _chk(fn(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0), _p(d_out), d_out.stride(0),
+            _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(stats), _p(seq_desc), int(n_seq), int(max_len),
+            int(H), int(dh), float(scale), int(causal), _stream()), "devqa_attention_bwd")
+    return dq, dk, dv
+
+
+def relu_bwd(act_out, grad_out):
+    assert act_out.dtype == grad_out.dtype and act_out.shape == grad_out.shape and act_out.is_contiguous() and grad_out.is_contiguous()
+    out = torch.empty_like(grad_out)
+    fn = load().devqa_relu_bwd if act_out.dtype == torch.bfloat16 else load().devqa_relu_bwd_f32
+    _chk(fn(_p(act_out), _p(grad_out), _p(out), act_out.numel(), _stream()), "devqa_relu_bwd")
+    return out
+
+
+def mend_normalize_concat(u, v, idx=None, u_mean=None, u_std=None, v_mean=None, v_std=None, eps=1e-7):
+    _need(u, torch.float32, "mend_normalize_concat u")
+    _need(v, torch.float32, "mend_normalize_concat v")
+    n = u.shape[0] if idx is None else idx.numel()
+    out = torch.empty((n, u.shape[1] + v.shape[1]), dtype=torch.float32, device=u.device)
+    if n:
+        _chk(load().devqa_mend_normalize_concat(_p(u), _p(v), _p(idx), _p(u_mean), _p(u_std), _p(v_mean), _p(v_std), float(eps), n,
+                                                u.shape[1], v.shape[1], _p(out), _stream()), "devqa_mend_normalize_concat")
+    return out
+
+
+def mend_lrlinear_epilogue(pre, bias, scale, shift, x):
+    _need(pre, torch.float32, "mend_lrlinear_epilogue pre")
+    _need(x, torch.float32, "mend_lrlinear_epilogue x")
+    out = torch.empty_like(pre)
+    _chk(load().devqa_mend_lrlinear_epilogue(_p(pre), _p(bias), _p(scale), _p(shift), _p(x), _p(out), pre.shape[0], pre.shape[1],
+                                             _stream()), "devqa_mend_lrlinear_epilogue")
+    return out
+
+
+def logit_kl_rows(l1, l2):
+    """fp32 [R]: KL(softmax(l1[r]) || softmax(l2[r])) per row (2-D fp32 views, unit inner stride)."""
+    assert l1.dtype == l2.dtype == torch.float32 and l1.shape == l2.shape and l1.stride(1) == 1 and l2.stride(1) == 1
+    kl = torch.empty((l1.shape[0],), dtype=torch.float32, device=l1.device)
+    _chk(load().devqa_logit_kl_rows(_p(l1), l1.stride(0), _p(l2), l2.stride(0), l1.shape[0], l1.shape[1], _p(kl), _stream()),
+         "devqa_logit_kl_rows")
+    return kl

@@ -132,12 +132,12 @@ def mend_aux_init(name: str, shape, seed: int = 7) -> np.ndarray:
     z = rng.standard_normal(shape, dtype=np.float32) if len(shape) else np.float32(rng.standard_normal())
     leaf = name.split(".")[-1]
     if name.startswith("edit_lrs"):
-        return np.asarray(1e-2 * (1.0 + 0.1 * abs(float(z))), np.float32).reshape(shape)
+        return np.asarray(2e-2 * (1.0 + 0.1 * abs(float(z))), np.float32).reshape(shape)
     if leaf in ("u_std", "v_std"):
-        base = 0.5 if leaf == "u_std" else 2e-3
+        base = 0.8 if leaf == "u_std" else 0.3
         return (base * (1.0 + 0.2 * np.abs(z))).astype(np.float32)
     if leaf in ("u_mean", "v_mean"):
-        base = 0.05 if leaf == "u_mean" else 1e-4
+        base = 0.05 if leaf == "u_mean" else 1e-2
         return (base * z).astype(np.float32)
     if leaf in ("u_s", "v_s"):
         return np.abs(z).astype(np.float32)

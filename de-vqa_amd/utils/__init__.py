@@ -78,4 +78,7 @@ def load_vllm_editor(editor_name: str, edit_model_name: str, device, extra_devic
     if editor_name == "ike_vl":  # needs corpus={sentences, embeddings} and encode=callable (see ike_vl.py)
         from ..editor.vllm_editors.ike_vl.ike_vl import IKEvl, IKEvlConfig
         return IKEvl(vllm, IKEvlConfig.from_yaml(config_path), device, **editor_kwargs)
+    if editor_name == "mend_vl":  # editor_ckpt_path: a reference-format `Best` checkpoint of the trained hyper-network
+        from ..editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
+        return MENDvl(vllm, MENDvlConfig.from_yaml(config_path), device, ckpt_path=editor_ckpt_path, **editor_kwargs)
     raise RuntimeError("No such editor %s" % editor_name)

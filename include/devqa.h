@@ -128,6 +128,40 @@ int devqa_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk
                         int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale,
                         int causal, void* stream);
 
+/* ---- attention backward (MEND_VL edit path) ---------------------------------------------------
+ * Gradients of devqa_attention for descriptors WITHOUT a visible prefix (kp_len == 0; every sequence attends to its own
+ * rows, causal or full): given q,k,v, the forward output o and d_out = dL/do, writes dq, dk, dv (same dtype/layout as
+ * the inputs).  stats: fp32 workspace [rows * H * 2] (logsumexp and dO.O per (row, head)).  fp32 arithmetic.
+ * Replaces the autograd backward of OPTAttention that R/editor/vllm_editors/mend_vl/mend_vl.py:177-186
+ * (`torch.autograd.grad(edit_loss, self.autograd_params)`) runs through the edited layers.
+ */
+int devqa_attention_bwd(const devqa_bf16* q, int64_t ldq, const devqa_bf16* k, int64_t ldk, const devqa_bf16* v, int64_t ldv,
+                        const devqa_bf16* o, int64_t ldo, const devqa_bf16* d_out, int64_t lddo, devqa_bf16* dq, int64_t lddq,
+                        devqa_bf16* dk, int64_t lddk, devqa_bf16* dv, int64_t lddv, float* stats, const int32_t* seq_desc,
+                        int n_seq, int max_len, int H, int dh, float scale, int causal, void* stream);
+int devqa_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o,
+                            int64_t ldo, const float* d_out, int64_t lddo, float* dq, int64_t lddq, float* dk, int64_t lddk,
+                            float* dv, int64_t lddv, float* stats, const int32_t* seq_desc, int n_seq, int max_len, int H, int dh,
+                            float scale, int causal, void* stream);
+
+/* ---- MEND_VL row-wise pieces --------------------------------------------------------------------
+ * relu_bwd: grad_in = grad_out where act_out > 0 else 0 -- the hooked fc1 output gradient (mend_vl.py:68-71).
+ * mend_normalize_concat: out[r] = [(u[idx[r]] - u_mean)/(u_std + eps) | (v[idx[r]] - v_mean)/(v_std + eps)]  fp32
+ *   [n_rows, du+dv]; idx NULL = identity, mean/std NULL = no normalisation (auxiliary_networks.py:118-148; the caller
+ *   builds idx from the nz_mask rule of :118-120).
+ * mend_lrlinear_epilogue: out = max((pre + bias) * scale + shift, 0) + x  (auxiliary_networks.py:70-83, init 'id').
+ * logit_kl_rows: kl[r] = sum_v softmax(l1[r])_v (log_softmax(l1[r])_v - log_softmax(l2[r])_v)  (mend_vl.py:355-366, K18).
+ */
+int devqa_relu_bwd(const devqa_bf16* act_out, const devqa_bf16* grad_out, devqa_bf16* grad_in, int64_t n, void* stream);
+int devqa_relu_bwd_f32(const float* act_out, const float* grad_out, float* grad_in, int64_t n, void* stream);
+int devqa_mend_normalize_concat(const float* u, const float* v, const int32_t* idx, const float* u_mean, const float* u_std,
+                                const float* v_mean, const float* v_std, float eps, int n_rows, int du, int dv, float* out,
+                                void* stream);
+int devqa_mend_lrlinear_epilogue(const float* pre, const float* bias, const float* scale, const float* shift, const float* x,
+                                 float* out, int n_rows, int D, void* stream);
+int devqa_logit_kl_rows(const float* logits1, int64_t ld1, const float* logits2, int64_t ld2, int R, int V, float* kl,
+                        void* stream);
+
 /* ---- K2 patch-embed staging ---------------------------------------------------------------
  * im2col for Conv2d(3->D, k=P, s=P): pixels fp32 [B,3,S,S] -> bf16 [B*(S/P)^2, Kpad] with
  * column (c*P+py)*P+px, zero padded to Kpad (Kpad % 8 == 0).  HF Blip2VisionEmbeddings,

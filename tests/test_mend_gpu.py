@@ -1,0 +1,119 @@
+"""GPU: MEND_VL edit path on the HIP engine against goldens produced by the reference's own MENDvl
+(tools/make_goldens_mend.py): hooked x / delta, transformed factors, delta weights (single edit, sequential running
+mean, text batch), post-edit / restored logits, logit_KL rows, evaluator results."""
+import json
+import os
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = {"fp32": dict(x=1e-4, delta=1e-3, xt=1e-3, dt=1e-3, dw=1e-3, logits=1e-3),
+       "bf16": dict(x=5e-2, delta=1e-1, xt=6e-2, dt=1e-1, dw=1e-1, logits=1e-1)}
+
+
+@pytest.fixture(scope="module", params=["fp32", "bf16"])
+def mend(gold_dir, request):
+    import devqa_amd  # noqa: F401
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from devqa_amd.editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
+    vllm = BLIP2OPTForEdit(os.path.join(gold_dir, "tiny_blip2"), "cuda:0", dtype=request.param)
+    cfg = MENDvlConfig.from_yaml(os.path.join(gold_dir, "tiny_mend_cfg.yaml"))
+    ed = MENDvl(vllm, cfg, "cuda:0", ckpt_path=os.path.join(gold_dir, "tiny_mend_ckpt.pt"))
+    j = json.load(open(os.path.join(gold_dir, "tiny_mend_goldens.json")))
+    z = np.load(os.path.join(gold_dir, "tiny_mend_goldens.npz"))
+    return vllm, ed, j, z, TOL[request.param], request.param
+
+
+def _rel(a, g):
+    return float(np.abs(a - g).max() / max(np.abs(g).max(), 1e-30))
+
+
+def _check(ed, z, tag, tol):
+    worst = {}
+    for i, m in enumerate(ed.modules):
+        got = dict(ed.last[m["name"]])
+        got["dw"] = ed.delta_weight(m["name"])
+        for key in ("x", "delta", "xt", "dt", "dw"):
+            g = z["%s_%s_%d" % (tag, key, i)]
+            a = got[key].float().cpu().numpy()
+            assert a.shape == g.shape, (tag, key, i, a.shape, g.shape)
+            if key == "x":   # right-padded rows of a ragged batch hold don't-care values (zero gradient: dropped by the
+                keep = (z["%s_delta_%d" % (tag, i)] != 0).any(-1)   # nz rule, auxiliary_networks.py:118-120)
+                a, g = a[keep], g[keep]
+            worst[key] = max(worst.get(key, 0.0), _rel(a, g))
+    print(tag, {k: "%.2e" % v for k, v in worst.items()})
+    for key, v in worst.items():
+        assert v < tol[key], (tag, key, v)
+
+
+def test_mend_edits(mend, in_gold_dir):
+    vllm, ed, j, z, tol, mode = mend
+    pr = j["probe"]
+
+    def logits():
+        (x, vt), y, m = vllm.prompts_imgs_target_to_xym([pr["prompt"]], [pr["image"]], [pr["target"]])
+        return vllm.get_llm_outpt(x, vt).logits.float().cpu().numpy()
+    ed.restore_to_original_model()
+    assert _rel(logits(), z["pre_logits"]) < tol["logits"] * 0.2
+    a, b, c = j["cases"]
+    ed.edit_one_piece(deepcopy(a["requests"][0]))
+    _check(ed, z, "a", tol)
+    e = _rel(logits(), z["a_post_logits"])
+    print("a post logits", e)
+    assert e < tol["logits"]
+    ed.edit_one_piece(deepcopy(b["requests"][1]))
+    _check(ed, z, "b", tol)
+    e = _rel(logits(), z["b_post_logits"])
+    print("b post logits", e)
+    assert e < tol["logits"]
+    ed.restore_to_original_model()
+    ed.edit_batch(deepcopy(c["requests"]))
+    _check(ed, z, "c", tol)
+    assert _rel(logits(), z["c_post_logits"]) < tol["logits"]
+    ed.restore_to_original_model()
+    assert _rel(logits(), z["restored_logits"]) < tol["logits"] * 0.2
+
+
+def test_logit_kl_rows(mend):
+    from devqa_amd import lib
+    vllm, ed, j, z, tol, mode = mend
+    l1, l2, mk = torch.from_numpy(z["kl_l1"]).cuda(), torch.from_numpy(z["kl_l2"]).cuda(), torch.from_numpy(z["kl_mask"]).cuda()
+    L = mk.shape[1]
+    a = l1[:, -L:].reshape(-1, l1.shape[-1]).contiguous()
+    b = l2[:, -L:].reshape(-1, l2.shape[-1]).contiguous()
+    kl = lib.logit_kl_rows(a, b).view(mk.shape)
+    tot = float((kl * mk).sum())
+    assert abs(tot - j["kl_sum"]) < 1e-4 * abs(j["kl_sum"])
+    assert abs(tot / float(mk.sum()) - j["kl"]) < 1e-4 * abs(j["kl"])
+    assert abs(float(vllm.logit_KL_loss(l1, l2, mk)) - j["kl"]) < 1e-4 * abs(j["kl"])
+
+
+def test_mend_evaluator(mend, in_gold_dir, gold_dir, tmp_path):
+    from devqa_amd.dataset.vllm import BaseVLLMEditData
+    from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation
+    vllm, ed, j, z, tol, mode = mend
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))
+
+    class Data(BaseVLLMEditData):
+        def dataset_name(self):
+            return "EVQA"
+    ed.restore_to_original_model()
+    data = Data(deepcopy(rec["records"][:4]), deepcopy(rec["records"][:4]))
+    res = VLLMEditorEvaluation(ed, data, "EVQA", str(tmp_path)).evaluate_sequential_edit(1, False, None)
+    gold = j["results_sen1"]
+    n = same = 0
+    for rs, gs in zip(res, gold):
+        r, g = rs[0], gs[0]
+        pairs = [(r["reliability"][0], g["reliability"][0])]
+        for sec in ("generality", "locality"):
+            for sub in g[sec]:
+                pairs.append((r[sec][sub][0], g[sec][sub][0]))
+        for a, b in pairs:
+            n += 1
+            same += int(round(a["acc"], 4) == round(b["acc"], 4) and a["predict_after_edit"] == b["predict_after_edit"])
+    print(mode, "evaluator == golden %d/%d" % (same, n))
+    assert n == 48
+    assert same == 48 if mode == "fp32" else same >= 36
