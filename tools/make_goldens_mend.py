@@ -131,5 +131,74 @@ def main():
     print("mend goldens written:", len(npz), "arrays")
 
 
+def realdim():
+    """One MEND_VL edit at the true OPT-2.7B layer dims (2 layers; hyper-network 12800 -> rank 1920, the shipped config's
+    sizes).  Model and hyper-network state are regenerated from seeded recipes on both sides; only slices and checksums
+    of the reference's results are stored."""
+    import shutil
+    from copy import deepcopy
+    from editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from editor.vllm_editors.mend_vl import mend_vl as ref_mend
+    rd_dir = "/tmp/devqa_realdim_blip2_mend"
+    rec = json.load(open(os.path.join(GOLD, "realdim_records.json")))
+    tok = MG.build_tokenizer()
+    model = MG.build_model(MG.REALDIM, seed=rec["seed"], style=rec["style"])
+    MG.save_tiny(model, tok, rd_dir, 224)
+    del model
+    os.chdir(GOLD)
+    cfg_d = {
+        "edit_model_name": "blip2-opt-2.7b",
+        "edit_modules": ["language_model.model.decoder.layers.0.fc1", "language_model.model.decoder.layers.0.fc2",
+                         "language_model.model.decoder.layers.1.fc1", "language_model.model.decoder.layers.1.fc2"],
+        "init_edit_lr": 1.0e-4, "edit_lr_lr": 1.0e-4, "relia_lambda": 0.1, "gen_lambda": 0.1, "loc_lambda": 0.1,
+        "aux_model": {"n_hidden": 1, "hidden_dim": None, "init": "id", "norm": True, "act": "relu", "rank": 1920,
+                      "shared": True, "lr": 1.0e-6},
+    }
+    yaml.safe_dump(cfg_d, open(os.path.join(GOLD, "realdim_mend_cfg.yaml"), "w"))
+    cfg = ref_mend.MENDvlConfig.from_yaml(os.path.join(GOLD, "realdim_mend_cfg.yaml"))
+    vllm = BLIP2OPTForEdit(rd_dir, "cpu")
+    ed = ref_mend.MENDvl(vllm, cfg, "cpu")
+    keys = {}
+    for mname, mod in ed.get_modules_for_training().items():
+        sd = mod.state_dict()
+        keys[mname] = {k: list(v.shape) for k, v in sd.items()}
+        for k in sd:
+            sd[k] = torch.from_numpy(mend_aux_init("%s.%s" % (mname, k), tuple(sd[k].shape), 11))
+        mod.load_state_dict(sd)
+    for gt in ed.aux_models.values():
+        gt.norm_init = True
+    npz, js = {}, {"modules": cfg_d["edit_modules"], "aux_seed": 11, "state_shapes": keys}
+    req = deepcopy(rec["records"][0]["requests"][0])
+    probe = rec["records"][1]["generality"]["text_rephrase"][0]
+
+    def probe_logits():
+        with torch.no_grad():
+            (x, vt), y, m = vllm.prompts_imgs_target_to_xym([probe["prompt"]], [probe["image"]], [probe["target"]])
+            lg = t2n(vllm.get_llm_outpt(x, vt).logits).astype(np.float32)
+            return lg[:, -y.shape[1]:, :]
+    npz["pre_logits_lastL"] = probe_logits()
+    ed.edit_one_piece(deepcopy(req))
+    for i, em in enumerate(ed.edit_modules):
+        x, dl = t2n(em.__x__).astype(np.float32), t2n(em.__delta__).astype(np.float32)
+        xo, do = em.aux_model_weight(em.__x__, em.__delta__, em.idx)
+        dw = t2n(em.__delta_weight__).astype(np.float64)
+        npz["x_rowsum_%d" % i] = x.astype(np.float64).sum(-1)
+        npz["delta_rowsum_%d" % i] = dl.astype(np.float64).sum(-1)
+        npz["delta_absmax_%d" % i] = np.abs(dl).max(-1)
+        npz["xt_slice_%d" % i] = t2n(xo).astype(np.float32)[:, :64]
+        npz["dt_slice_%d" % i] = t2n(do).astype(np.float32)[:, :64]
+        npz["dw_slice_%d" % i] = dw[:64, :64].astype(np.float32)
+        npz["dw_stats_%d" % i] = np.array([np.sqrt((dw ** 2).sum()), dw.sum(), np.abs(dw).max()])
+    npz["post_logits_lastL"] = probe_logits()
+    js["request"], js["probe"] = req, probe
+    np.savez_compressed(os.path.join(GOLD, "realdim_mend_goldens.npz"), **npz)
+    json.dump(js, open(os.path.join(GOLD, "realdim_mend_goldens.json"), "w"), indent=1)
+    shutil.rmtree(rd_dir, ignore_errors=True)
+    print("realdim mend goldens written")
+
+
 if __name__ == "__main__":
-    main()
+    if "--realdim" in sys.argv:
+        realdim()
+    else:
+        main()
