@@ -22,6 +22,7 @@ class LlavaEngine:
         self.edit_layer = self.t["num_hidden_layers"] - 1
         self.adt = model.wdtype
         self.want = "bf16" if self.adt == torch.bfloat16 else "f32"
+        self.lm = "language_model."      # parameter-name prefix of the LLaMA decoder (MiniGPT-4: "llama_model.")
         self.eps = self.t["rms_norm_eps"]
         self.theta = float(self.t.get("rope_theta", 10000.0))
         self._desc_cache = {}
@@ -186,7 +187,7 @@ class LlavaEngine:
         n_seq = ps.desc.shape[0]
         last = t["num_hidden_layers"] - 1 if upto_layer is None else upto_layer
         for i in range(last + 1):
-            p = "language_model.model.layers.%d." % i
+            p = self.lm + "model.layers.%d." % i
             h = lib.rmsnorm(x, self._p(p + "input_layernorm.weight"), self.eps, want=self.want)
             qkv = lib.gemm(h, m.fused_w["llama_qkv.%d" % i])
             lib.rope_(qkv[:, :2 * d], ps.pos, 2 * H, dh, self.theta)          # q heads then k heads
@@ -203,8 +204,8 @@ class LlavaEngine:
 
     @torch.no_grad()
     def lm_head(self, x_rows, add=None):
-        h = lib.rmsnorm(x_rows, self._p("language_model.model.norm.weight"), self.eps, add=add, want=self.want)
-        return lib.gemm(h, self._w("language_model.lm_head.weight"), want="f32")
+        h = lib.rmsnorm(x_rows, self._p(self.lm + "model.norm.weight"), self.eps, add=add, want=self.want)
+        return lib.gemm(h, self._w(self.lm + "lm_head.weight"), want="f32")
 
     @torch.no_grad()
     def full_logits(self, ps):
@@ -213,13 +214,13 @@ class LlavaEngine:
 
     # ---- FT_VL interface ---------------------------------------------------------------------------------------------
     def edit_target(self):
-        return "language_model.model.layers.%d.mlp.down_proj.weight" % self.edit_layer
+        return self.lm + "model.layers.%d.mlp.down_proj.weight" % self.edit_layer
 
     def edit_bias(self):
         return None
 
     def final_norm_bwd(self, x_rows, dH, add=None):
-        return lib.rmsnorm_bwd_dx(x_rows, self._p("language_model.model.norm.weight"), dH, self.eps, add=add)
+        return lib.rmsnorm_bwd_dx(x_rows, self._p(self.lm + "model.norm.weight"), dH, self.eps, add=add)
 
     def embed_table(self):
-        return self._p("language_model.model.embed_tokens.weight")
+        return self._p(self.lm + "model.embed_tokens.weight")

@@ -64,6 +64,9 @@ def load_vllm_for_edit(model_name: str, device: str, dtype="bf16"):  # :111-124
     if "llava" in model_name:
         from ..editor.vllms_for_edit.llava.llava import LlavaForEdit
         return LlavaForEdit(model_path, device, True, dtype=dtype)
+    if "minigpt" in model_name:
+        from ..editor.vllms_for_edit.minigpt4.minigpt4 import MiniGPT4ForEdit
+        return MiniGPT4ForEdit(model_path, device, True, dtype=dtype)
     raise BaseException("Have not write `BaseVLLMForEdit` for `%s`." % model_name)
 
 

@@ -41,6 +41,9 @@ class OracleTokenizer:
     def encode(self, s):
         return self.tk.encode(s).ids
 
+    def encode_no_special(self, s):
+        return self.tk.encode(s, add_special_tokens=False).ids
+
     def decode(self, ids):
         return self.tk.decode([int(i) for i in ids], skip_special_tokens=False)
 

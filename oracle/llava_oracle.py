@@ -38,6 +38,8 @@ def _rope(q, k, pos, theta):
 
 
 class OracleLlava(OracleBlip2):
+    lm_prefix = "language_model."   # parameter-name prefix of the LLaMA decoder (MiniGPT-4 oracle: "llama_model.")
+
     def __init__(self, weights, cfg, tokenizer, copy=True):
         self.w = {k: (v.detach().to(torch.float32).clone() if copy else v) for k, v in weights.items()}
         self.cfg = cfg
@@ -134,7 +136,7 @@ class OracleLlava(OracleBlip2):
         bias = torch.zeros(B, 1, T, T).masked_fill(~allow, neg)
         x = inputs_embeds
         for i in range(self.t_layers):
-            p = "language_model.model.layers.%d." % i
+            p = self.lm_prefix + "model.layers.%d." % i
             h = _rms(x, w[p + "input_layernorm.weight"], self.t_eps)
             q = _lin(h, w[p + "self_attn.q_proj.weight"]).view(B, T, H, dh).transpose(1, 2)
             k = _lin(h, w[p + "self_attn.k_proj.weight"]).view(B, T, H, dh).transpose(1, 2)
@@ -150,5 +152,5 @@ class OracleLlava(OracleBlip2):
 
     def get_llm_outpt(self, llm_inpt, vt_range=None):
         x = self.llm_hidden(llm_inpt["inputs_embeds"], llm_inpt["attention_mask"])
-        x = _rms(x, self.w["language_model.model.norm.weight"], self.t_eps)
-        return _lin(x, self.w["language_model.lm_head.weight"])
+        x = _rms(x, self.w[self.lm_prefix + "model.norm.weight"], self.t_eps)
+        return _lin(x, self.w[self.lm_prefix + "lm_head.weight"])

@@ -1,0 +1,87 @@
+"""CPU oracle for the MiniGPT-4 path -- TEST INFRASTRUCTURE (only tests/, smoke() and bench.py's cpu_baseline may
+import it).
+
+Restates R/editor/vllms_for_edit/minigpt4/minigpt4.py:33-68 and modules/minigpt4.py:88-111,214-241 (`encode_img`,
+`get_context_emb`) in plain PyTorch fp32 on a flat {MiniGPT-4 state-dict name: tensor} dict.
+
+PARITY UNPINNED by the reference itself: MiniGPT4ForEdit cannot be imported here (needs omegaconf, peft and
+`LLAMA_INPUTS_DOCSTRING`, all absent), and the reference holds no fixture for it.  What pins this
+restatement instead: the EVA-ViT / Q-Former / projection arithmetic is the SAME code path as OracleBlip2's (pinned by
+HF-BLIP-2 goldens; tests/test_oracle_minigpt4.py feeds renamed tiny-BLIP-2 weights through this class and compares
+with those goldens), the LLaMA decoder is OracleLlava's (pinned by HF-LLaVA goldens); only the composition (segment
+tokenisation, [BOS] + 32 query rows + text, vt_range = [1, 33], right padding) is restated from the reference source.
+"""
+import torch
+
+from .devqa_oracle import OracleBlip2, OracleTokenizer
+from .llava_oracle import OracleLlava
+
+# HF BLIP-2 names (what OracleBlip2's vision / Q-Former code reads) -> MiniGPT-4 names
+from devqa_amd.minigpt4_spec import blip2_alias, param_shapes  # noqa: E402  (pure-python name table, no compute)
+
+
+class OracleMiniGPT4(OracleLlava):
+    lm_prefix = "llama_model."
+
+    def __init__(self, weights, cfg, tokenizer, copy=True):
+        self.w = {k: (v.detach().to(torch.float32).clone() if copy else v) for k, v in weights.items()}
+        self.cfg = cfg
+        self.tok = tokenizer
+        v, q, t = cfg["vision_config"], cfg["qformer_config"], cfg["text_config"]
+        self.t_layers, self.t_heads = t["num_hidden_layers"], t["num_attention_heads"]
+        self.t_eps, self.theta = t["rms_norm_eps"], t["rope_theta"]
+        self.n_img = cfg["num_query_tokens"]
+        self.num_query_tokens = self.n_img
+        # a BLIP-2 oracle over an aliased view of the same tensors: vision -> ln_vision -> Q-Former -> llama_proj
+        names = {}
+        for n in param_shapes(cfg):
+            names[n] = n
+        b2 = {}
+        from devqa_amd import blip2_spec
+        b2cfg = {"vision_config": dict(v), "qformer_config": dict(q), "num_query_tokens": cfg["num_query_tokens"],
+                 "text_config": dict(hidden_size=t["hidden_size"], ffn_dim=8, num_hidden_layers=0, num_attention_heads=1,
+                                     vocab_size=8, max_position_embeddings=8, word_embed_proj_dim=t["hidden_size"])}
+        D = v["hidden_size"]
+        for hf in blip2_spec.param_shapes(b2cfg):
+            if hf.startswith("language_model."):
+                continue
+            a = blip2_alias(hf)
+            if a.startswith("derived:vit_qkv_bias."):
+                i = int(a.rsplit(".", 1)[1])
+                qb, vb = self.w["visual_encoder.blocks.%d.attn.q_bias" % i], self.w["visual_encoder.blocks.%d.attn.v_bias" % i]
+                b2[hf] = torch.cat([qb, torch.zeros(D), vb])           # eva_vit.py:193-197
+            else:
+                b2[hf] = self.w[a]
+        self.b2 = OracleBlip2(b2, b2cfg, None, copy=False)
+
+    def preprocess_image(self, img):
+        return self.b2.preprocess_image(img)
+
+    def encode_img(self, pixel_values):
+        return self.b2.image_tokens(pixel_values)
+
+    def _ids(self, s, special):
+        ids = self.tok.encode(s) if special else self.tok.encode_no_special(s)
+        return torch.tensor(ids, dtype=torch.long)
+
+    def get_llm_input_embeds(self, texts, imgs=None):
+        if isinstance(imgs, list) and all(i is None for i in imgs):
+            imgs = None
+        E = self.w["llama_model.model.embed_tokens.weight"]
+        if imgs is None:
+            ids, msk = self._tok_batch(texts)
+            return {"attention_mask": msk, "inputs_embeds": E[ids], "position_ids": None}, None
+        texts = ["<ImageHere>\n" + t if t.find("<ImageHere>") == -1 else t for t in texts]     # base.py:50-51
+        feats = self.encode_img(torch.cat([self.preprocess_image(i) for i in imgs]))
+        rows = []
+        for b, text in enumerate(texts):
+            segs = text.split("<ImageHere>")
+            assert len(segs) == 2
+            rows.append(torch.cat([E[self._ids(segs[0], True)], feats[b], E[self._ids(segs[1], False)]], 0))
+        T = max(r.shape[0] for r in rows)
+        emb = torch.zeros(len(rows), T, rows[0].shape[1])
+        msk = torch.zeros(len(rows), T, dtype=torch.long)
+        for b, r in enumerate(rows):
+            emb[b, :r.shape[0]] = r
+            msk[b, :r.shape[0]] = 1
+        return {"attention_mask": msk, "inputs_embeds": emb, "position_ids": None}, [1, self.n_img + 1]
