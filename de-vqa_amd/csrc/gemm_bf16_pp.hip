@@ -137,38 +137,47 @@ __device__ __forceinline__ uint32_t pp_pack2(float a, float b) {   // v_cvt_pk_b
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, pp_bf16x2_t));
 }
 
-template <int ACT>
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
-                                                           int64_t ldw, const float* __restrict__ bias, int M, int N, int K, float alpha,
-                                                           const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc,
-                                                           int tiles_m, int tiles_n, int group_m) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {   // workgroups that share an XCD (blockIdx % 8) get a contiguous range of tile ids (bijective for any nwg)
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    int tile_m, tile_n;
-    {   // grouped order: consecutive ids walk group_m row-tiles of one column-tile, then the next column-tile, so the
-        // ~32 workgroups an XCD runs together share A row panels and W column panels in its L2
-        const int per_group = group_m * tiles_n;
-        const int g = bid / per_group, in_g = bid - g * per_group;
-        const int gm = min(group_m, tiles_m - g * group_m);
-        tile_m = g * group_m + in_g % gm;
-        tile_n = in_g / gm;
-    }
-    const int m0 = tile_m * PP_BM, n0 = tile_n * PP_BN;
+struct PPArgs {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* W; int64_t ldw;
+    const float* bias;
+    int M, N, K;
+    float alpha;
+    const float* residual;
+    bf16_t* out_bf16;
+    float* out_f32;
+    int64_t ldc;
+    int tiles_m, tiles_n, group_m;
+    // stream-K tail: tiles [dp_tiles, tiles_m*tiles_n) are cut into sk_wgs contiguous ranges of `sk_per` K-tile
+    // iterations; partial accumulators go through `ws` ([sk tile][max_seg][256x256] fp32), `counters[sk tile]` elects
+    // the workgroup that finishes a tile
+    int dp_tiles, sk_wgs, sk_per, sk_max_seg;
+    float* ws;
+    int* counters;
+};
+
+// tile id -> (tile_m, tile_n): grouped order (group_m row-tiles of one column-tile, then the next column-tile), so the
+// ~32 workgroups an XCD runs together share A row panels and W column panels in its L2
+__device__ __forceinline__ void pp_tile_coords(const PPArgs& g, int id, int& tile_m, int& tile_n) {
+    const int per_group = g.group_m * g.tiles_n;
+    const int grp = id / per_group, in_g = id - grp * per_group;
+    const int gm = min(g.group_m, g.tiles_m - grp * g.group_m);
+    tile_m = grp * g.group_m + in_g % gm;
+    tile_n = in_g / gm;
+}
+
+// K-tiles [k0, k0 + nk) of tile (tile_m, tile_n) -> acc.  Every wave executes the same number of barriers.
+__device__ __forceinline__ void pp_mainloop(const PPArgs& g, unsigned char* smem, int m0, int n0, int k0, int nk,
+                                            float4_t (&acc)[8][4]) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
-
     PPState s;
     s.smem = smem;
-    s.gA = reinterpret_cast<const char*>(A);
-    s.gW = reinterpret_cast<const char*>(W);
+    s.gA = reinterpret_cast<const char*>(g.A) + (int64_t)k0 * (PP_BK * 2);
+    s.gW = reinterpret_cast<const char*>(g.W) + (int64_t)k0 * (PP_BK * 2);
     s.dst = wave * 2048;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -176,10 +185,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
         const int sc = (lane & 7) ^ ((r >> 1) & 7);              // source chunk for LDS chunk (lane & 7)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int grow = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), M - 1);
-            const int gcol = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), N - 1);
-            s.off[h][i] = (unsigned)(((int64_t)grow * lda + sc * 8) * 2);          // R_A0 + h
-            s.off[2 + h][i] = (unsigned)(((int64_t)gcol * ldw + sc * 8) * 2);      // R_B0 + h
+            const int grow = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), g.M - 1);
+            const int gcol = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), g.N - 1);
+            s.off[h][i] = (unsigned)(((int64_t)grow * g.lda + sc * 8) * 2);          // R_A0 + h
+            s.off[2 + h][i] = (unsigned)(((int64_t)gcol * g.ldw + sc * 8) * 2);      // R_B0 + h
         }
     }
     {
@@ -189,15 +198,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
         s.lb0 = wc * 4096 + fr * 128 + c0;
         s.lb1 = wc * 4096 + fr * 128 + (c0 ^ 64);
     }
-
-    float4_t acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
     short8_t a[4][2], b0[2][2], b1[2][2];
-
-    const int nk = K / PP_BK;
     // prologue: slots -6..-1 = A0,B0,B1,A1 of tile 0 and A0,B0 of tile 1; A0(0), B0(0) must have landed
     pp_stage<R_A0>(s, 0);
     pp_stage<R_B0>(s, 0);
@@ -212,7 +217,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier interval behind waves 0-3
-
     int t = 0;
     for (; t + 2 < nk; ++t) pp_tile<0>(s, t, acc, a, b0, b1);
     if (t + 1 < nk) {
@@ -221,18 +225,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     }
     pp_tile<2>(s, t, acc, a, b0, b1);
     if (wr == 0) __builtin_amdgcn_s_barrier();   // match the extra barrier of waves 4-7
+}
 
-    // ---- epilogue.  All LDS traffic of the K loop is over (last ds_read in phase 2 of the last tile, all LDS-DMA
-    // retired by the vmcnt(0) of its phases 1-3, and every wave is past two more barriers).  Each wave transposes its
-    // 128x64 accumulator tile through a PRIVATE 16-KiB LDS region, 64 rows at a time, so that global accesses are
-    // row-contiguous: a lane owns 4 consecutive columns of one row, 16 lanes cover 256 B (fp32) / 128 B (bf16) of it.
-    // MFMA operands were fed swapped: acc[i][j][e] = C[i*16 + fr][j*16 + fq*4 + e].
+// Epilogue.  All LDS traffic of the K loop is over (last ds_read in phase 2 of the last tile, all LDS-DMA retired by the
+// vmcnt(0) of its phases 1-3, and every wave is past two more barriers).  Each wave transposes its 128x64 accumulator
+// tile through a PRIVATE 16-KiB LDS region, 64 rows at a time, so that global accesses are row-contiguous: a lane owns
+// 4 consecutive columns of one row, 16 lanes cover 256 B (fp32) / 128 B (bf16) of it.
+// MFMA operands were fed swapped: acc[i][j][e] = C[i*16 + fr][j*16 + fq*4 + e].
+template <int ACT>
+__device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem, int m0, int n0, const float4_t (&acc)[8][4]) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
     unsigned char* stg = smem + wave * 16384;
     const int q = lane & 15;
     const int gn = n0 + wc * 64 + q * 4;
-    const bool col_ok = gn < N;
+    const bool col_ok = gn < g.N;
+    const int M = g.M;
+    const int64_t ldc = g.ldc;
+    const float alpha = g.alpha;
+    const float* residual = g.residual;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias != nullptr && col_ok) bv = *reinterpret_cast<const float4*>(bias + gn);
+    if (g.bias != nullptr && col_ok) bv = *reinterpret_cast<const float4*>(g.bias + gn);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int gm0 = m0 + wr * 128 + half * 64 + (lane >> 4);   // + it * 4
@@ -262,12 +278,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
             if (residual != nullptr) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
             if (col_ok && gm < M) {
                 const int64_t o = (int64_t)gm * ldc + gn;
-                if (out_f32) *reinterpret_cast<float4*>(out_f32 + o) = v;
-                if (out_bf16) {
+                if (g.out_f32) *reinterpret_cast<float4*>(g.out_f32 + o) = v;
+                if (g.out_bf16) {
                     uint2 p;
                     p.x = pp_pack2(v.x, v.y);
                     p.y = pp_pack2(v.z, v.w);
-                    *reinterpret_cast<uint2*>(out_bf16 + o) = p;
+                    *reinterpret_cast<uint2*>(g.out_bf16 + o) = p;
                 }
             }
         }
@@ -275,9 +291,92 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 }
 
 template <int ACT>
-static int launch_pp(int group_m, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K,
-                     float alpha, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc, hipStream_t st) {
-    const int tiles_m = (M + PP_BM - 1) / PP_BM, tiles_n = (N + PP_BN - 1) / PP_BN;
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4_t acc[8][4];
+    const int nk = g.K / PP_BK;
+    const int tid = threadIdx.x;
+    // Every workgroup walks a range [it, it1) of the (tile, K-tile) iteration space.  A data-parallel workgroup owns
+    // exactly one whole tile; a stream-K workgroup owns `sk_per` consecutive iterations of the tail tiles.
+    int it, it1;
+    const int w = (int)blockIdx.x - g.dp_tiles;
+    if (w < 0) {
+        // workgroups that share an XCD (blockIdx % 8) get a contiguous range of tile ids (bijective for any count)
+        const int bid = blockIdx.x, nwg = g.dp_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        it = ((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx) * nk;
+        it1 = it + nk;
+    } else {
+        it = g.dp_tiles * nk + w * g.sk_per;
+        it1 = min(g.tiles_m * g.tiles_n * nk, it + g.sk_per);
+    }
+    while (it < it1) {
+        const int tile = it / nk;
+        const int k0 = it - tile * nk;
+        const int kn = min(nk - k0, it1 - it);
+        int tile_m, tile_n;
+        pp_tile_coords(g, tile, tile_m, tile_n);
+        const int m0 = tile_m * PP_BM, n0 = tile_n * PP_BN;
+        pp_mainloop(g, smem, m0, n0, k0, kn, acc);
+        bool whole = true;
+        if (w >= 0) {
+            const int ts = tile - g.dp_tiles;             // tail-tile index
+            const int first_wg = (ts * nk) / g.sk_per, last_wg = ((ts + 1) * nk - 1) / g.sk_per;
+            const int nseg = last_wg - first_wg + 1;
+            if (nseg > 1) {
+                // partial tile: accumulators -> workspace in fragment order (lane-contiguous 16-B pieces: fully coalesced)
+                float4_t* base = reinterpret_cast<float4_t*>(g.ws) + (int64_t)ts * g.sk_max_seg * (32 * 512);
+                float4_t* slot = base + (int64_t)(w - first_wg) * (32 * 512);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) slot[(i * 4 + j) * 512 + tid] = acc[i][j];
+                // every wave's stores drained, workgroup barrier, then ONE agent-scope acq_rel RMW on the tile's counter
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                int* flag = reinterpret_cast<int*>(smem);
+                if (tid == 0) {
+                    const int old = __hip_atomic_fetch_add(g.counters + ts, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = old == nseg - 1;
+                    if (last) __hip_atomic_store(g.counters + ts, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+                    *flag = last;
+                }
+                __syncthreads();
+                whole = *flag != 0;
+                __syncthreads();      // the flag word is LDS the epilogue / the next prologue overwrites
+                if (whole) {          // this workgroup finished the tile: sum the partials in K order (deterministic)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                    for (int sg = 0; sg < nseg; ++sg) {
+                        const float4_t* p = base + (int64_t)sg * (32 * 512);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[i][j] += p[(i * 4 + j) * 512 + tid];
+                    }
+                }
+            }
+        }
+        if (whole) pp_epilogue<ACT>(g, smem, m0, n0, acc);
+        it += kn;
+        if (it < it1) __syncthreads();   // LDS is restaged by the next segment's prologue
+    }
+}
+
+namespace {
+struct PPWorkspace {
+    float* ws = nullptr;
+    size_t ws_bytes = 0;
+    int* counters = nullptr;
+    int n_counters = 0;
+    int n_cu = 0;
+};
+PPWorkspace g_ppws[16];
+}  // namespace
+
+template <int ACT>
+static int launch_pp(const PPArgs& g, hipStream_t st) {
     const size_t smem = 2 * PP_BUF;
     auto kern = gemm_bf16_pp_kernel<ACT>;
     static bool attr_done = false;
@@ -285,27 +384,81 @@ static int launch_pp(int group_m, const bf16_t* A, int64_t lda, const bf16_t* W,
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, A, lda, W, ldw, bias, M, N, K, alpha, residual, out_bf16,
-                       out_f32, ldc, tiles_m, tiles_n, group_m);
+    hipLaunchKernelGGL(kern, dim3(g.dp_tiles + g.sk_wgs), dim3(512), smem, st, g);
     DEVQA_LAUNCH_CHECK("gemm_bf16_pp");
     return DEVQA_OK;
 }
 
-// id: 0 group_m 8, 1 group_m 1 (plain column-major tile order), 2 group_m 4 (default), 3 group_m 16
+// id: 0 group_m 8, 1 group_m 1 (plain column-major tile order), 2 group_m 4 (default), 3 group_m 16,
+//     4 group_m 4 + stream-K tail (experimental: the partial-tile hand-off -- 256 KiB per segment through HBM/L2 plus an
+//       agent-scope acq_rel RMW whose release/acquire writes back / invalidates the XCD's L2 -- costs more than the
+//       partial round it removes on every shape of this path: measured 0.50-0.93x, profiles/r01_summary.md)
 int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K, float alpha,
                    int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc, hipStream_t st) {
-    static const int gms[4] = {8, 1, 4, 16};
-    if (id < 0 || id > 3) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
+    static const int gms[5] = {8, 1, 4, 16, 4};
+    if (id < 0 || id > 4) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
     if (K % PP_BK != 0 || K < PP_BK) return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: K=%d must be a positive multiple of 64", K);
     if ((int64_t)M * lda * 2 >= (1ll << 32) || (int64_t)N * ldw * 2 >= (1ll << 32))
         return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: operands must span < 4 GiB (32-bit lane offsets)");
-#define ARGS gms[id], A, lda, W, ldw, bias, M, N, K, alpha, residual, out_bf16, out_f32, ldc, st
-    switch (act) {
-        case DEVQA_ACT_NONE: return launch_pp<DEVQA_ACT_NONE>(ARGS);
-        case DEVQA_ACT_RELU: return launch_pp<DEVQA_ACT_RELU>(ARGS);
-        case DEVQA_ACT_GELU: return launch_pp<DEVQA_ACT_GELU>(ARGS);
-        case DEVQA_ACT_QUICK_GELU: return launch_pp<DEVQA_ACT_QUICK_GELU>(ARGS);
+    PPArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.residual = residual;
+    g.out_bf16 = out_bf16; g.out_f32 = out_f32; g.ldc = ldc;
+    g.tiles_m = (M + PP_BM - 1) / PP_BM;
+    g.tiles_n = (N + PP_BN - 1) / PP_BN;
+    g.group_m = gms[id];
+    const int T = g.tiles_m * g.tiles_n, nk = K / PP_BK;
+    g.dp_tiles = T; g.sk_wgs = 0; g.sk_per = 1; g.sk_max_seg = 1; g.ws = nullptr; g.counters = nullptr;
+    if (id == 4) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        PPWorkspace& wsp = g_ppws[dev & 15];
+        if (wsp.n_cu == 0) {
+            int n = 0;
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            wsp.n_cu = n > 0 ? n : 256;
+        }
+        const int P = wsp.n_cu;
+        const int R = T % P;                      // tiles of the last, partial round
+        // worth it when the partial round is neither nearly full nor nearly empty of work to spread
+        if (R > 0 && R * 8 <= P * 7) {
+            const long I = (long)R * nk;
+            int G = (int)(I / 8 < P ? I / 8 : P);  // >= 8 K-tiles per workgroup
+            if (G >= 2 && G > R) {
+                const int per = (int)((I + G - 1) / G);
+                G = (int)((I + per - 1) / per);
+                const int max_seg = (nk + per - 1) / per + 1;
+                const size_t need = (size_t)R * max_seg * 65536 * sizeof(float);
+                bool ok = true;
+                if (need > wsp.ws_bytes) {
+                    (void)hipStreamSynchronize(st);
+                    if (wsp.ws) (void)hipFree(wsp.ws);
+                    wsp.ws = nullptr;
+                    wsp.ws_bytes = 0;
+                    const size_t want = need + (need >> 2);
+                    if (hipMalloc(reinterpret_cast<void**>(&wsp.ws), want) == hipSuccess) wsp.ws_bytes = want; else ok = false;
+                }
+                if (ok && R > wsp.n_counters) {
+                    (void)hipStreamSynchronize(st);
+                    if (wsp.counters) (void)hipFree(wsp.counters);
+                    wsp.counters = nullptr;
+                    wsp.n_counters = 0;
+                    const int nc = R > 1024 ? R : 1024;
+                    if (hipMalloc(reinterpret_cast<void**>(&wsp.counters), nc * sizeof(int)) == hipSuccess &&
+                        hipMemset(wsp.counters, 0, nc * sizeof(int)) == hipSuccess) wsp.n_counters = nc; else ok = false;
+                }
+                if (ok) {
+                    g.dp_tiles = T - R; g.sk_wgs = G; g.sk_per = per; g.sk_max_seg = max_seg; g.ws = wsp.ws; g.counters = wsp.counters;
+                } else {
+                    (void)hipGetLastError();     // out of memory for the workspace: plain data-parallel launch
+                }
+            }
+        }
     }
-#undef ARGS
+    switch (act) {
+        case DEVQA_ACT_NONE: return launch_pp<DEVQA_ACT_NONE>(g, st);
+        case DEVQA_ACT_RELU: return launch_pp<DEVQA_ACT_RELU>(g, st);
+        case DEVQA_ACT_GELU: return launch_pp<DEVQA_ACT_GELU>(g, st);
+        case DEVQA_ACT_QUICK_GELU: return launch_pp<DEVQA_ACT_QUICK_GELU>(g, st);
+    }
     return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown activation %d", act);
 }
