@@ -290,12 +290,20 @@ __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem
     }
 }
 
-template <int ACT>
+template <int ACT, bool SK>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4_t acc[8][4];
     const int nk = g.K / PP_BK;
     const int tid = threadIdx.x;
+    if constexpr (!SK) {   // one whole tile per workgroup: the default
+        const int bid = blockIdx.x, nwg = g.dp_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        int tile_m, tile_n;
+        pp_tile_coords(g, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx, tile_m, tile_n);
+        pp_mainloop(g, smem, tile_m * PP_BM, tile_n * PP_BN, 0, nk, acc);
+        pp_epilogue<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
+        return;
+    }
     // Every workgroup walks a range [it, it1) of the (tile, K-tile) iteration space.  A data-parallel workgroup owns
     // exactly one whole tile; a stream-K workgroup owns `sk_per` consecutive iterations of the tail tiles.
     int it, it1;
@@ -375,10 +383,10 @@ struct PPWorkspace {
 PPWorkspace g_ppws[16];
 }  // namespace
 
-template <int ACT>
-static int launch_pp(const PPArgs& g, hipStream_t st) {
+template <int ACT, bool SK>
+static int launch_pp_k(const PPArgs& g, hipStream_t st) {
     const size_t smem = 2 * PP_BUF;
-    auto kern = gemm_bf16_pp_kernel<ACT>;
+    auto kern = gemm_bf16_pp_kernel<ACT, SK>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -387,6 +395,11 @@ static int launch_pp(const PPArgs& g, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(g.dp_tiles + g.sk_wgs), dim3(512), smem, st, g);
     DEVQA_LAUNCH_CHECK("gemm_bf16_pp");
     return DEVQA_OK;
+}
+
+template <int ACT>
+static int launch_pp(const PPArgs& g, hipStream_t st) {
+    return g.sk_wgs > 0 ? launch_pp_k<ACT, true>(g, st) : launch_pp_k<ACT, false>(g, st);
 }
 
 // id: 0 group_m 8, 1 group_m 1 (plain column-major tile order), 2 group_m 4 (default), 3 group_m 16,
