@@ -20,11 +20,18 @@
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((address_space(3))) short4_t* lds_s4_ptr;
 
+typedef __bf16 am_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float am_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t am_pack2(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE)
+    am_f32x2_t f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, am_bf16x2_t));
+}
+
 #define AM_KC 64  // keys per chunk
 #define AM_QT 64  // queries per workgroup
 
 template <int DHP>
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                              const bf16_t* __restrict__ k, int64_t ldk,
                                                              const bf16_t* __restrict__ v, int64_t ldv,
                                                              bf16_t* __restrict__ out, int64_t ldo,
@@ -71,23 +78,37 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __res
 #pragma unroll
     for (int i = 0; i < DT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;  // statistics of query fr (replicated over the 4 lane groups)
+    const float sc2 = scale * 1.44269504088896340736f;
 
     constexpr int CH = DHP / 8;  // 16-byte chunks per row
     constexpr int LD = AM_KC * CH / 256;  // 16-byte pieces of K (and of V) per thread and chunk
     static_assert(AM_KC * CH % 256 == 0, "chunk must split evenly over the workgroup");
     uint4 kreg[LD], vreg[LD];
+    // loop-invariant part of this thread's LD staging pieces: LDS offset, channel base pointers, row inside the chunk
+    int st_off[LD], st_row[LD];
+    const bf16_t* kcol[LD];
+    const bf16_t* vcol[LD];
+    bool st_ch[LD];
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+        const int i = tid + j * 256;
+        const int r = i / CH, cv = i - r * CH;
+        st_row[j] = r;
+        st_off[j] = r * STRIDE + cv * 16;
+        st_ch[j] = cv * 8 < dh;
+        kcol[j] = k + h * dh + cv * 8;
+        vcol[j] = v + h * dh + cv * 8;
+    }
     auto fetch = [&](int c0) {   // chunk c0 -> registers (zero beyond n_keys / dh)
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
-            const int i = tid + j * 256;
-            const int r = i / CH, cv = i % CH;
-            const int kidx = c0 + r;
+            const int kidx = c0 + st_row[j];
             kreg[j] = make_uint4(0, 0, 0, 0);
             vreg[j] = kreg[j];
-            if (kidx < n_keys && cv * 8 < dh) {
+            if (kidx < n_keys && st_ch[j]) {
                 const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);
-                kreg[j] = *reinterpret_cast<const uint4*>(k + grow * ldk + h * dh + cv * 8);
-                vreg[j] = *reinterpret_cast<const uint4*>(v + grow * ldv + h * dh + cv * 8);
+                kreg[j] = *reinterpret_cast<const uint4*>(kcol[j] + grow * ldk);
+                vreg[j] = *reinterpret_cast<const uint4*>(vcol[j] + grow * ldv);
             }
         }
     };
@@ -97,10 +118,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __res
         __syncthreads();  // previous chunk fully consumed
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
-            const int i = tid + j * 256;
-            const int r = i / CH, cv = i % CH;
-            *reinterpret_cast<uint4*>(Ks + r * STRIDE + cv * 16) = kreg[j];
-            *reinterpret_cast<uint4*>(Vs + r * STRIDE + cv * 16) = vreg[j];
+            *reinterpret_cast<uint4*>(Ks + st_off[j]) = kreg[j];
+            *reinterpret_cast<uint4*>(Vs + st_off[j]) = vreg[j];
         }
         __syncthreads();
         if (c0 + AM_KC < n_keys) fetch(c0 + AM_KC);  // next chunk's loads fly under this chunk's MFMAs
@@ -119,30 +138,37 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __res
                 st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[t], 0, 0, 0);
             }
         }
-        // ---- mask, scale, online softmax for query fr ----
-        float mloc = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kidx = c0 + 16 * t + 4 * fq + r;
-                bool ok = kidx < n_keys;
-                if (causal && kidx >= kp_len) ok = ok && (kidx - kp_len) <= qrow + causal_off;
-                const float sv = ok ? st[t][r] * scale : -INFINITY;
-                st[t][r] = sv;
-                mloc = fmaxf(mloc, sv);
-            }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        float alpha = 1.f, lloc = 0.f;
-        if (m_new != -INFINITY) {
-            alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+        // ---- mask, online softmax for query fr.  Scores stay unscaled: with c = scale * log2(e) > 0,
+        // softmax(scale * s) = exp2(c * s - c * max s); masking is needed only in chunks that hold a key past the end
+        // or a causally hidden key (uniform per workgroup) ----
+        const bool need_mask = (c0 + AM_KC > n_keys) || (causal && c0 + AM_KC > kp_len);
+        if (need_mask) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = (st[t][r] == -INFINITY) ? 0.f : __expf(st[t][r] - m_new);
+                    const int kidx = c0 + 16 * t + 4 * fq + r;
+                    bool ok = kidx < n_keys;
+                    if (causal && kidx >= kp_len) ok = ok && (kidx - kp_len) <= qrow + causal_off;
+                    st[t][r] = ok ? st[t][r] : -INFINITY;
+                }
+        }
+        float mloc = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
+                           fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
+        mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(st[2][0], st[2][1]), fmaxf(st[2][2], st[2][3])),
+                                 fmaxf(fmaxf(st[3][0], st[3][1]), fmaxf(st[3][2], st[3][3]))));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);          // running max of the UNSCALED scores
+        float alpha = 1.f, lloc = 0.f;
+        if (m_new != -INFINITY) {
+            const float mc = m_new * sc2;
+            alpha = __builtin_amdgcn_exp2f(m_run * sc2 - mc);   // m_run = -inf -> 0
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], sc2, -mc));   // masked (-inf) -> 0
                     st[t][r] = p;
                     lloc += p;
                 }
@@ -159,10 +185,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __res
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             uint4 u;
-            u.x = pack_bf16x2(st[2 * s2][0], st[2 * s2][1]);
-            u.y = pack_bf16x2(st[2 * s2][2], st[2 * s2][3]);
-            u.z = pack_bf16x2(st[2 * s2 + 1][0], st[2 * s2 + 1][1]);
-            u.w = pack_bf16x2(st[2 * s2 + 1][2], st[2 * s2 + 1][3]);
+            u.x = am_pack2(st[2 * s2][0], st[2 * s2][1]);
+            u.y = am_pack2(st[2 * s2][2], st[2 * s2][3]);
+            u.z = am_pack2(st[2 * s2 + 1][0], st[2 * s2 + 1][1]);
+            u.w = am_pack2(st[2 * s2 + 1][2], st[2 * s2 + 1][3]);
             pf[s2] = *reinterpret_cast<short8_t*>(&u);
         }
         // ---- rescale O: its rows are queries 4fq + r, whose alpha lives in lane (fr' = 4fq + r) ----

@@ -109,6 +109,50 @@ class BaseVLLMForEdit(ABC):
         loss = (kl * msk).sum()
         return loss / msk.sum() if average else loss
 
+    # ---- image-feature cache (native path only) --------------------------------------------------------------
+    def image_features(self, imgs):
+        """[len(imgs), n_img, d] fp32 features of images given as paths / PIL / arrays.  An image addressed by PATH is
+        encoded once and kept (64-entry LRU) for as long as no parameter outside the language model changes: the
+        evaluator shows the same 4 images of a sample to 21 probes (R/evaluation/vllm_editor_eval.py:98-121) and every
+        shipped editor edits language-model weights only.  The stamp below (version counters of all non-LLM
+        parameters) drops the cache if an editor ever touches the vision side."""
+        import numpy as np
+        from collections import OrderedDict
+        cache = self.__dict__.setdefault("_img_feat_cache", OrderedDict())
+        lm = self._lm_param_prefix()
+        stamp = tuple(p._version for n, p in self.model.named_parameters() if not n.startswith(lm))
+        if self.__dict__.get("_img_feat_stamp") != stamp:
+            cache.clear()
+            self._img_feat_stamp = stamp
+        keys = [i if isinstance(i, str) else None for i in imgs]
+        need = [j for j, k in enumerate(keys) if k is None or k not in cache]
+        feats = {}
+        if need:
+            uniq = []
+            for j in need:   # encode each distinct missing path once
+                if keys[j] is None or keys[j] not in [keys[u] for u in uniq]:
+                    uniq.append(j)
+            pix = torch.from_numpy(np.stack([self.load_pixels(imgs[j]) for j in uniq])).to(self.device)
+            enc = self.engine.encode_images(pix)
+            for r, j in enumerate(uniq):
+                if keys[j] is not None:
+                    cache[keys[j]] = enc[r]
+                    while len(cache) > 64:
+                        cache.popitem(last=False)
+                else:
+                    feats[j] = enc[r]
+        out = []
+        for j, k in enumerate(keys):
+            if k is not None:
+                cache.move_to_end(k)
+                out.append(cache[k])
+            else:
+                out.append(feats[j])
+        return torch.stack(out)
+
+    def _lm_param_prefix(self):
+        return "language_model."
+
     def set_device(self, device):  # base.py:134-136
         self.device = device
         self.model.to(device)

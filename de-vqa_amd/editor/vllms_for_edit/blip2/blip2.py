@@ -82,8 +82,7 @@ class BLIP2OPTForEdit(BaseVLLMForEdit):
         if imgs is not None:
             if isinstance(imgs, list):
                 imgs = imgs[-1]  # quirk kept: only the LAST image of the list is used (blip2.py:54-55)
-            pix = torch.from_numpy(self.load_pixels(imgs)[None]).to(self.device)
-            it = self.engine.encode_images(pix)  # [1, Q, d]
+            it = self.image_features([imgs])  # [1, Q, d]
             if B != 1:
                 it = it.expand(B, -1, -1)
             emb = torch.cat([it, emb], dim=1)

@@ -85,8 +85,7 @@ class LlavaForEdit(BaseVLLMForEdit):
         if imgs is not None:
             if B != 1:
                 raise BaseException("LlavaForEdit (HIP path): image inputs are supported one text at a time")
-            pix = torch.from_numpy(np.stack([self.load_pixels(i) for i in imgs])).to(self.device)
-            feats = self.engine.encode_images(pix)                       # [1, n_img, d]
+            feats = self.image_features(imgs)                            # [1, n_img, d]
             pos = int(torch.where(ids[0] == self.get_img_special_token_id())[0][0])
             emb = torch.cat([emb[:, :pos], feats, emb[:, pos + 1:]], dim=1)
             msk = torch.ones(emb.shape[:2], dtype=msk.dtype, device=self.device)

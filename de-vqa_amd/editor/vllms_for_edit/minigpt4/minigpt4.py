@@ -38,6 +38,9 @@ class MiniGPT4ForEdit(BaseVLLMForEdit):
     def get_llm_tokenizer(self):
         return self.tokenizer
 
+    def _lm_param_prefix(self):
+        return "llama_model."
+
     def load_pixels(self, img):
         if isinstance(img, str):
             with Image.open(img) as im:
@@ -68,8 +71,7 @@ class MiniGPT4ForEdit(BaseVLLMForEdit):
             t = torch.tensor(ids, dtype=torch.int32, device=self.device)
             return lib.gather_rows(emb_tab, t).to(torch.float32)
         if imgs is not None:
-            pix = torch.from_numpy(np.stack([self.load_pixels(i) for i in imgs])).to(self.device)
-            feats = self.engine.encode_images(pix)                      # [B, 32, d]
+            feats = self.image_features(imgs)                           # [B, 32, d]
             rows = []
             for b, text in enumerate(texts):
                 s0, s1 = self._segments(text)

@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs #3-#5 at FULL model dims on one MI355X (random weights from the seeded numpy recipes, text
+prompts from the committed EVQA-shaped records, the tiny fixtures' tokenizers): not the headline metric (bench.py), a
+check that the other model families / editors run at scale, with their throughput.
+
+  python tools/bench_configs.py llava_ft      # LLaVA-1.5-7B + FT_VL, batched engine
+  python tools/bench_configs.py blip2_mend    # BLIP-2-OPT-2.7B + MEND_VL (layers 29-31, hyper-network 12800 -> 1920)
+  python tools/bench_configs.py minigpt4_ike  # MiniGPT-4 (Vicuna-7B) + IKE_VL (k = 32 over a 15000 x 384 corpus)
+"""
+import json
+import os
+import sys
+import time
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+from copy import deepcopy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import devqa_amd  # noqa: E402,F401
+from devqa_amd.synth import mend_aux_init, param_init  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+DEV = "cuda:0"
+
+
+def fill(model, seed, style, threads=16):
+    names = list(model._shapes.keys())
+    with ThreadPoolExecutor(threads) as ex:
+        futs = {n: ex.submit(param_init, n, model._shapes[n], seed, style) for n in names}
+        for n in names:
+            arr = futs.pop(n).result()
+            model.load_named_tensors(lambda _n, a=arr: torch.from_numpy(a), names=[n], refresh=False)
+    model.refresh_derived(force=True)
+
+
+def records(n):
+    rec = json.load(open(os.path.join(GOLD, "evqa8_records.json")))["records"]
+    out = []
+    for i in range(n):
+        r = deepcopy(rec[i % len(rec)])
+        out.append(r)
+    return out
+
+
+class Data:
+    pass
+
+
+def run_eval(editor, n, batched, out_dir="/tmp/devqa_bench_cfg"):
+    from devqa_amd.dataset.vllm import BaseVLLMEditData
+    from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation
+
+    class D(BaseVLLMEditData):
+        def dataset_name(self):
+            return "EVQA"
+    os.chdir(GOLD)
+    ev = VLLMEditorEvaluation(editor, D(records(n), records(n)), "EVQA", out_dir)
+    ev.evaluate_sequential_edit(1, False, None, batched=batched, save=False)   # warm-up (kernel load, caches)
+    torch.cuda.synchronize()
+    ev = VLLMEditorEvaluation(editor, D(records(n), records(n)), "EVQA", out_dir)
+    t0 = time.time()
+    res = ev.evaluate_sequential_edit(1, False, None, batched=batched, save=False)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    return len(res) / dt, dt, res
+
+
+def llava_ft(n=8):
+    from transformers import AutoTokenizer
+    from devqa_amd.llava_spec import LLAVA_1_5_7B
+    from devqa_amd.editor.vllms_for_edit.llava.modeling import LlavaNative
+    from devqa_amd.editor.vllms_for_edit.llava.llava import LlavaForEdit
+    from devqa_amd.editor.vllm_editors.ft_vl.ft_vl import FTvl, FTvlConfig
+    t0 = time.time()
+    cfg7b = dict(LLAVA_1_5_7B, image_token_index=4)   # the stand-in tokenizer (tiny fixture) maps '<image>' to id 4
+    model = LlavaNative(cfg7b, DEV, "bf16")
+    fill(model, 3, "llava")
+    tok = AutoTokenizer.from_pretrained(os.path.join(GOLD, "tiny_llava"))
+    vllm = LlavaForEdit(None, DEV, True, model=model, tokenizer=tok)
+    cfg = FTvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "ft_vl", "llava-v1.5-7b.yaml"))
+    ed = FTvl(vllm, cfg, DEV)
+    print("build %.1fs" % (time.time() - t0), flush=True)
+    cps, dt, res = run_eval(ed, n, True)
+    r0 = res[0][0]
+    print(json.dumps({"config": "LLaVA-1.5-7B + FT_VL (batched engine, %d cycles/step)" % n, "cycles_per_s": round(cps, 2),
+                      "s_per_step": round(dt, 3), "reliability_acc_first": r0["reliability"][0]["acc"]}))
+
+
+def blip2_mend(n=4):
+    from transformers import AutoTokenizer
+    from devqa_amd import blip2_spec
+    from devqa_amd.editor.vllms_for_edit.blip2.modeling import Blip2Native
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from devqa_amd.editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
+    t0 = time.time()
+    model = Blip2Native(blip2_spec.BLIP2_OPT_2_7B, DEV, "bf16")
+    fill(model, 20251121, "opt")
+    tok = AutoTokenizer.from_pretrained(os.path.join(GOLD, "tiny_blip2"))
+    vllm = BLIP2OPTForEdit(None, DEV, model=model, tokenizer=tok)
+    cfg = MENDvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "mend_vl", "blip2-opt-2.7b.yaml"))
+    D = 2560 + 10240
+    shapes = {}
+    for key in ("(2560, 10240)", "(10240, 2560)"):
+        du, dv = eval(key)
+        shapes.update({key + ".u_mean": (du,), key + ".u_std": (du,), key + ".v_mean": (dv,), key + ".v_std": (dv,)})
+        for l in range(2):
+            q = key + ".mlp.layers.%d." % l
+            shapes.update({q + "u": (D, 1920), q + "v": (1920, D), q + "bias": (D,), q + "mode_shift.weight": (3, D),
+                           q + "mode_scale.weight": (3, D)})
+    with ThreadPoolExecutor(8) as ex:
+        aux = dict(zip(shapes, ex.map(lambda kv: torch.from_numpy(mend_aux_init("aux_models." + kv[0], kv[1], 11)), shapes.items())))
+    tm = {"aux_models": aux, "edit_lrs": {str(i): torch.tensor(1e-4) for i in range(6)}}
+    ed = MENDvl(vllm, cfg, DEV, train_modules=tm)
+    print("build %.1fs" % (time.time() - t0), flush=True)
+    cps, dt, res = run_eval(ed, n, None)
+    print(json.dumps({"config": "BLIP-2-OPT-2.7B + MEND_VL (generic per-sample evaluator)", "cycles_per_s": round(cps, 3),
+                      "s_per_cycle": round(dt / n, 3), "edit_time_s": res[0][0]["reliability"][0].get("edit_time")}))
+
+
+def _hash_encode(sentences, dim=384):
+    out = np.zeros((len(sentences), dim), np.float32)
+    for i, s in enumerate(sentences):
+        out[i] = np.random.default_rng(zlib.crc32(s.encode())).standard_normal(dim, dtype=np.float32)
+    return out
+
+
+def minigpt4_ike(n=4):
+    from transformers import AutoTokenizer
+    from devqa_amd.minigpt4_spec import MINIGPT4_VICUNA_7B
+    from devqa_amd.editor.vllms_for_edit.minigpt4.modeling import MiniGPT4Native
+    from devqa_amd.editor.vllms_for_edit.minigpt4.minigpt4 import MiniGPT4ForEdit
+    from devqa_amd.editor.vllm_editors.ike_vl.ike_vl import IKEvl, IKEvlConfig
+    t0 = time.time()
+    model = MiniGPT4Native(MINIGPT4_VICUNA_7B, DEV, "bf16")
+    fill(model, 5, "llava")
+    tok = AutoTokenizer.from_pretrained(os.path.join(GOLD, "tiny_llava"))
+    vllm = MiniGPT4ForEdit(None, DEV, True, model=model, tokenizer=tok)
+    N = 15000
+    sents = ["New Fact: fact %d is %d\nPrompt: fact %d is %d\n\n" % (i, i * 7 % 13, i, i * 7 % 13) for i in range(N)]
+    corpus = {"sentences": sents, "embeddings": np.random.default_rng(1).standard_normal((N, 384), dtype=np.float32)}
+    ed = IKEvl(vllm, IKEvlConfig("minigpt-4-vicuna-7b", k=32), DEV, corpus, _hash_encode)
+    print("build %.1fs" % (time.time() - t0), flush=True)
+    cps, dt, res = run_eval(ed, n, None)
+    print(json.dumps({"config": "MiniGPT-4 (Vicuna-7B) + IKE_VL k=32 over 15000x384 (generic per-sample evaluator)",
+                      "cycles_per_s": round(cps, 3), "s_per_cycle": round(dt / n, 3)}))
+
+
+if __name__ == "__main__":
+    {"llava_ft": llava_ft, "blip2_mend": blip2_mend, "minigpt4_ike": minigpt4_ike}[sys.argv[1]](*[int(a) for a in sys.argv[2:]])
