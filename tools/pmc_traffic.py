@@ -33,12 +33,20 @@ def collect(d, counter):
 
 def short(name):
     m = re.match(r"(?:void )?([A-Za-z0-9_:]+(?:<[^(]*>)?)", name)
-    return (m.group(1) if m else name)[:90]
+    n = (m.group(1) if m else name)[:90]
+    if n.startswith("gemm_bf16_pp_kernel"):   # activation / stream-K template variants of one kernel
+        return "gemm_bf16_pp_kernel"
+    return n
 
 
 def main():
     fd, wd, out = sys.argv[1:4]
-    fe, wr = collect(fd, "FETCH_SIZE"), collect(wd, "WRITE_SIZE")
+    fe0, wr0 = collect(fd, "FETCH_SIZE"), collect(wd, "WRITE_SIZE")
+    fe, wr = defaultdict(lambda: [0.0, 0]), defaultdict(lambda: [0.0, 0])
+    for src, dst in ((fe0, fe), (wr0, wr)):
+        for k, (v, n) in src.items():
+            dst[short(k)][0] += v
+            dst[short(k)][1] += n
     rows = []
     for k in fe:
         f_kib, n = fe[k]
