@@ -108,3 +108,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(lib.DevqaError):
         lib.load()
+
+
+def test_read_res_table(tmp_path):
+    """R/read_res.py:10-27: column order and the 1-acc convention for the non-t3 locality probes."""
+    import json
+    import devqa_amd  # noqa: F401
+    from devqa_amd.read_res import COLUMNS, collect
+    d = tmp_path / "eval_results" / "ft_vl" / "blip2-opt-2.7b" / "EVQA" / "sequential_edit_1"
+    d.mkdir(parents=True)
+    loc = {k: {"acc": 0.25 + 0.05 * i} for i, k in enumerate(["text_loc", "t3i3", "t1i4", "t2i4", "t1i2", "t1i3", "t2i1", "t2i2", "t3i1"])}
+    json.dump({"total_mean": {"reliability": {"acc": 1.0}, "generality": {"text_rephrase": {"acc": 1.0}, "image_rephrase": {"acc": 1.0}},
+                              "locality": loc}}, open(d / "mean_results.json", "w"))
+    rows = collect(str(tmp_path / "eval_results"))
+    assert rows[0] == COLUMNS and len(rows) == 2
+    r = dict(zip(COLUMNS, rows[1]))
+    assert (r["model"], r["data"], r["method"]) == ("blip2-opt-2.7b", "EVQA", "ft_vl")
+    assert abs(float(r["t1i2"]) - (1 - loc["t1i2"]["acc"])) < 1e-12 and abs(float(r["t3i1"]) - loc["t3i1"]["acc"]) < 1e-12
+    assert abs(float(r["text_loc"]) - loc["text_loc"]["acc"]) < 1e-12
