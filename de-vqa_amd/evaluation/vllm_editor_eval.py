@@ -45,11 +45,88 @@ class VLLMEditorEvaluation:
         return pre.to(torch.long).unsqueeze(0), y, m
 
     @staticmethod
+    def _argmax_many(vllm, probes, max_rows=12288):
+        """[(prompt, image, target)] -> [(pre, y, m)], same values as _argmax_last per probe, but the probes of one
+        evaluation phase (the model does not change inside a phase: 9 locality probes per sample before the edit, 12
+        after, vllm_editor_eval.py:98-121) go through the decoder TOGETHER: inputs are built per probe through the
+        plugin API (so editor hooks on get_llm_input_embeds still apply), right-padded into one batch, the decoder runs
+        once and logits are computed on the label rows only."""
+        from .. import lib
+        eng = vllm.engine
+        out = [None] * len(probes)
+        items = []
+        if hasattr(vllm, "image_features"):   # one batched encoder call for the phase's distinct images (fills the cache)
+            uniq = list(dict.fromkeys(img for _, img, _ in probes if isinstance(img, str)))
+            if uniq:
+                vllm.image_features(uniq)
+        for i, (prompt, image, target) in enumerate(probes):
+            (x, vt), y, m = vllm.prompts_imgs_target_to_xym([prompt], [image], [target])
+            assert len(y) == 1 and len(m) == 1
+            items.append((i, x["inputs_embeds"][0], y, m))
+        start = 0
+        while start < len(items):
+            end, tmax = start, 0
+            while end < len(items) and (end == start or max(tmax, items[end][1].shape[0]) * (end - start + 1) <= max_rows):
+                tmax = max(tmax, items[end][1].shape[0])
+                end += 1
+            chunk = items[start:end]
+            B, d = len(chunk), chunk[0][1].shape[1]
+            emb = torch.zeros((B, tmax, d), dtype=torch.float32, device=chunk[0][1].device)
+            msk = torch.zeros((B, tmax), dtype=torch.int32, device=emb.device)
+            rows = []
+            for b, (_, e, y, m) in enumerate(chunk):
+                T, L = e.shape[0], y.shape[1]
+                emb[b, :T] = e
+                msk[b, :T] = 1
+                rows += [b * tmax + T - L + j for j in range(L)]
+            ps = eng.pack_from_embeds(emb, msk)
+            x_fin, _ = eng.decoder_layers(ps)
+            idx = torch.tensor(rows, dtype=torch.int32, device=emb.device)
+            logits = eng.lm_head(lib.gather_rows(x_fin, idx))
+            pre, _, _ = lib.vocab_rows(logits)
+            pre = pre.to(torch.long)
+            r0 = 0
+            for (i, _, y, m) in chunk:
+                L = y.shape[1]
+                out[i] = (pre[r0:r0 + L].unsqueeze(0), y, m)
+                r0 += L
+            start = end
+        return out
+
+    @staticmethod
+    def _can_batch_probes(editor):
+        """Probe batching needs the native engine interface and an editor that does not read the per-probe
+        `query_triple` / `query_range` keys inside get_llm_outpt (retrieval editors such as LTE_VL do)."""
+        eng = getattr(editor.vllm, "engine", None)
+        return (eng is not None and hasattr(eng, "pack_from_embeds") and hasattr(eng, "lm_head")
+                and not getattr(editor, "reads_query_hook", False))
+
+    @staticmethod
     def _acc(pre_y, label_ids, label_masks):
         return float(((pre_y == label_ids) * label_masks).sum() / label_masks.sum())
 
-    def __get_results_after_edit__(self, vllm, ed, rd):
+    def __get_results_after_edit__(self, vllm, ed, rd, batch_probes=False):
         tok = vllm.get_llm_tokenizer()
+        if batch_probes:
+            probes = [(e["prompt"], e["image"], e["target_new"]) for e in ed["requests"]]
+            probes += [(e["prompt"], e["image"], e["target"]) for g in ed["generality"] for e in ed["generality"][g]]
+            probes += [(e["prompt"], e["image"], e["target"]) for l in ed["locality"] for e in ed["locality"][l]]
+            res = iter(self._argmax_many(vllm, probes))
+            for rdr in rd["reliability"]:
+                pre, y, m = next(res)
+                rdr["predict_after_edit"] = tok.decode(pre[m.to(bool)])
+                rdr["acc"] = self._acc(pre, y, m)
+            for gen_name in ed["generality"]:
+                for rdg in rd["generality"][gen_name]:
+                    pre, y, m = next(res)
+                    rdg["predict_after_edit"] = tok.decode(pre[m.to(bool)])
+                    rdg["acc"] = self._acc(pre, y, m)
+            for loc_name in ed["locality"]:
+                for rdl, edl in zip(rd["locality"][loc_name], ed["locality"][loc_name]):
+                    pre, _, m = next(res)
+                    rdl["predict_after_edit"] = tok.decode(pre[m.to(bool)])
+                    rdl["acc"] = self._acc(pre, edl["before_edit_ids"], m)
+            return rd
         for rdr, edr in zip(rd["reliability"], ed["requests"]):
             pre, y, m = self._argmax_last(vllm, edr["prompt"], edr["image"], edr["target_new"])
             rdr["predict_after_edit"] = tok.decode(pre[m.to(bool)])
@@ -148,6 +225,7 @@ class VLLMEditorEvaluation:
 
     def _sequential_generic(self, editor, result_data, eval_data):
         tok = editor.vllm.get_llm_tokenizer()
+        bp = self._can_batch_probes(editor) and os.environ.get("DEVQA_PROBE_BATCH", "1") != "0"
         editor.restore_to_original_model()
         results = []
         for split_rd, split_ed in zip(result_data, eval_data):
@@ -156,6 +234,13 @@ class VLLMEditorEvaluation:
                 rd["reliability"] = rd.pop("requests")
                 for r in rd["reliability"]:
                     r["target"] = r.pop("target_new")
+                if bp:
+                    pairs = [(rdl, edl) for ln in ed["locality"] for rdl, edl in zip(rd["locality"][ln], ed["locality"][ln])]
+                    outs = self._argmax_many(editor.vllm, [(e["prompt"], e["image"], e["target"]) for _, e in pairs])
+                    for (rdl, edl), (pre, _, m) in zip(pairs, outs):
+                        rdl["predict_before_edit"] = tok.decode(pre[m.to(bool)])
+                        edl["before_edit_ids"] = pre
+                    continue
                 for loc_name in ed["locality"].keys():
                     for rdl, edl in zip(rd["locality"][loc_name], ed["locality"][loc_name]):
                         pre, _, m = self._argmax_last(editor.vllm, edl["prompt"], edl["image"], edl["target"])
@@ -167,7 +252,7 @@ class VLLMEditorEvaluation:
                     editor.edit_one_piece(edr)
                     rdr["edit_time"] = time() - start_t
             for rd, ed in zip(split_rd, split_ed):
-                rd = self.__get_results_after_edit__(editor.vllm, ed, rd)
+                rd = self.__get_results_after_edit__(editor.vllm, ed, rd, bp)
                 split_res.append(rd)
             editor.restore_to_original_model()
             results.append(split_res)
