@@ -223,7 +223,8 @@ def main():
                        "cycles_per_step": E, "cycles_total": total_cycles, "mean_ft_steps": round(steps_mean, 2),
                        "layers": "39/12/32" if layers is None else args.layers, "sharding": "splits block-partitioned, 1 gather"},
             "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None if traffic is None else traffic["hbm_bytes_per_launch"], "traffic_detail": traffic,
                          "avg_launch_us": round(1e3 * dms / max(dn, 1), 2), "launches": int(dn),
                          "executed_tflops": round((dfl / 1e12) / (dms / 1e3), 1) if dms > 0 else 0.0,
                          "all_gemm_executed_tflops": round((g_fl / 1e12) / (g_ms / 1e3), 1) if g_ms > 0 else 0.0,
