@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20251121)
     ap.add_argument("--layers", type=str, default=None, help="debug only: 'v,q,t' layer counts (INVALID as a benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="run the two stages of every batch back to back on one stream")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -173,16 +174,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(W):
-        be.run_batch(*batches[i])
+    if W:
+        be.run_batches(batches[:W], pipelined=not args.no_pipeline)
     for k in be.stats:
         be.stats[k] = 0
     barrier()
     lib.profile_gemm(1)
     t0 = time.time()
     outs, metas = [], []
-    for i in range(W, W + K):
-        o, mt = be.run_batch(*batches[i])
+    for o, mt in be.run_batches(batches[W:W + K], pipelined=not args.no_pipeline):
         outs += o
         metas += mt
     barrier()

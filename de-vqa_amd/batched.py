@@ -92,11 +92,11 @@ class BatchedEditEval:
         lo, hi = shard_range(n, rank, world)
         self.editor.restore_to_original_model()
         local, meta = [], []
+        batches = []
         for b0 in range(lo, hi, self.E):
             b1 = min(hi, b0 + self.E)
-            rds = [result_data[i][0] for i in range(b0, b1)]
-            eds = [eval_data[i][0] for i in range(b0, b1)]
-            out, mt = self.run_batch(rds, eds)
+            batches.append(([result_data[i][0] for i in range(b0, b1)], [eval_data[i][0] for i in range(b0, b1)]))
+        for out, mt in self.run_batches(batches):
             local.extend(out)
             meta.extend(mt)
         self.last_meta = meta
@@ -148,12 +148,36 @@ class BatchedEditEval:
         strs, y, m, _ = self.vllm.xym_token_bookkeeping([prompt], [target])
         return self._tok(strs[0], has_image), y[0].tolist(), m[0].tolist()
 
-    @torch.no_grad()
     def run_batch(self, rds: List[Dict], eds: List[Dict]):
+        """One batch, both stages back to back on the current stream."""
+        return self._stage_b(self._stage_a(rds, eds))
+
+    def run_batches(self, batches, pipelined=True):
+        """batches: list of (rds, eds).  Software pipeline over two HIP streams: stage A of batch i+1 (host bookkeeping,
+        vision encoder, frozen decoder prefix: the MFMA-heavy part) is queued on the current stream BEFORE stage B of
+        batch i (pre-edit tails, the FT_VL loop, post-edit tails: many small launches that leave most CUs idle) is queued
+        on a side stream, so the GPU runs them concurrently.  Same kernels, same results as run_batch per batch."""
+        if not pipelined or len(batches) < 2:
+            return [self.run_batch(r, e) for r, e in batches]
+        side = self.__dict__.get("_side_stream")
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=self.eng.dev)
+        outs = []
+        ctx = self._stage_a(*batches[0])
+        for i in range(len(batches)):
+            nxt = self._stage_a(*batches[i + 1]) if i + 1 < len(batches) else None
+            outs.append(self._stage_b(ctx, side))
+            ctx = nxt
+        return outs
+
+    @torch.no_grad()
+    def _stage_a(self, rds: List[Dict], eds: List[Dict]):
         eng, vllm, cfg = self.eng, self.vllm, self.editor.cfg
         dev = eng.dev
         t0 = time.time()
         E = len(eds)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]   # start of vision, end of vision, end of stage A
+        ev[0].record()
         # ---- 1. host bookkeeping ----------------------------------------------------------------
         img_index: Dict[str, int] = {}
         img_list = []
@@ -237,9 +261,7 @@ class BatchedEditEval:
             raise NotImplementedError("batched FT_VL supports <= 16 target tokens per edit (got %d)" % kmax)
         t1c = time.time()
         self.stats["t_host"] += (t1 - t0) + (t1c - t1b)
-        torch.cuda.synchronize()
-        t2 = time.time()
-        self.stats["t_vision"] += (t1b - t1) + (t2 - t1c)   # queueing + what is left of the encoder after pass 2
+        ev[1].record()
         # ---- 3. frozen decoder prefix ---------------------------------------------------------------
         ps = eng.pack_from_tokens(seqs, img_tokens, share_prefix=self.share_prefix)
         x_mid, a = eng.decoder_layers(ps, stop_before_fc2=True)
@@ -280,35 +302,57 @@ class BatchedEditEval:
         if b2 is not None:
             resid_ft = (resid_ft + b2).contiguous()
         del a, x_mid
-        torch.cuda.synchronize()
-        t3 = time.time()
-        self.stats["t_decoder"] += t3 - t2
+        ev[2].record()
+        return dict(rds=rds, probes=probes, E=E, kmax=kmax, d=d, b2=b2, w0=w0, w0_op=w0_op, cyc_rows=cyc_rows, a_tail=a_tail,
+                    resid_tail=resid_tail, a_ft=a_ft, resid_ft=resid_ft, labels=labels, mask=mask, ev=ev)
+
+    @torch.no_grad()
+    def _stage_b(self, c, stream=None):
+        """Stage B on `stream` (None: the current stream).  The tensors of stage A stay referenced by `c` until the
+        stream has been synchronised at the end, so the caching allocator cannot hand them out early."""
+        if stream is None:
+            return self._stage_b_body(c)
+        stream.wait_event(c["ev"][2])
+        with torch.cuda.stream(stream):
+            return self._stage_b_body(c)
+
+    def _stage_b_body(self, c):
+        eng, vllm, cfg = self.eng, self.vllm, self.editor.cfg
+        rds, probes, E, kmax, d, b2, w0, w0_op = c["rds"], c["probes"], c["E"], c["kmax"], c["d"], c["b2"], c["w0"], c["w0_op"]
+        cyc_rows, a_tail, resid_tail, a_ft, resid_ft, labels, mask = (c["cyc_rows"], c["a_tail"], c["resid_tail"], c["a_ft"],
+                                                                      c["resid_ft"], c["labels"], c["mask"])
+        evb = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        evb[0].record()
         # ---- 4. pre-edit tail (all probes share W0) ----------------------------------------------------
         y_pre = lib.gemm(a_tail, w0_op, b2, residual=resid_tail, want="f32")  # fc2 rows of every probe, pristine W
         pre_argmax = self._argmax_from_y(y_pre)
         # ---- 5. FT loop (on the active columns of each edit) --------------------------------------------
-        t4s = time.time()
+        evb[1].record()
         n_steps, losses, delta_c, idx, cnt, npad = self._ft_loop(w0, a_ft, resid_ft, labels, mask, E, kmax, d, cfg)
-        torch.cuda.synchronize()
-        t4 = time.time()
-        self.stats["t_ft"] += t4 - t4s
+        evb[2].record()
         # ---- 6. post-edit tail:  y_post = y_pre + (dW_e restricted to its active columns) . a -------------
-        steps_h = n_steps.cpu().numpy()
-        losses_h = losses.cpu().numpy()
         delta_op = delta_c if eng.adt == torch.float32 else lib.cast_f32_bf16(delta_c)  # [E, d, npad]
         y_post = y_pre  # updated in place, cycle by cycle
         for e, (r0, r1) in enumerate(cyc_rows):
             a_pc = lib.gather_cols(a_tail[r0:r1], idx[e:e + 1], cnt[e:e + 1], npad, per_edit=False)[0]
             lib.gemm(a_pc, delta_op[e], residual=y_post[r0:r1], out_f32=y_post[r0:r1])
         post_argmax = self._argmax_from_y(y_post)
+        evb[3].record()
         pre_h = pre_argmax.cpu().numpy()
         post_h = post_argmax.cpu().numpy()
-        torch.cuda.synchronize()
+        steps_h = n_steps.cpu().numpy()
+        losses_h = losses.cpu().numpy()
+        torch.cuda.current_stream().synchronize()
         t5 = time.time()
-        self.stats["t_tail"] += (t5 - t4) + (t4s - t3)
+        eva = c["ev"]
+        ft_ms = evb[1].elapsed_time(evb[2])
+        self.stats["t_vision"] += eva[0].elapsed_time(eva[1]) * 1e-3     # GPU time per phase (streams may overlap)
+        self.stats["t_decoder"] += eva[1].elapsed_time(eva[2]) * 1e-3
+        self.stats["t_ft"] += ft_ms * 1e-3
+        self.stats["t_tail"] += (evb[0].elapsed_time(evb[1]) + evb[2].elapsed_time(evb[3])) * 1e-3
         # ---- 7. host: results -----------------------------------------------------------------------------
         tok = vllm.tokenizer
-        edit_time = (t4 - t4s) / E
+        edit_time = ft_ms * 1e-3 / E
         out, meta = [], []
         for e, (rd, plist) in enumerate(zip(rds, probes)):
             for p in plist:

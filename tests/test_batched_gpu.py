@@ -100,3 +100,32 @@ def test_early_stop_and_no_update_paths(gold_dir, in_gold_dir):
         assert g["cfg"]["lr"] == 0.03
         assert int(be.last_steps[e]) == g["steps"]
         np.testing.assert_allclose(be.last_losses[e, :g["steps"]], g["losses"], rtol=2e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_pipelined_batches_equal_sequential(gold_dir, in_gold_dir, dtype):
+    """run_batches with the two-stream pipeline (stage A of batch i+1 queued before stage B of batch i on a side
+    stream) returns exactly what running the batches one after the other returns."""
+    from devqa_amd.batched import BatchedEditEval
+    vllm, ed, data = _setup(gold_dir, dtype)
+
+    def batches():
+        out = []
+        for b0 in (0, 3, 6):
+            sl = slice(b0, min(8, b0 + 3))
+            out.append(([deepcopy(r) for r in data.data_with_img_path[sl]], [deepcopy(r) for r in data.data_with_img[sl]]))
+        return out
+    be = BatchedEditEval(ed, cycles_per_batch=3)
+    seq = be.run_batches(batches(), pipelined=False)
+    pip = be.run_batches(batches(), pipelined=True)
+    pip2 = be.run_batches(batches() + batches(), pipelined=True)[3:]
+    for other in (pip, pip2):
+        assert len(seq) == len(other) == 3
+        for (o1, m1), (o2, m2) in zip(seq, other):
+            assert m1 == m2
+            for r1, r2 in zip(o1, o2):
+                for sec in ("generality", "locality"):
+                    for sub in r1[sec]:
+                        a, b = r1[sec][sub][0], r2[sec][sub][0]
+                        assert a["acc"] == b["acc"] and a["predict_after_edit"] == b["predict_after_edit"]
+                assert r1["reliability"][0]["acc"] == r2["reliability"][0]["acc"]
