@@ -197,8 +197,65 @@ def realdim():
     print("realdim mend goldens written")
 
 
+def train():
+    """G6b: two consecutive MENDvl.train_a_batch steps (B = 1, the only batch size the reference's BLIP-2 wrapper can
+    organise: it encodes imgs[-1] only) from the deterministic hyper-network state with FRESH normalisation flags
+    (norm_init False, as after construction + load_ckpt): losses, log dict, clipped gradients, parameter / buffer
+    values after each Adam step."""
+    from copy import deepcopy
+    from editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from editor.vllm_editors.mend_vl import mend_vl as ref_mend
+    os.chdir(GOLD)
+    rec = json.load(open(os.path.join(GOLD, "evqa8_records.json")))
+    records = rec["records"]
+    cfg = ref_mend.MENDvlConfig.from_yaml(os.path.join(GOLD, "tiny_mend_cfg.yaml"))
+    cfg.aux_model.lr = 1.0e-3       # visible parameter movement in two steps (shipped: 1e-6)
+    cfg.edit_lr_lr = 1.0e-3
+    vllm = BLIP2OPTForEdit(os.path.join(GOLD, "tiny_blip2"), "cpu")
+    ed = ref_mend.MENDvl(vllm, cfg, "cpu")
+    ck = torch.load(os.path.join(GOLD, "tiny_mend_ckpt.pt"), map_location="cpu", weights_only=True)
+    for k, mod in ed.get_modules_for_training().items():
+        mod.load_state_dict(ck["train_modules"][k])
+    ed.set_train(True)
+    ed.opt = ed.get_a_new_optimizer()
+    grads = {}
+    orig_step = ed.opt.step
+
+    def step(*a, **k):
+        for mname, mod in ed.get_modules_for_training().items():
+            for n, p_ in mod.named_parameters():
+                grads["%s.%s" % (mname, n)] = None if p_.grad is None else p_.grad.detach().clone()
+        return orig_step(*a, **k)
+    ed.opt.step = step
+    npz, js = {}, {"aux_lr": cfg.aux_model.lr, "edit_lr_lr": cfg.edit_lr_lr, "steps": []}
+
+    def organise(d):   # organize_batch_data for a batch of one (mend_vl.py:264-290)
+        e = vllm.prompts_imgs_target_to_xym([d["requests"][0]["prompt"]], [d["requests"][0]["image"]], [d["requests"][0]["target_new"]])
+        g = {k: vllm.prompts_imgs_target_to_xym([d["generality"][k][0]["prompt"]], [d["generality"][k][0]["image"]],
+                                                [d["generality"][k][0]["target"]]) for k in d["generality"]}
+        l = {k: vllm.prompts_imgs_target_to_xym([d["locality"][k][0]["prompt"]], [d["locality"][k][0]["image"]],
+                                                [d["locality"][k][0]["target"]]) for k in d["locality"]}
+        return e, g, l
+    for si in range(2):
+        with torch.no_grad():
+            batch = organise(deepcopy(records[si]))
+        loss, log = ed.train_a_batch(batch)
+        js["steps"].append({"sample": si, "loss": loss, "log": log})
+        for n, g in grads.items():
+            if g is not None:
+                npz["s%d_grad_%s" % (si, n)] = t2n(g).astype(np.float32)
+        for mname, mod in ed.get_modules_for_training().items():
+            for n, t in mod.state_dict().items():
+                npz["s%d_state_%s.%s" % (si, mname, n)] = t2n(t).astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "tiny_mend_train_goldens.npz"), **npz)
+    json.dump(js, open(os.path.join(GOLD, "tiny_mend_train_goldens.json"), "w"), indent=1)
+    print("mend train goldens written:", len(npz), "arrays; losses", [s_["loss"] for s_ in js["steps"]])
+
+
 if __name__ == "__main__":
-    if "--realdim" in sys.argv:
+    if "--train" in sys.argv:
+        train()
+    elif "--realdim" in sys.argv:
         realdim()
     else:
         main()
