@@ -137,3 +137,173 @@ extern "C" int devqa_logit_kl_rows(const float* logits1, int64_t ld1, const floa
     DEVQA_LAUNCH_CHECK("logit_kl_rows");
     return DEVQA_OK;
 }
+
+// ---- MEND_VL training (train_a_batch, R/editor/vllm_editors/mend_vl/mend_vl.py:301-341) ---------------------------------
+
+// d/d(logits2) of coef[r] * KL(softmax(l1[r]) || softmax(l2[r])) = coef[r] * (softmax(l2[r]) - softmax(l1[r]));  kl[r] too
+template <typename T>
+__global__ __launch_bounds__(256) void kl_dlogits_kernel(const float* __restrict__ l1, const float* __restrict__ l2, int64_t ld1,
+                                                         int64_t ld2, int V, const float* __restrict__ coef, float* __restrict__ kl,
+                                                         T* __restrict__ dl2, int64_t ldd) {
+    __shared__ float red[8];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* a = l1 + (int64_t)r * ld1;
+    const float* b = l2 + (int64_t)r * ld2;
+    auto block_max = [&](float v) {
+        v = wave_max(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    };
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    float ma = -INFINITY, mb = -INFINITY;
+    for (int c = tid; c < V; c += 256) { ma = fmaxf(ma, a[c]); mb = fmaxf(mb, b[c]); }
+    ma = block_max(ma);
+    mb = block_max(mb);
+    float sa = 0.f, sb = 0.f;
+    for (int c = tid; c < V; c += 256) { sa += expf(a[c] - ma); sb += expf(b[c] - mb); }
+    sa = block_sum(sa);
+    sb = block_sum(sb);
+    const float lza = ma + logf(sa), lzb = mb + logf(sb);
+    const float cf = coef[r];
+    float acc = 0.f;
+    for (int c = tid; c < V; c += 256) {
+        const float lp1 = a[c] - lza, lp2 = b[c] - lzb;
+        const float p1 = expf(lp1);
+        acc += p1 * (lp1 - lp2);
+        mo_st<T>(dl2 + (int64_t)r * ldd + c, cf * (expf(lp2) - p1));
+    }
+    acc = block_sum(acc);
+    if (tid == 0) kl[r] = acc;
+}
+
+// running mean / sum of squared deviations over rows, one row at a time (auxiliary_networks.py:88-91,122-136):
+//   k += 1; new_m = m + (x - m) / k; s += (x - m) * (x - new_m); m = new_m        (reset: m = x_0, s = 0, k = 1)
+// then std = sqrt(s / (k - 1)).  One thread per feature; k (a scalar) is updated by thread 0 after all features used it.
+__global__ void welford_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx, int n_rows, int D, int reset,
+                                    float* __restrict__ mean, float* __restrict__ s, float* __restrict__ stdv,
+                                    const float* __restrict__ k_in, float* __restrict__ k_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float kk = reset ? 0.f : k_in[0];
+    float m = reset ? 0.f : mean[c], ss = reset ? 0.f : s[c];
+    for (int r = 0; r < n_rows; ++r) {
+        const float v = x[(int64_t)(idx ? idx[r] : r) * D + c];
+        if (kk == 0.f) { m = v; ss = 0.f; kk = 1.f; continue; }
+        kk += 1.f;
+        const float nm = m + (v - m) / kk;
+        ss += (v - m) * (v - nm);
+        m = nm;
+    }
+    mean[c] = m;
+    s[c] = ss;
+    stdv[c] = sqrtf(ss / (kk - 1.f));
+    if (c == 0) k_out[0] = kk;   // every thread computed the same kk; k_out != k_in (late blocks still read k_in)
+}
+
+// backward of out = max(z, 0) + x, z = (pre + bias) * scale + shift for one mode row:
+//   dz = dout * (z >= 0);  dpre = dz * scale;  g_scale += sum_r dz * (pre + bias);  g_shift += sum_r dz;  g_bias += sum_r dpre
+__global__ void mend_lrlinear_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ bias, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, const float* __restrict__ dout, int n_rows, int D,
+                                         float* __restrict__ dpre, float* __restrict__ g_scale, float* __restrict__ g_shift,
+                                         float* __restrict__ g_bias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    const float b = bias[c], sc = scale[c], sh = shift[c];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int r = 0; r < n_rows; ++r) {
+        const int64_t i = (int64_t)r * D + c;
+        const float pb = pre[i] + b;
+        const float z = pb * sc + sh;
+        const float dz = z >= 0.f ? dout[i] : 0.f;   // clamp(min=0): the gradient passes AT 0 (auxiliary_networks.py:78-79)
+        const float dp = dz * sc;
+        dpre[i] = dp;
+        a0 += dz * pb;
+        a1 += dz;
+        a2 += dp;
+    }
+    g_scale[c] += a0;
+    g_shift[c] += a1;
+    g_bias[c] += a2;
+}
+
+// sum of squares -> out[0] += sum x^2 (fp32 atomics; caller zeroes out)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += x[i] * x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// torch.optim.Adam (no weight decay, amsgrad off): g = grad * grad_scale[0]; m, v moments; step t (1-based)
+__global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+                                 int64_t n, float lr, float b1, float b2, float eps, int t, const float* __restrict__ grad_scale) {
+    const float gs = grad_scale ? grad_scale[0] : 1.f;
+    const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = grad[i] * gs;
+        const float mi = b1 * m[i] + (1.f - b1) * g;
+        const float vi = b2 * v[i] + (1.f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+    }
+}
+
+extern "C" int devqa_kl_dlogits(const float* logits1, int64_t ld1, const float* logits2, int64_t ld2, int R, int V, const float* coef,
+                                float* kl, void* dlogits2, int64_t ldd, int dlogits_bf16, void* stream) {
+    DEVQA_CHECK_ARG(logits1 && logits2 && coef && kl && dlogits2 && R > 0 && V > 0, "kl_dlogits: bad arguments");
+    if (dlogits_bf16)
+        hipLaunchKernelGGL(kl_dlogits_kernel<bf16_t>, dim3(R), dim3(256), 0, (hipStream_t)stream, logits1, logits2, ld1, ld2, V, coef, kl,
+                           (bf16_t*)dlogits2, ldd);
+    else
+        hipLaunchKernelGGL(kl_dlogits_kernel<float>, dim3(R), dim3(256), 0, (hipStream_t)stream, logits1, logits2, ld1, ld2, V, coef, kl,
+                           (float*)dlogits2, ldd);
+    DEVQA_LAUNCH_CHECK("kl_dlogits");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_welford_rows(const float* x, const int32_t* idx, int n_rows, int D, int reset, float* mean, float* s, float* stdv,
+                                  const float* k_in, float* k_out, void* stream) {
+    DEVQA_CHECK_ARG(x && mean && s && stdv && k_in && k_out && k_in != k_out && n_rows >= 0 && D > 0, "welford_rows: bad arguments");
+    hipLaunchKernelGGL(welford_rows_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, idx, n_rows, D, reset, mean, s,
+                       stdv, k_in, k_out);
+    DEVQA_LAUNCH_CHECK("welford_rows");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_mend_lrlinear_bwd(const float* pre, const float* bias, const float* scale, const float* shift, const float* dout,
+                                       int n_rows, int D, float* dpre, float* g_scale, float* g_shift, float* g_bias, void* stream) {
+    DEVQA_CHECK_ARG(pre && bias && scale && shift && dout && dpre && g_scale && g_shift && g_bias && n_rows > 0 && D > 0,
+                    "mend_lrlinear_bwd: bad arguments");
+    hipLaunchKernelGGL(mend_lrlinear_bwd_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, pre, bias, scale, shift, dout,
+                       n_rows, D, dpre, g_scale, g_shift, g_bias);
+    DEVQA_LAUNCH_CHECK("mend_lrlinear_bwd");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
+    DEVQA_CHECK_ARG(x && out && n > 0, "sumsq: bad arguments");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(mo_grid(n) > 1024 ? 1024 : mo_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    DEVQA_LAUNCH_CHECK("sumsq");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_adam_step(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               int step, const float* grad_scale, void* stream) {
+    DEVQA_CHECK_ARG(p && grad && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+    hipLaunchKernelGGL(adam_step_kernel, dim3(mo_grid(n)), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, lr, beta1, beta2, eps, step,
+                       grad_scale);
+    DEVQA_LAUNCH_CHECK("adam_step");
+    return DEVQA_OK;
+}

@@ -24,6 +24,7 @@ from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, List
 
+import numpy as np
 import torch
 import yaml
 
@@ -70,7 +71,7 @@ _MOD_RE = re.compile(r"^(.*\.layers\.)(\d+)\.(fc1|fc2)$")
 
 class MENDvl(VLLMBaseEditor):
     def __init__(self, vllm, config: MENDvlConfig, device="cuda:0", vllm_proc_data=None, device_proc_data=None,
-                 ckpt_path=None, train_modules=None):
+                 ckpt_path=None, train_modules=None, for_train=False):
         super().__init__(vllm, device)
         self.cfg = config
         eng = self.vllm.engine
@@ -95,10 +96,15 @@ class MENDvl(VLLMBaseEditor):
         self.n_layers = config.aux_model.n_hidden + 1
         self.aux = None
         self.last: Dict[str, Dict] = {}
+        self.training = False
+        self.norm_init = {}     # GradientTransform.norm_init per shape: False after construction / load (see _transform)
+        self.opt = None
         if ckpt_path is not None:
             self.load_ckpt(ckpt_path)
         elif train_modules is not None:
             self.load_train_modules(train_modules)
+        elif for_train:
+            self.reinit_train_parameters()
         eng.module_deltas = {}
 
     # ---- trained state ------------------------------------------------------------------------------------------
@@ -111,13 +117,16 @@ class MENDvl(VLLMBaseEditor):
 
     def load_train_modules(self, tm):
         self.aux = {k: v.to(self.dev, torch.float32).contiguous() for k, v in tm["aux_models"].items()}
+        self.lr_t = torch.tensor([float(tm["edit_lrs"][str(i)]) for i in range(len(self.modules))], dtype=torch.float32,
+                                 device=self.dev)
         for i, m in enumerate(self.modules):
             m["lr"] = float(tm["edit_lrs"][str(i)])
         for shape in {m["shape"] for m in self.modules}:
             for leaf in ("u_mean", "u_std", "v_mean", "v_std"):
                 t = self.aux["%s.%s" % (str(shape), leaf)]
-                if not bool(torch.isfinite(t).all()):
-                    raise RuntimeError("MEND_VL normalisation buffers are not finite: load a trained checkpoint")
+                if not bool(torch.isfinite(t).all()) and not self.training:
+                    self._stats_finite = False
+        self._stats_finite = getattr(self, "_stats_finite", True)
 
     # ---- plugin API ---------------------------------------------------------------------------------------------
     def name_of_editor_and_model(self):
@@ -146,6 +155,8 @@ class MENDvl(VLLMBaseEditor):
     def __edit_batch__(self, llm_inpt, vt_range, label_ids, label_masks):
         if self.aux is None:
             raise RuntimeError("MEND_VL needs trained hyper-network weights (ckpt_path / train_modules)")
+        if not self.training and not getattr(self, "_stats_finite", True) and not any(self.norm_init.values()):
+            raise RuntimeError("MEND_VL normalisation buffers are not finite: load a trained checkpoint")
         eng, dev = self.vllm.engine, self.dev
         emb, am = llm_inpt["inputs_embeds"], llm_inpt["attention_mask"]
         B, T = emb.shape[:2]
@@ -178,30 +189,44 @@ class MENDvl(VLLMBaseEditor):
             xin32 = xin.to(torch.float32).contiguous()
             d32 = delta.to(torch.float32).contiguous()
             nz = ((xin32 != 0).any(-1) & (d32 != 0).any(-1)).nonzero().flatten().to(torch.int32)   # auxiliary_networks.py:118-120
-            xt, dt = self._transform(m, xin32, d32, nz)
+            xt, dt, trace = self._transform(m, xin32, d32, nz)
             m["X"].append(xt)
             m["D"].append(dt * m["lr"])
             m["n"] += int(nz.numel())
-            self.last[m["name"]] = {"x": xin32, "delta": d32, "xt": xt, "dt": dt}
+            self.last[m["name"]] = {"x": xin32, "delta": d32, "xt": xt, "dt": dt, "trace": trace}
         self._install_deltas()
 
     def _transform(self, m, xin32, d32, nz):
-        """GradientTransform.forward in eval mode + IDMLP (auxiliary_networks.py:112-151, 20-24, 62-83)."""
+        """GradientTransform.forward + IDMLP (auxiliary_networks.py:112-151, 20-24, 62-83).  In training mode the running
+        normalisation statistics are first updated row by row (:122-136; `norm_init` is a plain attribute the reference
+        does NOT restore from a checkpoint, so the first training row after construction re-initialises them), and the
+        intermediate activations are kept for the backward pass."""
         pre = "%s." % str(m["shape"])
         A = self.aux
         norm = bool(self.cfg.aux_model.norm)
+        if self.training and nz.numel() > 0:
+            reset = not self.norm_init.get(m["shape"], False)
+            k_old = A[pre + "k"]
+            k_new = lib.welford_rows(xin32, nz, reset, A[pre + "u_mean"], A[pre + "u_s"], A[pre + "u_std"], k_old)
+            lib.welford_rows(d32, nz, reset, A[pre + "v_mean"], A[pre + "v_s"], A[pre + "v_std"], k_old)
+            A[pre + "k"] = k_new
+            self.norm_init[m["shape"]] = True
         inp = lib.mend_normalize_concat(xin32, d32, nz, A[pre + "u_mean"] if norm else None, A[pre + "u_std"] if norm else None,
                                         A[pre + "v_mean"] if norm else None, A[pre + "v_std"] if norm else None, 1e-7)
+        din = xin32.shape[1]
         if inp.shape[0] == 0:
-            return inp[:, :xin32.shape[1]], inp[:, xin32.shape[1]:]
+            return inp[:, :din], inp[:, din:], None
+        trace = []
         for l in range(self.n_layers):
             q = pre + "mlp.layers.%d." % l
             tlow = lib.gemm(inp, A[q + "v"])                  # [n, rank]   = x v^T        (exact-fp32 GEMM)
             prea = lib.gemm(tlow, A[q + "u"])                 # [n, D]      = (x v^T) u^T
-            inp = lib.mend_lrlinear_epilogue(prea, A[q + "bias"], A[q + "mode_scale.weight"][m["idx"]].contiguous(),
+            out = lib.mend_lrlinear_epilogue(prea, A[q + "bias"], A[q + "mode_scale.weight"][m["idx"]].contiguous(),
                                              A[q + "mode_shift.weight"][m["idx"]].contiguous(), inp)
-        din = xin32.shape[1]
-        return inp[:, :din].contiguous(), inp[:, din:].contiguous()
+            if self.training:
+                trace.append({"inp": inp, "t": tlow, "pre": prea})
+            inp = out
+        return inp[:, :din].contiguous(), inp[:, din:].contiguous(), (trace if self.training else None)
 
     def _install_deltas(self):
         """Factors of the running-mean delta weight for the engine: dW = X^T D / n with X, D the concatenated rows of
@@ -236,3 +261,245 @@ class MENDvl(VLLMBaseEditor):
             X = torch.cat([X, torch.zeros((pad, X.shape[1]), dtype=X.dtype, device=X.device)])
             D = torch.cat([D, torch.zeros((pad, D.shape[1]), dtype=D.dtype, device=D.device)])
         return lib.gemm(X.t().contiguous(), D.t().contiguous())     # X^T D: A = X^T [d_in, n], W = D^T [d_out, n]
+
+    # ================================================================================================================
+    # training (mend_vl.py:248-341; base.py:142-268).  One step = pre-edit locality logits -> edit -> reliability /
+    # generality label losses + locality KL on the edited model -> gradients of the hyper-network -> clip -> Adam.
+    # The reference runs 1 + 1 + 2 + 9 separate forwards and an autograd backward; here the 12 post-edit probes go
+    # through the decoder as ONE packed batch (they do not interact), the backward is the explicit one of the edit
+    # path, and gradients reach the hyper-network through the low-rank factors (delta_W is never materialised).
+    # ================================================================================================================
+    def reinit_train_parameters(self, seed=None):
+        """Fresh hyper-network state as the reference constructs it (auxiliary_networks.py:31-38,45-52,99-105): u = 0,
+        v ~ N(0, 1), bias = 0, mode shift 0 / scale 1, NaN normalisation buffers (filled by the first training rows),
+        edit learning rates = cfg.init_edit_lr."""
+        g = torch.Generator().manual_seed(0 if seed is None else int(seed))
+        rank = self.cfg.aux_model.rank
+        tm = {"aux_models": {}, "edit_lrs": {str(i): torch.tensor(float(self.cfg.init_edit_lr)) for i in range(len(self.modules))}}
+        for shape in dict.fromkeys(m["shape"] for m in self.modules):
+            du, dv = shape
+            D, key = du + dv, str(shape)
+            n_modes = sum(1 for m in self.modules if m["shape"] == shape)
+            mid = min(rank, D)
+            nan = float("nan")
+            tm["aux_models"].update({key + ".u_mean": torch.full((du,), nan), key + ".v_mean": torch.full((dv,), nan),
+                                     key + ".u_std": torch.full((du,), nan), key + ".v_std": torch.full((dv,), nan),
+                                     key + ".u_s": torch.full((du,), nan), key + ".v_s": torch.full((dv,), nan),
+                                     key + ".k": torch.full((1,), nan)})
+            for l in range(self.n_layers):
+                q = key + ".mlp.layers.%d." % l
+                tm["aux_models"].update({q + "u": torch.zeros(D, mid), q + "v": torch.randn(mid, D, generator=g),
+                                         q + "bias": torch.zeros(D), q + "mode_shift.weight": torch.zeros(n_modes, D),
+                                         q + "mode_scale.weight": torch.ones(n_modes, D)})
+        self.load_train_modules(tm)
+
+    def get_modules_for_training(self):
+        """{'aux_models': state dict, 'edit_lrs': state dict} -- the two entries of the reference's checkpoint."""
+        return {"aux_models": self.aux, "edit_lrs": {str(i): self.lr_t[i] for i in range(len(self.modules))}}
+
+    def _trainable(self):
+        return [k for k in self.aux if ".mlp.layers." in k]
+
+    def set_train(self, if_train=False):
+        self.training = bool(if_train)
+
+    def get_a_new_optimizer(self):
+        """torch.optim.Adam([{aux_models, lr = cfg.aux_model.lr}, {edit_lrs, lr = cfg.edit_lr_lr}]) (:293-296) as plain state."""
+        st = {"t": 0, "m": {}, "v": {}}
+        for k in self._trainable():
+            st["m"][k] = torch.zeros_like(self.aux[k])
+            st["v"][k] = torch.zeros_like(self.aux[k])
+        st["m"]["edit_lrs"] = torch.zeros_like(self.lr_t)
+        st["v"]["edit_lrs"] = torch.zeros_like(self.lr_t)
+        return st
+
+    def save_ckpt(self, path, i=0, epoch=0, loss=0.0, ema_loss=None):
+        """The reference's `Best` layout (base.py:237-252); optimizer moments under 'opt' in this implementation's own
+        form (the reference stores a torch.optim state dict there; load_ckpt of either side ignores a foreign 'opt')."""
+        tm = {"aux_models": {k: v.detach().cpu() for k, v in self.aux.items()},
+              "edit_lrs": {str(i_): self.lr_t[i_].detach().cpu() for i_ in range(len(self.modules))}}
+        opt = None if self.opt is None else {"t": self.opt["t"], "m": {k: v.cpu() for k, v in self.opt["m"].items()},
+                                            "v": {k: v.cpu() for k, v in self.opt["v"].items()}}
+        torch.save({"i": i, "epoch": epoch, "loss": loss, "ema_loss": ema_loss, "train_modules": tm, "opt": opt,
+                    "lr_scheduler": None}, path)
+
+    @staticmethod
+    def _items(xym):
+        """((llm_inpt, vt), y, m) with batch B -> per-sequence (embeds [T,d] fp32, labels [L], mask [L])"""
+        (x, _vt), y, m = xym
+        emb, am = x["inputs_embeds"], x["attention_mask"]
+        out = []
+        for b in range(emb.shape[0]):
+            T = int(am[b].sum())
+            out.append((emb[b, :T].to(torch.float32), y[b], m[b]))
+        return out
+
+    def _pack(self, items):
+        eng = self.vllm.engine
+        tmax = (max(e.shape[0] for e, _, _ in items) + 3) // 4 * 4
+        B, d = len(items), items[0][0].shape[1]
+        emb = torch.zeros((B, tmax, d), dtype=torch.float32, device=self.dev)
+        msk = torch.zeros((B, tmax), dtype=torch.int32, device=self.dev)
+        rows, spans = [], []
+        for b, (e, y, m) in enumerate(items):
+            T, L = e.shape[0], y.shape[-1]
+            emb[b, :T] = e
+            msk[b, :T] = 1
+            spans.append((len(rows), len(rows) + L))
+            rows += [b * tmax + T - L + j for j in range(L)]
+        return eng.pack_from_embeds(emb, msk), torch.tensor(rows, dtype=torch.int32, device=self.dev), spans
+
+    @torch.no_grad()
+    def train_a_batch(self, a_batch_of_training_data):
+        """-> (loss, log_dict) with the reference's keys (:301-341)."""
+        if self.opt is None:
+            self.opt = self.get_a_new_optimizer()
+        eng, dev, cfg = self.vllm.engine, self.dev, self.cfg
+        edit_xym, gen_xym, loc_xym = a_batch_of_training_data
+        self.restore_to_original_model()                                   # clear_module_deltas(True, True, True)
+        self.training = True
+        # ---- pre-edit logits of the locality probes (label rows only: the KL is taken over the last-L window) ----
+        loc_names = list(loc_xym.keys())
+        loc_items = [it for k in loc_names for it in self._items(loc_xym[k])]
+        ps, ridx, spans = self._pack(loc_items)
+        x_fin, _ = eng.decoder_layers(ps)
+        pre_logits = eng.lm_head(lib.gather_rows(x_fin, ridx))              # [R_loc, V] fp32
+        # ---- the edit (updates the running statistics, keeps the hyper-network activations) ------------------
+        (x, vt), y, msk = edit_xym
+        self.__edit_batch__(x, vt, y, msk)
+        # ---- post-edit probes: reliability (the edit batch), generality, locality -- one packed pass -------------
+        groups = [("rel", None, self._items(edit_xym), cfg.relia_lambda)]
+        groups += [("gen", k, self._items(gen_xym[k]), cfg.gen_lambda) for k in gen_xym]
+        groups += [("loc", k, self._items(loc_xym[k]), cfg.loc_lambda) for k in loc_names]
+        items = [it for g in groups for it in g[2]]
+        save = {"layers": set(self.layers)}
+        ps, ridx, spans = self._pack(items)
+        x_fin, _ = eng.decoder_layers(ps, save=save)
+        pre_ln = lib.gather_rows(x_fin, ridx)
+        logits = eng.lm_head(pre_ln)                                        # [R, V]
+        R = logits.shape[0]
+        coef = torch.zeros((R,), dtype=torch.float32, device=dev)
+        labels = torch.zeros((R,), dtype=torch.int32, device=dev)
+        is_kl = torch.zeros((R,), dtype=torch.bool, device=dev)
+        gi, layout = 0, []
+        for kind, name, its, lam in groups:
+            tot = float(sum(float(m.sum()) for _, _, m in its))            # label_loss / logit_KL_loss average over the batch's mask
+            r0 = spans[gi][0]
+            for (_, y_, m_) in its:
+                a, b = spans[gi]
+                coef[a:b] = m_.to(dev, torch.float32) * (lam / tot)
+                labels[a:b] = y_.to(dev, torch.int32)
+                gi += 1
+            layout.append((kind, name, r0, spans[gi - 1][1]))
+        n_lab = layout[len(groups) - len(loc_names) - 1][3] if loc_names else R      # label-loss rows come first, KL rows last
+        _, nll, dlog = lib.vocab_rows(logits[:n_lab], labels[:n_lab].contiguous(), coef[:n_lab].contiguous(), want_argmax=False,
+                                      want_nll=True, want_dlogits=True, dlogits_dtype=eng.adt)
+        row_loss = nll * coef[:n_lab]
+        if loc_names:
+            kl, dkl = lib.kl_dlogits(pre_logits, logits[n_lab:], coef[n_lab:].contiguous(), eng.adt)
+            dlog = torch.cat([dlog, dkl], 0)
+            row_loss = torch.cat([row_loss, kl * coef[n_lab:]], 0)
+        row_loss_h = row_loss.cpu()
+        log = {"Generality loss": {}, "Locality loss": {}}
+        for kind, name, a, b in layout:
+            v = float(row_loss_h[a:b].sum())
+            if kind == "rel":
+                log["Reliability loss"] = v
+            else:
+                log["Generality loss" if kind == "gen" else "Locality loss"][name] = v
+        loss = float(row_loss_h.sum())
+        # ---- backward: logits rows -> final norm -> edited layers; (input, output-gradient) of every edited module -----
+        dH = lib.gemm_rows_longk(dlog.contiguous(), self.vllm.model.embed_T) if R <= 64 else \
+            lib.gemm(dlog.contiguous(), self.vllm.model.embed_T, want="f32")
+        dxr = eng.final_norm_bwd(pre_ln, dH)
+        dx = torch.zeros_like(x_fin)
+        dx.index_copy_(0, ridx.long(), dxr)
+        caps, _ = eng.decoder_backward(ps, save, dx, {m["name"] for m in self.modules})
+        # ---- gradients of the hyper-network through the low-rank factors ------------------------------------------
+        G = {k: torch.zeros_like(self.aux[k]) for k in self._trainable()}
+        g_lr = torch.zeros_like(self.lr_t)
+
+        def padk(t):      # [r, k] -> zero-padded to k % 4 == 0 (exact-fp32 GEMM operand)
+            pad = (-t.shape[1]) % 4
+            return t.contiguous() if pad == 0 else torch.cat([t, torch.zeros((t.shape[0], pad), dtype=t.dtype, device=dev)], 1).contiguous()
+        for mi, m in enumerate(self.modules):
+            tr = self.last[m["name"]].get("trace")
+            if not tr or m["n"] == 0:
+                continue
+            inp, dout = caps[m["name"]]
+            inp32, dout32 = inp.to(torch.float32).contiguous(), dout.to(torch.float32).contiguous()
+            xt, dt = self.last[m["name"]]["xt"], self.last[m["name"]]["dt"]
+            n, s_ = xt.shape[0], m["lr"] / m["n"]
+            T1 = lib.gemm(dt, dout32)                                   # [n, R'] = dt . dOut^T
+            T2 = lib.gemm(xt, inp32)                                    # [n, R'] = xt . inp^T
+            g_lr[mi] = (T1 * T2).sum() / m["n"]                         # d loss / d lr  (dW = xt^T dt lr / n)
+            dxt = lib.gemm(padk(T1), padk(inp32.t()), alpha=s_)         # [n, d_in]  = s T1 . inp
+            ddt = lib.gemm(padk(T2), padk(dout32.t()), alpha=s_)        # [n, d_out] = s T2 . dOut
+            dcat = torch.cat([dxt, ddt], 1).contiguous()
+            pre = "%s." % str(m["shape"])
+            for l in range(self.n_layers - 1, -1, -1):
+                q = pre + "mlp.layers.%d." % l
+                rec = tr[l]
+                A = self.aux
+                dpre = lib.mend_lrlinear_bwd(rec["pre"], A[q + "bias"], A[q + "mode_scale.weight"][m["idx"]].contiguous(),
+                                             A[q + "mode_shift.weight"][m["idx"]].contiguous(), dcat,
+                                             G[q + "mode_scale.weight"][m["idx"]], G[q + "mode_shift.weight"][m["idx"]], G[q + "bias"])
+                lib.gemm(padk(dpre.t()), padk(rec["t"].t()), residual=G[q + "u"], out_f32=G[q + "u"])          # += dpre^T t
+                dtl = lib.gemm(dpre, A[q + "u"].t().contiguous())                                               # [n, rank] = dpre . u
+                lib.gemm(padk(dtl.t()), padk(rec["inp"].t()), residual=G[q + "v"], out_f32=G[q + "v"])          # += dt^T inp
+                dcat = lib.gemm(dtl, A[q + "v"].t().contiguous(), residual=dcat, out_f32=torch.empty_like(dcat))  # dt . v + dcat
+        # ---- clip_grad_norm_(aux_models.parameters(), 100, error_if_nonfinite=True) + Adam ---------------------------
+        ss = torch.zeros((1,), dtype=torch.float32, device=dev)
+        for k in G:
+            lib.sumsq_(G[k], ss)
+        norm = float(ss.sqrt())
+        if not np.isfinite(norm):
+            raise RuntimeError("The total norm of the hyper-network gradients is non-finite")
+        log["Grad-Norm"] = norm
+        scale = torch.tensor([min(1.0, 100.0 / (norm + 1e-6))], dtype=torch.float32, device=dev)
+        self.last_grads = dict(G, edit_lrs=g_lr)
+        st = self.opt
+        st["t"] += 1
+        for k in G:
+            lib.adam_step_(self.aux[k], G[k], st["m"][k], st["v"][k], cfg.aux_model.lr, st["t"], scale)
+        lib.adam_step_(self.lr_t, g_lr, st["m"]["edit_lrs"], st["v"]["edit_lrs"], cfg.edit_lr_lr, st["t"], None)
+        for i, m in enumerate(self.modules):
+            m["lr"] = float(self.lr_t[i])
+        return loss, log
+
+    def organize_batch_data(self, a_batch_of_training_data: List):
+        """mend_vl.py:264-290 -- (edit_xym, gen_xym, loc_xym) built through the wrapper's prompts_imgs_target_to_xym."""
+        vllm = self.vllm
+        d = a_batch_of_training_data
+        edit = vllm.prompts_imgs_target_to_xym([x["requests"][0]["prompt"] for x in d], [x["requests"][0]["image"] for x in d],
+                                               [x["requests"][0]["target_new"] for x in d])
+        gen = {k: vllm.prompts_imgs_target_to_xym([x["generality"][k][0]["prompt"] for x in d], [x["generality"][k][0]["image"] for x in d],
+                                                  [x["generality"][k][0]["target"] for x in d]) for k in d[0]["generality"]}
+        loc = {k: vllm.prompts_imgs_target_to_xym([x["locality"][k][0]["prompt"] for x in d], [x["locality"][k][0]["image"] for x in d],
+                                                  [x["locality"][k][0]["target"] for x in d]) for k in d[0]["locality"]}
+        return edit, gen, loc
+
+    def train(self, vllm_edit_data, total_epochs=1, batch_size=1, save_ckpt_path=None, seed=None, ema_alpha=0.1, log_fn=None):
+        """The reference's training loop (base.py:192-225) without TensorBoard and without the second-device producer
+        thread: shuffled batches, EMA loss, the best-EMA checkpoint saved under `save_ckpt_path` (`Best`)."""
+        data = vllm_edit_data.data if hasattr(vllm_edit_data, "data") else list(vllm_edit_data)
+        rng = np.random.default_rng(seed)
+        self.set_train(True)
+        if self.opt is None:
+            self.opt = self.get_a_new_optimizer()
+        ema, best, i = 1.0, float("inf"), 1
+        for epoch in range(1, total_epochs + 1):
+            order = rng.permutation(len(data))
+            for b0 in range(0, len(order) - batch_size + 1, batch_size):
+                batch = self.organize_batch_data([data[j] for j in order[b0:b0 + batch_size]])
+                loss, log = self.train_a_batch(batch)
+                ema = ema_alpha * loss + (1 - ema_alpha) * ema
+                if log_fn is not None:
+                    log_fn(i, dict(log, Loss=loss, **{"EMA Loss": ema, "Epoch": epoch}))
+                if ema < best:
+                    best = ema
+                    if save_ckpt_path is not None:
+                        self.save_ckpt(save_ckpt_path, i, epoch, loss, ema)
+                i += 1
+        self.set_train(False)
+        return ema

@@ -81,6 +81,11 @@ def load():
     _sig(L.devqa_mend_normalize_concat, [P, P, P, P, P, P, P, F, I, I, I, P, P])
     _sig(L.devqa_mend_lrlinear_epilogue, [P, P, P, P, P, P, I, I, P])
     _sig(L.devqa_logit_kl_rows, [P, I64, P, I64, I, I, P, P])
+    _sig(L.devqa_kl_dlogits, [P, I64, P, I64, I, I, P, P, P, I64, I, P])
+    _sig(L.devqa_welford_rows, [P, P, I, I, I, P, P, P, P, P, P])
+    _sig(L.devqa_mend_lrlinear_bwd, [P, P, P, P, P, I, I, P, P, P, P, P])
+    _sig(L.devqa_sumsq_f32, [P, I64, P, P])
+    _sig(L.devqa_adam_step, [P, P, P, P, I64, F, F, F, F, I, P, P])
     _lib = L
     return L
 
@@ -93,7 +98,8 @@ EXPORTS = ["devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_ro
            "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk", "devqa_attention_bwd",
            "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_mend_normalize_concat",
-           "devqa_mend_lrlinear_epilogue", "devqa_logit_kl_rows"]
+           "devqa_mend_lrlinear_epilogue", "devqa_logit_kl_rows", "devqa_kl_dlogits", "devqa_welford_rows",
+           "devqa_mend_lrlinear_bwd", "devqa_sumsq_f32", "devqa_adam_step"]
 
 
 def gemm_rows_longk(a, w):
@@ -484,3 +490,46 @@ def logit_kl_rows(l1, l2):
     _chk(load().devqa_logit_kl_rows(_p(l1), l1.stride(0), _p(l2), l2.stride(0), l1.shape[0], l1.shape[1], _p(kl), _stream()),
          "devqa_logit_kl_rows")
     return kl
+
+
+def kl_dlogits(l1, l2, coef, dtype=torch.float32):
+    """-> (kl [R] fp32, dlogits2 [R,V] `dtype`): rows of KL(softmax(l1) || softmax(l2)) and coef * (softmax(l2) - softmax(l1))."""
+    assert l1.dtype == l2.dtype == torch.float32 and l1.shape == l2.shape and l1.stride(1) == 1 and l2.stride(1) == 1
+    _need(coef, torch.float32, "kl_dlogits coef")
+    R, V = l1.shape
+    kl = torch.empty((R,), dtype=torch.float32, device=l1.device)
+    d = torch.empty((R, V), dtype=dtype, device=l1.device)
+    _chk(load().devqa_kl_dlogits(_p(l1), l1.stride(0), _p(l2), l2.stride(0), R, V, _p(coef), _p(kl), _p(d), V,
+                                 int(dtype == torch.bfloat16), _stream()), "devqa_kl_dlogits")
+    return kl, d
+
+
+def welford_rows(x, idx, reset, mean, s, std, k):
+    """In-place update of mean / s / std; returns the NEW sample counter tensor (k itself is left untouched)."""
+    _need(x, torch.float32, "welford_rows x")
+    n = x.shape[0] if idx is None else idx.numel()
+    k_out = torch.empty_like(k)
+    _chk(load().devqa_welford_rows(_p(x), _p(idx), n, x.shape[1], int(bool(reset)), _p(mean), _p(s), _p(std), _p(k), _p(k_out),
+                                   _stream()), "devqa_welford_rows")
+    return k_out
+
+
+def mend_lrlinear_bwd(pre, bias, scale, shift, dout, g_scale, g_shift, g_bias):
+    _need(pre, torch.float32, "mend_lrlinear_bwd pre")
+    _need(dout, torch.float32, "mend_lrlinear_bwd dout")
+    dpre = torch.empty_like(pre)
+    _chk(load().devqa_mend_lrlinear_bwd(_p(pre), _p(bias), _p(scale), _p(shift), _p(dout), pre.shape[0], pre.shape[1], _p(dpre),
+                                        _p(g_scale), _p(g_shift), _p(g_bias), _stream()), "devqa_mend_lrlinear_bwd")
+    return dpre
+
+
+def sumsq_(x, out):
+    _need(x, torch.float32, "sumsq x")
+    _chk(load().devqa_sumsq_f32(_p(x), x.numel(), _p(out), _stream()), "devqa_sumsq_f32")
+
+
+def adam_step_(p, grad, m, v, lr, step, grad_scale=None, beta1=0.9, beta2=0.999, eps=1e-8):
+    for t in (p, grad, m, v):
+        _need(t, torch.float32, "adam_step tensor")
+    _chk(load().devqa_adam_step(_p(p), _p(grad), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                _p(grad_scale), _stream()), "devqa_adam_step")

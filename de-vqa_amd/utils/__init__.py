@@ -83,5 +83,6 @@ def load_vllm_editor(editor_name: str, edit_model_name: str, device, extra_devic
         return IKEvl(vllm, IKEvlConfig.from_yaml(config_path), device, **editor_kwargs)
     if editor_name == "mend_vl":  # editor_ckpt_path: a reference-format `Best` checkpoint of the trained hyper-network
         from ..editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
-        return MENDvl(vllm, MENDvlConfig.from_yaml(config_path), device, ckpt_path=editor_ckpt_path, **editor_kwargs)
+        return MENDvl(vllm, MENDvlConfig.from_yaml(config_path), device, ckpt_path=editor_ckpt_path, for_train=for_train,
+                      **editor_kwargs)
     raise RuntimeError("No such editor %s" % editor_name)

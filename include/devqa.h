@@ -162,6 +162,25 @@ int devqa_mend_lrlinear_epilogue(const float* pre, const float* bias, const floa
 int devqa_logit_kl_rows(const float* logits1, int64_t ld1, const float* logits2, int64_t ld2, int R, int V, float* kl,
                         void* stream);
 
+/* ---- MEND_VL training step (R/editor/vllm_editors/mend_vl/mend_vl.py:301-341) -----------------------------------
+ * kl_dlogits: kl[r] as devqa_logit_kl_rows and dlogits2[r,:] = coef[r] * (softmax(l2[r]) - softmax(l1[r])), the gradient of
+ *   coef-weighted KL(l1 || l2) w.r.t. l2 (autograd of logit_KL_loss, :355-366); dlogits2 bf16 or fp32, row stride ldd.
+ * welford_rows: the running mean / variance update of GradientTransform in training mode, row by row in order
+ *   (auxiliary_networks.py:88-91,122-136); reset != 0 = the `norm_init == False` branch (first row initialises).
+ * mend_lrlinear_bwd: backward of devqa_mend_lrlinear_epilogue for one mode row: dpre [n,D] and += into the scale / shift /
+ *   bias gradients.   sumsq_f32: out[0] += sum x^2 (gradient-norm clipping, :336-337).
+ * adam_step: torch.optim.Adam defaults (no weight decay): grad scaled by grad_scale[0] (the clip coefficient), step >= 1.
+ */
+int devqa_kl_dlogits(const float* logits1, int64_t ld1, const float* logits2, int64_t ld2, int R, int V, const float* coef,
+                     float* kl, void* dlogits2, int64_t ldd, int dlogits_bf16, void* stream);
+int devqa_welford_rows(const float* x, const int32_t* idx, int n_rows, int D, int reset, float* mean, float* s, float* stdv,
+                       const float* k_in, float* k_out, void* stream);   /* k_out != k_in: the sample counter before / after */
+int devqa_mend_lrlinear_bwd(const float* pre, const float* bias, const float* scale, const float* shift, const float* dout,
+                            int n_rows, int D, float* dpre, float* g_scale, float* g_shift, float* g_bias, void* stream);
+int devqa_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
+int devqa_adam_step(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int step, const float* grad_scale, void* stream);
+
 /* ---- K2 patch-embed staging ---------------------------------------------------------------
  * im2col for Conv2d(3->D, k=P, s=P): pixels fp32 [B,3,S,S] -> bf16 [B*(S/P)^2, Kpad] with
  * column (c*P+py)*P+px, zero padded to Kpad (Kpad % 8 == 0).  HF Blip2VisionEmbeddings,

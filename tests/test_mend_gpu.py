@@ -168,3 +168,95 @@ def test_mend_realdim(gold_dir, in_gold_dir, mode):
     assert e < tol["logits"]
     ed.restore_to_original_model()
     assert _rel(logits(), z["pre_logits_lastL"]) < tol["logits"]
+
+
+# ---- training step (train_a_batch) against the reference's MENDvl.train_a_batch (tools/make_goldens_mend.py --train) ----
+TR_TOL = {"fp32": dict(loss=2e-4, grad=3e-3, state=1e-4), "bf16": dict(loss=2e-2, grad=3e-2, state=None)}
+# bf16: the tiny fixture's edit moves the logits by ~10, so element-wise gradients carry bf16 noise; the bar is on each
+# gradient tensor's direction (cosine >= 0.97) and on the total norm (3 %)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_mend_training_steps(gold_dir, in_gold_dir, mode):
+    import devqa_amd  # noqa: F401
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from devqa_amd.editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
+    j = json.load(open(os.path.join(gold_dir, "tiny_mend_train_goldens.json")))
+    z = np.load(os.path.join(gold_dir, "tiny_mend_train_goldens.npz"))
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))["records"]
+    vllm = BLIP2OPTForEdit(os.path.join(gold_dir, "tiny_blip2"), "cuda:0", dtype=mode)
+    cfg = MENDvlConfig.from_yaml(os.path.join(gold_dir, "tiny_mend_cfg.yaml"))
+    cfg.aux_model.lr, cfg.edit_lr_lr = j["aux_lr"], j["edit_lr_lr"]
+    ed = MENDvl(vllm, cfg, "cuda:0", ckpt_path=os.path.join(gold_dir, "tiny_mend_ckpt.pt"))
+    ed.set_train(True)
+    tol = TR_TOL[mode]
+    for si, g in enumerate(j["steps"]):
+        batch = ed.organize_batch_data([deepcopy(rec[g["sample"]])])
+        loss, log = ed.train_a_batch(batch)
+        print(mode, si, "loss %.5f (ref %.5f) grad-norm %.4f (ref %.4f)" % (loss, g["loss"], log["Grad-Norm"], g["log"]["Grad-Norm"]))
+        assert abs(loss - g["loss"]) < tol["loss"] * abs(g["loss"])
+        assert abs(log["Reliability loss"] - g["log"]["Reliability loss"]) < tol["loss"] * 5 * abs(g["log"]["Reliability loss"])
+        for k, v in g["log"]["Locality loss"].items():
+            assert abs(log["Locality loss"][k] - v) < tol["loss"] * 5 * max(abs(v), 1e-2), (k, log["Locality loss"][k], v)
+        for k, v in g["log"]["Generality loss"].items():
+            assert abs(log["Generality loss"][k] - v) < tol["loss"] * 5 * abs(v)
+        assert abs(log["Grad-Norm"] - g["log"]["Grad-Norm"]) < tol["grad"] * g["log"]["Grad-Norm"]
+        worst = 0.0
+        for n, gr in ed.last_grads.items():
+            if n == "edit_lrs":
+                gold = np.array([z["s%d_grad_edit_lrs.%d" % (si, i)] for i in range(len(ed.modules))]).reshape(-1)
+            else:
+                gold = z["s%d_grad_aux_models.%s" % (si, n)]
+            got = gr.cpu().numpy().reshape(gold.shape)
+            e = _rel(got, gold)
+            worst = max(worst, e)
+            if mode == "fp32":
+                assert e < tol["grad"], (si, n, e)
+            elif np.abs(gold).max() > 0:
+                cos = float((got * gold).sum() / (np.linalg.norm(got) * np.linalg.norm(gold) + 1e-30))
+                assert cos > 0.97, (si, n, cos)
+        print(mode, si, "worst gradient rel err %.2e" % worst)
+        if tol["state"] is not None:
+            for n in ed._trainable():
+                gold = z["s%d_state_aux_models.%s" % (si, n)]
+                assert np.abs(ed.aux[n].cpu().numpy() - gold).max() < 2e-5 + tol["state"] * np.abs(gold).max(), (si, n)
+            for i in range(len(ed.modules)):
+                assert abs(float(ed.lr_t[i]) - float(z["s%d_state_edit_lrs.%d" % (si, i)])) < 2e-6
+            for key in ("(40, 80)", "(80, 40)"):
+                for leaf in ("u_mean", "u_std", "v_mean", "v_std", "k"):
+                    gold = z["s%d_state_aux_models.%s.%s" % (si, key, leaf)]
+                    assert _rel(ed.aux["%s.%s" % (key, leaf)].cpu().numpy(), gold) < 1e-3, (si, key, leaf)
+    # checkpoint round trip in the reference's layout
+    path = "/tmp/devqa_mend_best.pt"
+    ed.save_ckpt(path, 2, 1, 0.0, 0.0)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck["train_modules"]) == {"aux_models", "edit_lrs"} and "(40, 80).mlp.layers.0.u" in ck["train_modules"]["aux_models"]
+    ed2 = MENDvl(vllm, cfg, "cuda:0", ckpt_path=path)
+    assert torch.equal(ed2.aux["(40, 80).mlp.layers.1.v"], ed.aux["(40, 80).mlp.layers.1.v"])
+
+
+def test_mend_train_from_scratch_then_edit(gold_dir, in_gold_dir, tmp_path):
+    """The training loop from the reference's fresh state (u = 0, NaN normalisation buffers): finite losses, the
+    statistics become finite after the first step, the Best checkpoint reloads and edits."""
+    import devqa_amd  # noqa: F401
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from devqa_amd.editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))["records"]
+    vllm = BLIP2OPTForEdit(os.path.join(gold_dir, "tiny_blip2"), "cuda:0", dtype="fp32")
+    cfg = MENDvlConfig.from_yaml(os.path.join(gold_dir, "tiny_mend_cfg.yaml"))
+    cfg.aux_model.lr, cfg.init_edit_lr = 1e-3, 1e-3
+    ed = MENDvl(vllm, cfg, "cuda:0", for_train=True)
+    with pytest.raises(RuntimeError):
+        ed.edit_one_piece(deepcopy(rec[0]["requests"][0]))       # untrained: NaN buffers (auxiliary_networks.py:99-105)
+    logs = []
+    best = str(tmp_path / "Best")
+    ema = ed.train([deepcopy(r) for r in rec[:3]], total_epochs=2, batch_size=1, save_ckpt_path=best, seed=3,
+                   log_fn=lambda i, d: logs.append(d["Loss"]))
+    assert len(logs) == 6 and all(np.isfinite(l) for l in logs) and np.isfinite(ema)
+    for key in ("(40, 80)", "(80, 40)"):
+        assert bool(torch.isfinite(ed.aux[key + ".u_std"]).all()) and float(ed.aux[key + ".k"]) > 2
+    assert float(ed.aux["(40, 80).mlp.layers.0.u"].abs().max()) > 0        # u left its zero init
+    ed2 = MENDvl(vllm, cfg, "cuda:0", ckpt_path=best)
+    ed2.edit_one_piece(deepcopy(rec[0]["requests"][0]))
+    assert ed2.delta_weight(ed2.modules[0]["name"]) is not None
+    ed2.restore_to_original_model()

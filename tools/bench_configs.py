@@ -121,6 +121,37 @@ def blip2_mend(n=4):
                       "s_per_cycle": round(dt / n, 3), "edit_time_s": res[0][0]["reliability"][0].get("edit_time")}))
 
 
+def blip2_mend_train(n=6):
+    """One MEND_VL training step (train_a_batch) per sample at full BLIP-2-OPT-2.7B dims, hyper-network 12800 -> 1920."""
+    from transformers import AutoTokenizer
+    from devqa_amd import blip2_spec
+    from devqa_amd.editor.vllms_for_edit.blip2.modeling import Blip2Native
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from devqa_amd.editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
+    t0 = time.time()
+    model = Blip2Native(blip2_spec.BLIP2_OPT_2_7B, DEV, "bf16")
+    fill(model, 20251121, "opt")
+    tok = AutoTokenizer.from_pretrained(os.path.join(GOLD, "tiny_blip2"))
+    vllm = BLIP2OPTForEdit(None, DEV, model=model, tokenizer=tok)
+    cfg = MENDvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "mend_vl", "blip2-opt-2.7b.yaml"))
+    ed = MENDvl(vllm, cfg, DEV, for_train=True)
+    ed.set_train(True)
+    print("build %.1fs" % (time.time() - t0), flush=True)
+    os.chdir(GOLD)
+    recs = records(n + 1)
+    losses = []
+    loss, _ = ed.train_a_batch(ed.organize_batch_data([recs[0]]))      # warm-up
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for r in recs[1:]:
+        loss, log = ed.train_a_batch(ed.organize_batch_data([r]))
+        losses.append(round(loss, 4))
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / n
+    print(json.dumps({"config": "BLIP-2-OPT-2.7B + MEND_VL train_a_batch (B = 1: 1 edit + 12 post-edit probes + 9 pre-edit)",
+                      "s_per_step": round(dt, 4), "steps_per_s": round(1 / dt, 2), "losses": losses, "grad_norm_last": log["Grad-Norm"]}))
+
+
 def _hash_encode(sentences, dim=384):
     out = np.zeros((len(sentences), dim), np.float32)
     for i, s in enumerate(sentences):
@@ -150,4 +181,4 @@ def minigpt4_ike(n=4):
 
 
 if __name__ == "__main__":
-    {"llava_ft": llava_ft, "blip2_mend": blip2_mend, "minigpt4_ike": minigpt4_ike}[sys.argv[1]](*[int(a) for a in sys.argv[2:]])
+    {"llava_ft": llava_ft, "blip2_mend": blip2_mend, "minigpt4_ike": minigpt4_ike, "blip2_mend_train": blip2_mend_train}[sys.argv[1]](*[int(a) for a in sys.argv[2:]])
