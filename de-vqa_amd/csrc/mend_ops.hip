@@ -307,3 +307,114 @@ extern "C" int devqa_adam_step(float* p, const float* grad, float* m, float* v, 
     DEVQA_LAUNCH_CHECK("adam_step");
     return DEVQA_OK;
 }
+
+// ---- TP_VL (T-Patcher) patch-neuron step (R/editor/vllm_editors/tp_vl/tp_vl.py:155-192) ------------------------------------
+// One new FFN neuron (key k [d], bias b, value v [d_out]) on frozen activations.  forward: pre[t] = h[t].k + b for the rows
+// of the "edit-role" sequence, y[r] = ybase[r] + relu(pre[lab[r]]) * v for its label rows.  backward (one workgroup):
+//   loss_a = mean_t exp(-pre[t]);  loss_m = mean_t exp(pm[t] * (pm[t] > 0)),  pm = hm.k + b  (memory text)
+//   dpre[t]  = -la * exp(-pre[t]) / T   (+ (dy[r].v) * (pre[t] > 0) on label rows);   dpm[t] = lm * exp(pm[t]) * (pm[t] > 0) / Tm
+//   gk = h^T dpre + hm^T dpm + wd k;  gb = sum dpre + sum dpm + wd b;  gv = sum_r relu(pre[lab[r]]) dy[r] + wd v
+__global__ __launch_bounds__(256) void tp_neuron_fwd_kernel(const float* __restrict__ h, int T, int d, const float* __restrict__ k,
+                                                            const float* __restrict__ b, const int32_t* __restrict__ lab, int L,
+                                                            const float* __restrict__ v, const float* __restrict__ ybase, int d_out,
+                                                            float* __restrict__ pre, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < T; t += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < d; c += 64) acc += h[(int64_t)t * d + c] * k[c];
+        acc = wave_sum(acc);
+        if (lane == 0) pre[t] = acc + b[0];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * d_out; i += 256) {
+        const int r = i / d_out, c = i - r * d_out;
+        y[i] = ybase[i] + fmaxf(pre[lab[r]], 0.f) * v[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void tp_neuron_bwd_kernel(const float* __restrict__ h, const float* __restrict__ pre, int T, int d,
+                                                            const int32_t* __restrict__ lab, int L, const float* __restrict__ dy,
+                                                            int d_out, const float* __restrict__ hm, int Tm, const float* __restrict__ k,
+                                                            const float* __restrict__ b, const float* __restrict__ v, float la, float lm,
+                                                            float wd, float* __restrict__ scratch, float* __restrict__ gk,
+                                                            float* __restrict__ gb, float* __restrict__ gv, float* __restrict__ losses) {
+    // scratch: [T + Tm] fp32 (dpre | dpm)
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* dpre = scratch;
+    float* dpm = scratch + T;
+    float la_acc = 0.f, lm_acc = 0.f;
+    for (int t = tid; t < T; t += 256) {
+        const float e = expf(-pre[t]);
+        la_acc += e;
+        dpre[t] = -la * e / (float)T;
+    }
+    for (int t = wave; t < Tm; t += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < d; c += 64) acc += hm[(int64_t)t * d + c] * k[c];
+        acc = wave_sum(acc) + b[0];
+        if (lane == 0) {
+            const float e = expf(acc > 0.f ? acc : 0.f);
+            dpm[t] = acc > 0.f ? lm * e / (float)Tm : 0.f;
+            lm_acc += e;
+        }
+    }
+    __syncthreads();
+    for (int r = wave; r < L; r += 4) {     // label rows: dpre += (dy[r] . v) * (pre > 0)
+        float acc = 0.f;
+        for (int c = lane; c < d_out; c += 64) acc += dy[(int64_t)r * d_out + c] * v[c];
+        acc = wave_sum(acc);
+        if (lane == 0 && pre[lab[r]] > 0.f) atomicAdd(&dpre[lab[r]], acc);
+    }
+    la_acc = wave_sum(la_acc);
+    lm_acc = wave_sum(lm_acc);
+    if (lane == 0) red[wave] = la_acc;
+    __syncthreads();
+    const float la_tot = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    if (lane == 0) red[wave] = lm_acc;
+    __syncthreads();
+    const float lm_tot = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) {
+        losses[0] = la_tot / (float)T;
+        losses[1] = lm_tot / (float)Tm;
+    }
+    __syncthreads();
+    for (int c = tid; c < d; c += 256) {
+        float acc = wd * k[c];
+        for (int t = 0; t < T; ++t) acc += h[(int64_t)t * d + c] * dpre[t];
+        for (int t = 0; t < Tm; ++t) acc += hm[(int64_t)t * d + c] * dpm[t];
+        gk[c] = acc;
+    }
+    for (int c = tid; c < d_out; c += 256) {
+        float acc = wd * v[c];
+        for (int r = 0; r < L; ++r) acc += fmaxf(pre[lab[r]], 0.f) * dy[(int64_t)r * d_out + c];
+        gv[c] = acc;
+    }
+    if (tid == 0) {
+        float acc = wd * b[0];
+        for (int t = 0; t < T; ++t) acc += dpre[t];
+        for (int t = 0; t < Tm; ++t) acc += dpm[t];
+        gb[0] = acc;
+    }
+}
+
+extern "C" int devqa_tp_neuron_fwd(const float* h, int T, int d, const float* k, const float* b, const int32_t* lab, int L,
+                                   const float* v, const float* ybase, int d_out, float* pre, float* y, void* stream) {
+    DEVQA_CHECK_ARG(h && k && b && lab && v && ybase && pre && y && T > 0 && d > 0 && L > 0 && d_out > 0, "tp_neuron_fwd: bad arguments");
+    hipLaunchKernelGGL(tp_neuron_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, h, T, d, k, b, lab, L, v, ybase, d_out, pre, y);
+    DEVQA_LAUNCH_CHECK("tp_neuron_fwd");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_tp_neuron_bwd(const float* h, const float* pre, int T, int d, const int32_t* lab, int L, const float* dy, int d_out,
+                                   const float* hm, int Tm, const float* k, const float* b, const float* v, float lambda_a,
+                                   float lambda_m, float weight_decay, float* scratch, float* gk, float* gb, float* gv, float* losses,
+                                   void* stream) {
+    DEVQA_CHECK_ARG(h && pre && lab && dy && hm && k && b && v && scratch && gk && gb && gv && losses && T > 0 && Tm > 0 && L > 0,
+                    "tp_neuron_bwd: bad arguments");
+    hipLaunchKernelGGL(tp_neuron_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, h, pre, T, d, lab, L, dy, d_out, hm, Tm, k, b, v,
+                       lambda_a, lambda_m, weight_decay, scratch, gk, gb, gv, losses);
+    DEVQA_LAUNCH_CHECK("tp_neuron_bwd");
+    return DEVQA_OK;
+}

@@ -264,7 +264,7 @@ class Blip2Engine:
     # stop_before_fc2, the last processed layer stops at the fc2 input: returns (x_mid, a_bf16).
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def decoder_layers(self, ps: PackedSeqs, upto_layer=None, stop_before_fc2=False, save=None):
+    def decoder_layers(self, ps: PackedSeqs, upto_layer=None, stop_before_fc2=False, save=None, return_h=False):
         """save: None, or {"layers": set of layer ids}; filled with save[i] = activations the backward of layer i needs
         (decoder_backward).  Low-rank module deltas registered in self.module_deltas (MEND_VL's forward_edit_hook,
         mend_vl.py:73-80) are applied to the fc1 / fc2 outputs."""
@@ -298,12 +298,22 @@ class Blip2Engine:
             if rec is not None:
                 rec["a"] = a
             if stop_before_fc2 and i == last:
-                return x, a
+                return (x, a, h) if return_h else (x, a)
             lib.gemm(a, self._w(p + "fc2.weight"), self._p(p + "fc2.bias"), residual=x, out_f32=x)
             d2 = deltas.get(p + "fc2")
             if d2 is not None:
                 lib.gemm(lib.gemm(a, d2["xt"]), d2["dtT"], residual=x, out_f32=x)
+            self.add_extra_neurons(i, h, x)
         return x, None
+
+    def add_extra_neurons(self, layer, h, x):
+        """x += relu(h K^T + B) V for the patch neurons appended to `layer`'s FFN (TP_VL, tp_vl.py:74-103): the hooks
+        concatenate the extra pre-activations with fc1's output, the layer's ReLU acts on all of them and fc2's hooks add
+        extra_act @ extra_values.  self.extra_neurons[layer] = {"K": [n_pad, d] , "B": fp32 [n_pad], "VT": [d, n_pad]}
+        (operand dtype, zero-padded neurons contribute relu(0) * 0)."""
+        ent = (getattr(self, "extra_neurons", None) or {}).get(layer)
+        if ent is not None:
+            lib.gemm(lib.gemm(h, ent["K"], ent["B"], act=lib.ACT_RELU), ent["VT"], residual=x, out_f32=x)
 
     def _wt(self, key, getter):
         """Transposed GEMM operand W^T [in, out] (contiguous) of a frozen weight, cached: dX = dY . W runs on the TN

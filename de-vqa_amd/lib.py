@@ -86,6 +86,8 @@ def load():
     _sig(L.devqa_mend_lrlinear_bwd, [P, P, P, P, P, I, I, P, P, P, P, P])
     _sig(L.devqa_sumsq_f32, [P, I64, P, P])
     _sig(L.devqa_adam_step, [P, P, P, P, I64, F, F, F, F, I, P, P])
+    _sig(L.devqa_tp_neuron_fwd, [P, I, I, P, P, P, I, P, P, I, P, P, P])
+    _sig(L.devqa_tp_neuron_bwd, [P, P, I, I, P, I, P, I, P, I, P, P, P, F, F, F, P, P, P, P, P, P])
     _lib = L
     return L
 
@@ -99,7 +101,7 @@ EXPORTS = ["devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_ro
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk", "devqa_attention_bwd",
            "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_mend_normalize_concat",
            "devqa_mend_lrlinear_epilogue", "devqa_logit_kl_rows", "devqa_kl_dlogits", "devqa_welford_rows",
-           "devqa_mend_lrlinear_bwd", "devqa_sumsq_f32", "devqa_adam_step"]
+           "devqa_mend_lrlinear_bwd", "devqa_sumsq_f32", "devqa_adam_step", "devqa_tp_neuron_fwd", "devqa_tp_neuron_bwd"]
 
 
 def gemm_rows_longk(a, w):
@@ -533,3 +535,30 @@ def adam_step_(p, grad, m, v, lr, step, grad_scale=None, beta1=0.9, beta2=0.999,
         _need(t, torch.float32, "adam_step tensor")
     _chk(load().devqa_adam_step(_p(p), _p(grad), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step),
                                 _p(grad_scale), _stream()), "devqa_adam_step")
+
+
+def tp_neuron_fwd(h, k, b, lab, v, ybase):
+    for t in (h, k, b, v, ybase):
+        _need(t, torch.float32, "tp_neuron_fwd tensor")
+    T, d = h.shape
+    L, d_out = ybase.shape
+    pre = torch.empty((T,), dtype=torch.float32, device=h.device)
+    y = torch.empty_like(ybase)
+    _chk(load().devqa_tp_neuron_fwd(_p(h), T, d, _p(k), _p(b), _p(lab), L, _p(v), _p(ybase), d_out, _p(pre), _p(y), _stream()),
+         "devqa_tp_neuron_fwd")
+    return pre, y
+
+
+def tp_neuron_bwd(h, pre, lab, dy, hm, k, b, v, lambda_a, lambda_m, weight_decay):
+    for t in (h, pre, dy, hm, k, b, v):
+        _need(t, torch.float32, "tp_neuron_bwd tensor")
+    T, d = h.shape
+    L, d_out = dy.shape
+    Tm = hm.shape[0]
+    scratch = torch.empty((T + Tm,), dtype=torch.float32, device=h.device)
+    gk, gb, gv = torch.empty_like(k), torch.empty_like(b), torch.empty_like(v)
+    losses = torch.empty((2,), dtype=torch.float32, device=h.device)
+    _chk(load().devqa_tp_neuron_bwd(_p(h), _p(pre), T, d, _p(lab), L, _p(dy), d_out, _p(hm), Tm, _p(k), _p(b), _p(v), float(lambda_a),
+                                    float(lambda_m), float(weight_decay), _p(scratch), _p(gk), _p(gb), _p(gv), _p(losses), _stream()),
+         "devqa_tp_neuron_bwd")
+    return gk, gb, gv, losses

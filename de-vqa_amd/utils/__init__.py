@@ -85,4 +85,7 @@ def load_vllm_editor(editor_name: str, edit_model_name: str, device, extra_devic
         from ..editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
         return MENDvl(vllm, MENDvlConfig.from_yaml(config_path), device, ckpt_path=editor_ckpt_path, for_train=for_train,
                       **editor_kwargs)
+    if editor_name == "tp_vl":   # needs locality_texts=[...] or locality_data_path=<text file> (the reference reads wikitext)
+        from ..editor.vllm_editors.tp_vl.tp_vl import TPvl, TPvlConfig
+        return TPvl(vllm, TPvlConfig.from_yaml(config_path), device, **editor_kwargs)
     raise RuntimeError("No such editor %s" % editor_name)

@@ -181,6 +181,20 @@ int devqa_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
 int devqa_adam_step(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int step, const float* grad_scale, void* stream);
 
+/* ---- TP_VL (T-Patcher) patch-neuron step (R/editor/vllm_editors/tp_vl/tp_vl.py:155-192) --------------------------------
+ * One new FFN neuron (key k [d], bias b [1], value v [d_out]) trained on FROZEN activations of the edited layer.
+ * tp_neuron_fwd: pre[t] = h[t].k + b for the T rows of the edit-role sequence; y[r] = ybase[r] + relu(pre[lab[r]]) * v for
+ *   its L label rows (ybase = the layer's output rows without the new neuron).
+ * tp_neuron_bwd: given dy = dLoss_e/dy [L,d_out] and the memory text's rows hm [Tm,d]: gradients gk, gb, gv of
+ *   loss_e + lambda_a * mean_t exp(-pre[t]) + lambda_m * mean_t exp(pm[t] * (pm[t] > 0)) (+ weight_decay * p, Adam's L2),
+ *   losses[0..1] = (loss_a, loss_m).  scratch: fp32 [T + Tm].  All fp32; one workgroup (T, Tm are tens of rows).
+ */
+int devqa_tp_neuron_fwd(const float* h, int T, int d, const float* k, const float* b, const int32_t* lab, int L, const float* v,
+                        const float* ybase, int d_out, float* pre, float* y, void* stream);
+int devqa_tp_neuron_bwd(const float* h, const float* pre, int T, int d, const int32_t* lab, int L, const float* dy, int d_out,
+                        const float* hm, int Tm, const float* k, const float* b, const float* v, float lambda_a, float lambda_m,
+                        float weight_decay, float* scratch, float* gk, float* gb, float* gv, float* losses, void* stream);
+
 /* ---- K2 patch-embed staging ---------------------------------------------------------------
  * im2col for Conv2d(3->D, k=P, s=P): pixels fp32 [B,3,S,S] -> bf16 [B*(S/P)^2, Kpad] with
  * column (c*P+py)*P+px, zero padded to Kpad (Kpad % 8 == 0).  HF Blip2VisionEmbeddings,
