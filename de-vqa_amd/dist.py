@@ -57,3 +57,28 @@ def gather_results(local_results, local_rows, n_total, rank, world, device):
         assert int(rows[i, 0]) == i
         assert abs(float(rows[i, 1]) - r["reliability"][0]["acc"]) < 1e-6
     return allres
+
+
+def gather_results_ragged(local_results, local_rows, rank, world, device):
+    """As gather_results, for blocks whose sizes are not the shard_range partition of a known total (the generic
+    evaluator shards SPLITS, which may hold several samples each): sizes are exchanged first."""
+    n_local = torch.tensor([len(local_results)], dtype=torch.int64, device=device)
+    sizes_t = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes_t, n_local)
+    sizes = [int(t.item()) for t in sizes_t]
+    mx = max(max(sizes), 1)
+    buf = torch.zeros((mx, 16), dtype=torch.float32, device=device)
+    if len(local_rows):
+        buf[:len(local_rows)] = torch.from_numpy(np.asarray(local_rows, np.float32)).to(device)
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    objs = [None] * world if rank == 0 else None
+    dist.gather_object(local_results, objs, dst=0)
+    if rank != 0:
+        return None
+    rows = np.concatenate([o[:s].cpu().numpy() for o, s in zip(outs, sizes)], 0)
+    allres = [r for part in objs for r in part]
+    assert len(allres) == len(rows)
+    for i, r in enumerate(allres):
+        assert int(rows[i, 0]) == i and abs(float(rows[i, 1]) - r["reliability"][0]["acc"]) < 1e-6
+    return allres

@@ -224,6 +224,37 @@ class VLLMEditorEvaluation:
         return results
 
     def _sequential_generic(self, editor, result_data, eval_data):
+        """The reference's call sequence per split.  Splits are independent (every split starts from restored weights,
+        vllm_editor_eval.py:98,122), so under torch.distributed rank r runs the contiguous block of splits
+        [r*S/W, (r+1)*S/W) and rank 0 gathers: one collective of fixed-width score rows + a host gather of the result
+        dicts; other ranks return None."""
+        import torch.distributed as dist
+        from ..batched import BatchedEditEval, shard_range
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        n_splits = len(eval_data)
+        lo, hi = shard_range(n_splits, rank, world)
+        local = self._run_splits(editor, result_data[lo:hi], eval_data[lo:hi])
+        if world == 1:
+            return local
+        # the gather helpers move one row / one dict per SAMPLE: flatten the splits, regroup on rank 0
+        sizes = [len(sp) for sp in result_data]
+        first = sum(sizes[:lo])
+        flat = [r for sp in local for r in sp]
+        rows = BatchedEditEval.score_rows(flat, [(0, 0.0)] * len(flat), first)
+        from ..dist import gather_results_ragged
+        dev = torch.device(editor.device if isinstance(editor.device, str) else "cuda:%d" % editor.device) \
+            if dist.get_backend() == "nccl" else torch.device("cpu")
+        allres = gather_results_ragged(flat, rows, rank, world, dev)
+        if allres is None:
+            return None
+        out, i = [], 0
+        for sz in sizes:
+            out.append(allres[i:i + sz])
+            i += sz
+        return out
+
+    def _run_splits(self, editor, result_data, eval_data):
         tok = editor.vllm.get_llm_tokenizer()
         bp = self._can_batch_probes(editor) and os.environ.get("DEVQA_PROBE_BATCH", "1") != "0"
         editor.restore_to_original_model()

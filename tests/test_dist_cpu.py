@@ -64,3 +64,51 @@ def test_shard_range_partitions():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_generic(rank, world, sizes, port, q):
+    """The generic evaluator's split sharding: fake per-split results, real shard / gather / regroup code."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import devqa_amd  # noqa: F401
+    from devqa_amd.dist import init_from_env
+    from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation
+    init_from_env("gloo")
+    ids, splits = 0, []
+    for sz in sizes:
+        splits.append(list(range(ids, ids + sz)))
+        ids += sz
+
+    class Ed:
+        device = "cpu"
+
+        def name_of_editor_and_model(self):
+            return "fake", "fake"
+    ev = VLLMEditorEvaluation.__new__(VLLMEditorEvaluation)
+    ev._run_splits = lambda editor, rd, ed: [[_fake_result(i) for i in sp] for sp in rd]
+    out = ev._sequential_generic(Ed(), splits, splits)
+    if rank == 0:
+        q.put([[r["reliability"][0]["predict_after_edit"] for r in sp] for sp in out])
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes", [[2, 2, 3, 2, 2], [1], [2, 2]])
+def test_generic_evaluator_shards_splits_world2(sizes):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + len(sizes)) % 2000
+    procs = [ctx.Process(target=_worker_generic, args=(r, 2, sizes, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    want, i = [], 0
+    for sz in sizes:
+        want.append(["r%d" % j for j in range(i, i + sz)])
+        i += sz
+    assert out == want
