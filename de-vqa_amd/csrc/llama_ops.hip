@@ -194,3 +194,37 @@ extern "C" int devqa_swiglu_bf16(const devqa_bf16* gu, int R, int F, devqa_bf16*
 extern "C" int devqa_swiglu_f32(const float* gu, int R, int F, float* out, void* stream) {
     return launch_swiglu<float>(gu, R, F, out, stream);
 }
+
+// backward of a = silu(g) * u for the explicit backward of the MEND_VL edit path through LLaMA FFNs
+// (R/editor/vllm_editors/mend_vl/mend_vl.py:177-186 reaches it through autograd):
+//   dg = da * u * sig(g) * (1 + g * (1 - sig(g))),  du = da * silu(g);  gu [R, 2F] (gate | up) in T, da / dgu fp32
+template <typename T>
+__global__ void swiglu_bwd_kernel(const T* __restrict__ gu, const float* __restrict__ da, int R, int F, float* __restrict__ dgu) {
+    const int64_t total = (int64_t)R * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % F);
+        const int64_t r = i / F;
+        const float g = ldf(gu + r * 2 * F + j), u = ldf(gu + r * 2 * F + F + j);
+        const float sg = 1.f / (1.f + expf(-g));
+        const float d = da[i];
+        dgu[r * 2 * F + j] = d * u * sg * (1.f + g * (1.f - sg));
+        dgu[r * 2 * F + F + j] = d * g * sg;
+    }
+}
+
+template <typename T>
+static int launch_swiglu_bwd(const T* gu, const float* da, int R, int F, float* dgu, void* stream) {
+    DEVQA_CHECK_ARG(gu && da && dgu, "swiglu_bwd: null pointer");
+    DEVQA_CHECK_SHAPE(R > 0 && F > 0, "swiglu_bwd: bad dims");
+    const int64_t total = (int64_t)R * F;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144);
+    hipLaunchKernelGGL(swiglu_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gu, da, R, F, dgu);
+    DEVQA_LAUNCH_CHECK("swiglu_bwd");
+    return DEVQA_OK;
+}
+extern "C" int devqa_swiglu_bwd_bf16(const devqa_bf16* gu, const float* da, int R, int F, float* dgu, void* stream) {
+    return launch_swiglu_bwd<bf16_t>(gu, da, R, F, dgu, stream);
+}
+extern "C" int devqa_swiglu_bwd_f32(const float* gu, const float* da, int R, int F, float* dgu, void* stream) {
+    return launch_swiglu_bwd<float>(gu, da, R, F, dgu, stream);
+}

@@ -66,7 +66,6 @@ class MENDvlConfig(BaseConfig):
         raise
 
 
-_MOD_RE = re.compile(r"^(.*\.layers\.)(\d+)\.(fc1|fc2)$")
 
 
 class MENDvl(VLLMBaseEditor):
@@ -81,10 +80,11 @@ class MENDvl(VLLMBaseEditor):
         # same-shape modules share a GradientTransform; edit_modules order = group by group (mend_vl.py:200-223)
         groups = OrderedDict()
         self.layers = set()
+        mod_re = re.compile(eng.MEND_MODULE_RE)
         for name in config.edit_modules:
-            m = _MOD_RE.match(name)
+            m = mod_re.match(name)
             if m is None:
-                raise NotImplementedError("native MEND_VL edits decoder fc1/fc2 modules; got %s" % name)
+                raise NotImplementedError("native MEND_VL edits the decoder's FFN projections (%s); got %s" % (eng.MEND_MODULE_RE, name))
             self.layers.add(int(m.group(2)))
             out_dim, in_dim = self.vllm.model.get(name + ".weight").shape
             groups.setdefault((in_dim, out_dim), []).append(name)
@@ -105,7 +105,7 @@ class MENDvl(VLLMBaseEditor):
             self.load_train_modules(train_modules)
         elif for_train:
             self.reinit_train_parameters()
-        eng.module_deltas = {}
+        eng.set_module_deltas({})
 
     # ---- trained state ------------------------------------------------------------------------------------------
     def load_ckpt(self, ckpt_path, restrict=True, load_opt=False):
@@ -138,7 +138,7 @@ class MENDvl(VLLMBaseEditor):
     def restore_to_original_model(self):
         for m in self.modules:
             m["X"], m["D"], m["n"] = [], [], 0
-        self.vllm.engine.module_deltas = {}
+        self.vllm.engine.set_module_deltas({})
 
     def edit_one_piece(self, request: Dict):
         self.edit_batch([request])
@@ -244,11 +244,8 @@ class MENDvl(VLLMBaseEditor):
             Dp = torch.zeros((npad, D.shape[1]), dtype=torch.float32, device=self.dev)
             Xp[:n], Dp[:n] = X, D
             op = (lambda t: lib.cast_f32_bf16(t.contiguous())) if eng.adt == torch.bfloat16 else (lambda t: t.contiguous())
-            ent = {"xt": op(Xp), "xtT": op(Xp.t()), "dt": op(Dp), "dtT": op(Dp.t())}
-            if m["name"].endswith("fc1"):
-                ent["w_cat"] = torch.cat([self.vllm.model.weight_for_gemm(m["name"] + ".weight"), ent["dtT"]], 1).contiguous()
-            deltas[m["name"]] = ent
-        eng.module_deltas = deltas
+            deltas[m["name"]] = {"xt": op(Xp), "xtT": op(Xp.t()), "dt": op(Dp), "dtT": op(Dp.t())}
+        eng.set_module_deltas(deltas)
 
     def delta_weight(self, name):
         """fp32 [d_in, d_out] delta weight of one edited module (the reference's __delta_weight__), for inspection."""

@@ -315,6 +315,16 @@ class Blip2Engine:
         if ent is not None:
             lib.gemm(lib.gemm(h, ent["K"], ent["B"], act=lib.ACT_RELU), ent["VT"], residual=x, out_f32=x)
 
+    MEND_MODULE_RE = r"^(.*\.layers\.)(\d+)\.(fc1|fc2)$"
+
+    def set_module_deltas(self, deltas):
+        """deltas: {module name: {"xt" [n_pad, d_in], "xtT", "dt" [n_pad, d_out] (scaled), "dtT"}} in the operand dtype;
+        fc1 entries get the concatenated-K weight [W1 | dt^T] the forward uses."""
+        for name, e in deltas.items():
+            if name.endswith("fc1"):
+                e["w_cat"] = torch.cat([self._w(name + ".weight"), e["dtT"]], 1).contiguous()
+        self.module_deltas = deltas
+
     def _wt(self, key, getter):
         """Transposed GEMM operand W^T [in, out] (contiguous) of a frozen weight, cached: dX = dY . W runs on the TN
         kernels as gemm(dY, W^T)."""

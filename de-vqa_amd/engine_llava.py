@@ -179,15 +179,21 @@ class LlavaEngine:
 
     # ---- LLaMA decoder layers -----------------------------------------------------------------------------------
     @torch.no_grad()
-    def decoder_layers(self, ps, upto_layer=None, stop_before_fc2=False):
+    def decoder_layers(self, ps, upto_layer=None, stop_before_fc2=False, save=None):
+        """save: None, or {"layers": set of layer ids}: filled with the activations decoder_backward needs.  Low-rank module
+        deltas (set_module_deltas; MEND_VL's forward_edit_hook, mend_vl.py:73-80) are applied to gate / up / down outputs."""
         t, m = self.t, self.m
         d, H = t["hidden_size"], t["num_attention_heads"]
         dh = d // H
         x = ps.x
         n_seq = ps.desc.shape[0]
         last = t["num_hidden_layers"] - 1 if upto_layer is None else upto_layer
+        deltas = getattr(self, "module_deltas", None) or {}
         for i in range(last + 1):
             p = self.lm + "model.layers.%d." % i
+            rec = None
+            if save is not None and i in save["layers"]:
+                rec = save[i] = {"x_in": x.clone()}
             h = lib.rmsnorm(x, self._p(p + "input_layernorm.weight"), self.eps, want=self.want)
             qkv = lib.gemm(h, m.fused_w["llama_qkv.%d" % i])
             lib.rope_(qkv[:, :2 * d], ps.pos, 2 * H, dh, self.theta)          # q heads then k heads
@@ -195,12 +201,90 @@ class LlavaEngine:
                                 out=torch.zeros((x.shape[0], d), dtype=self.adt, device=self.dev))
             lib.gemm(att, self._w(p + "self_attn.o_proj.weight"), residual=x, out_f32=x)
             h = lib.rmsnorm(x, self._p(p + "post_attention_layernorm.weight"), self.eps, want=self.want)
-            gu = lib.gemm(h, m.fused_w["llama_gu.%d" % i])
+            dg, du = deltas.get(p + "mlp.gate_proj"), deltas.get(p + "mlp.up_proj")
+            if dg is None and du is None:
+                gu = lib.gemm(h, m.fused_w["llama_gu.%d" % i])
+            else:   # [h | h xt_g^T | h xt_u^T] . [W_gu | dt_g (gate rows) | dt_u (up rows)]^T: one GEMM over the concatenated K
+                parts = [h] + [lib.gemm(h, e["xt"]) for e in (dg, du) if e is not None]
+                gu = lib.gemm(torch.cat(parts, 1), self._gu_cat[i])
             a = lib.swiglu(gu)
+            if rec is not None:
+                rec.update(qkv=qkv, att=att, x_mid=x.clone(), h2=h, gu=gu, a=a)
             if stop_before_fc2 and i == last:
                 return x, a
             lib.gemm(a, self._w(p + "mlp.down_proj.weight"), residual=x, out_f32=x)
+            dd = deltas.get(p + "mlp.down_proj")
+            if dd is not None:
+                lib.gemm(lib.gemm(a, dd["xt"]), dd["dtT"], residual=x, out_f32=x)
         return x, None
+
+    # ---- MEND_VL support: module kinds, delta installation, explicit backward ---------------------------------------------
+    MEND_MODULE_RE = r"^(.*\.layers\.)(\d+)\.mlp\.(gate_proj|up_proj|down_proj)$"
+
+    def set_module_deltas(self, deltas):
+        """deltas: {module name: {"xt" [n_pad, d_in], "xtT", "dt" [n_pad, d_out] (scaled), "dtT"}} in the operand dtype."""
+        self.module_deltas = deltas
+        self._gu_cat = {}
+        F = self.t["intermediate_size"]
+        for i in {int(n.split(".layers.")[1].split(".")[0]) for n in deltas if n.endswith("gate_proj") or n.endswith("up_proj")}:
+            p = self.lm + "model.layers.%d." % i
+            cols = [self.m.fused_w["llama_gu.%d" % i]]
+            for kind, top in (("gate_proj", True), ("up_proj", False)):
+                e = deltas.get(p + "mlp." + kind)
+                if e is not None:
+                    z = torch.zeros_like(e["dtT"])
+                    cols.append(torch.cat([e["dtT"], z] if top else [z, e["dtT"]], 0))    # [2F, n_pad]
+            self._gu_cat[i] = torch.cat(cols, 1).contiguous()
+
+    def _wt(self, key, getter):
+        c = self.__dict__.setdefault("_wt_cache", {})
+        if key not in c:
+            c[key] = getter().t().contiguous()
+        return c[key]
+
+    @torch.no_grad()
+    def decoder_backward(self, ps, save, dx, capture):
+        """Backward through the saved LLaMA layers (highest first); see Blip2Engine.decoder_backward.  Captures (input rows,
+        output-gradient rows) of the gate / up / down projections named in `capture`."""
+        t, m = self.t, self.m
+        d, H, F = t["hidden_size"], t["num_attention_heads"], t["intermediate_size"]
+        dh = d // H
+        n_seq = ps.desc.shape[0]
+        deltas = getattr(self, "module_deltas", None) or {}
+        neg_pos = (-ps.pos).contiguous()
+        out = {}
+        for i in sorted(save["layers"], reverse=True):
+            p = self.lm + "model.layers.%d." % i
+            rec = save[i]
+            dz = self._act(dx)
+            if p + "mlp.down_proj" in capture:
+                out[p + "mlp.down_proj"] = (rec["a"], dx.clone())
+            da = lib.gemm(dz, self._wt(p + "down", lambda: self._w(p + "mlp.down_proj.weight")), want="f32")
+            dd = deltas.get(p + "mlp.down_proj")
+            if dd is not None:
+                lib.gemm(lib.gemm(dz, dd["dt"]), dd["xtT"], residual=da, out_f32=da)
+            dgu = lib.swiglu_bwd(rec["gu"], da)                      # fp32 [R, 2F]
+            dgate, dup = dgu[:, :F].contiguous(), dgu[:, F:].contiguous()
+            if p + "mlp.gate_proj" in capture:
+                out[p + "mlp.gate_proj"] = (rec["h2"], dgate)
+            if p + "mlp.up_proj" in capture:
+                out[p + "mlp.up_proj"] = (rec["h2"], dup)
+            dh2 = lib.gemm(self._act(dgu), self._wt(p + "gu", lambda: m.fused_w["llama_gu.%d" % i]), want="f32")
+            for e, g in ((deltas.get(p + "mlp.gate_proj"), dgate), (deltas.get(p + "mlp.up_proj"), dup)):
+                if e is not None:
+                    lib.gemm(lib.gemm(self._act(g), e["dt"]), e["xtT"], residual=dh2, out_f32=dh2)
+            dy = lib.rmsnorm_bwd_dx(rec["x_mid"], self._p(p + "post_attention_layernorm.weight"), dh2, self.eps)
+            lib.delta_op(1, dy, None, dx)
+            datt = lib.gemm(self._act(dy), self._wt(p + "o", lambda: self._w(p + "self_attn.o_proj.weight")))
+            qkv = rec["qkv"]
+            dq, dk, dv = lib.attention_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], rec["att"], datt, ps.desc, n_seq,
+                                           ps.max_len, H, dh, dh ** -0.5, 1)
+            dqk = torch.cat([dq, dk], 1).contiguous()
+            lib.rope_(dqk, neg_pos, 2 * H, dh, self.theta)            # the rotation's transpose = rotation by -pos
+            dh1 = lib.gemm(torch.cat([dqk, dv], 1), self._wt(p + "qkv", lambda: m.fused_w["llama_qkv.%d" % i]), want="f32")
+            dx = lib.rmsnorm_bwd_dx(rec["x_in"], self._p(p + "input_layernorm.weight"), dh1, self.eps)
+            lib.delta_op(1, dx, None, dy)
+        return out, dx
 
     @torch.no_grad()
     def lm_head(self, x_rows, add=None):

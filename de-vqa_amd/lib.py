@@ -86,6 +86,8 @@ def load():
     _sig(L.devqa_mend_lrlinear_bwd, [P, P, P, P, P, I, I, P, P, P, P, P])
     _sig(L.devqa_sumsq_f32, [P, I64, P, P])
     _sig(L.devqa_adam_step, [P, P, P, P, I64, F, F, F, F, I, P, P])
+    _sig(L.devqa_swiglu_bwd_bf16, [P, P, I, I, P, P])
+    _sig(L.devqa_swiglu_bwd_f32, [P, P, I, I, P, P])
     _sig(L.devqa_tp_neuron_fwd, [P, I, I, P, P, P, I, P, P, I, P, P, P])
     _sig(L.devqa_tp_neuron_bwd, [P, P, I, I, P, I, P, I, P, I, P, P, P, F, F, F, P, P, P, P, P, P])
     _lib = L
@@ -101,7 +103,8 @@ EXPORTS = ["devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_ro
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk", "devqa_attention_bwd",
            "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_mend_normalize_concat",
            "devqa_mend_lrlinear_epilogue", "devqa_logit_kl_rows", "devqa_kl_dlogits", "devqa_welford_rows",
-           "devqa_mend_lrlinear_bwd", "devqa_sumsq_f32", "devqa_adam_step", "devqa_tp_neuron_fwd", "devqa_tp_neuron_bwd"]
+           "devqa_mend_lrlinear_bwd", "devqa_sumsq_f32", "devqa_adam_step", "devqa_tp_neuron_fwd", "devqa_tp_neuron_bwd",
+           "devqa_swiglu_bwd_bf16", "devqa_swiglu_bwd_f32"]
 
 
 def gemm_rows_longk(a, w):
@@ -562,3 +565,14 @@ def tp_neuron_bwd(h, pre, lab, dy, hm, k, b, v, lambda_a, lambda_m, weight_decay
                                     float(lambda_m), float(weight_decay), _p(scratch), _p(gk), _p(gb), _p(gv), _p(losses), _stream()),
          "devqa_tp_neuron_bwd")
     return gk, gb, gv, losses
+
+
+def swiglu_bwd(gu, da):
+    """gu [R,2F] (gate | up; bf16 or fp32), da fp32 [R,F] -> dgu fp32 [R,2F]"""
+    assert gu.dim() == 2 and gu.is_contiguous() and gu.shape[1] % 2 == 0
+    _need(da, torch.float32, "swiglu_bwd da")
+    R, F2 = gu.shape
+    out = torch.empty((R, F2), dtype=torch.float32, device=gu.device)
+    fn = load().devqa_swiglu_bwd_bf16 if gu.dtype == torch.bfloat16 else load().devqa_swiglu_bwd_f32
+    _chk(fn(_p(gu), _p(da), R, F2 // 2, _p(out), _stream()), "devqa_swiglu_bwd")
+    return out

@@ -128,6 +128,11 @@ int devqa_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk
                         int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale,
                         int causal, void* stream);
 
+/* SwiGLU backward (MEND_VL edit path through LLaMA FFNs): gu [R,2F] (gate | up, bf16 or fp32), da fp32 [R,F] ->
+ * dgu fp32 [R,2F] = (da u sig(g)(1 + g(1 - sig(g))) | da silu(g)).  Autograd of LlamaMLP's act_fn(gate) * up. */
+int devqa_swiglu_bwd_bf16(const devqa_bf16* gu, const float* da, int R, int F, float* dgu, void* stream);
+int devqa_swiglu_bwd_f32(const float* gu, const float* da, int R, int F, float* dgu, void* stream);
+
 /* ---- attention backward (MEND_VL edit path) ---------------------------------------------------
  * Gradients of devqa_attention for descriptors WITHOUT a visible prefix (kp_len == 0; every sequence attends to its own
  * rows, causal or full): given q,k,v, the forward output o and d_out = dL/do, writes dq, dk, dv (same dtype/layout as

@@ -146,8 +146,15 @@ class OracleLlava(OracleBlip2):
             o = torch.matmul(a, v).transpose(1, 2).reshape(B, T, D)
             x = x + _lin(o, w[p + "self_attn.o_proj.weight"])
             h = _rms(x, w[p + "post_attention_layernorm.weight"], self.t_eps)
-            a1 = F.silu(_lin(h, w[p + "mlp.gate_proj.weight"])) * _lin(h, w[p + "mlp.up_proj.weight"])
-            x = x + _lin(a1, w[p + "mlp.down_proj.weight"])
+            hook = getattr(self, "module_hook", None)   # (module name, input, output) -> output; MEND-style editors
+            g1, u1 = _lin(h, w[p + "mlp.gate_proj.weight"]), _lin(h, w[p + "mlp.up_proj.weight"])
+            if hook is not None:
+                g1, u1 = hook(p + "mlp.gate_proj", h, g1), hook(p + "mlp.up_proj", h, u1)
+            a1 = F.silu(g1) * u1
+            d1 = _lin(a1, w[p + "mlp.down_proj.weight"])
+            if hook is not None:
+                d1 = hook(p + "mlp.down_proj", a1, d1)
+            x = x + d1
         return x
 
     def get_llm_outpt(self, llm_inpt, vt_range=None):
