@@ -122,3 +122,54 @@ def test_minigpt4_evaluator_generic_and_batched(mg, in_gold_dir, tmp_path):
         print(mode, "batched" if batched else "generic", "== oracle %d/%d" % (same, len(fg)))
         assert len(fr) == len(fg) == 36
         assert same == 36 if mode == "fp32" else same >= 27
+
+
+def test_minigpt4_mend_vs_oracle(mg, in_gold_dir):
+    """MEND_VL on MiniGPT-4's LLaMA (llama_model.model.layers.N.mlp.*): one edit + one training step vs the oracles."""
+    from devqa_amd.editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
+    from devqa_amd.synth import mend_aux_init
+    from oracle.mend_oracle import OracleMENDvl
+    vllm, orc, rec, tol, mode = mg
+    mods = ["llama_model.model.layers.%d.mlp.%s" % (l, k) for l in (0, 1) for k in ("gate_proj", "up_proj", "down_proj")]
+    aux = dict(n_hidden=1, hidden_dim=None, init="id", norm=True, act="relu", rank=16, shared=True, lr=1e-3)
+    cfg = MENDvlConfig(edit_modules=mods, init_edit_lr=1e-2, edit_lr_lr=1e-3, aux_model=MENDvlConfig.AuxModelConfig(**aux),
+                       edit_model_name="minigpt-4-vicuna-7b", relia_lambda=0.1, gen_lambda=0.1, loc_lambda=0.1)
+    d, F = 64, 96
+    tm = {"aux_models": {}, "edit_lrs": {str(i): torch.tensor(float(mend_aux_init("edit_lrs.%d" % i, (), 7))) for i in range(6)}}
+    for (du, dv), n_modes in (((d, F), 4), ((F, d), 2)):
+        key, D = str((du, dv)), du + dv
+        shapes = {"u_mean": (du,), "u_std": (du,), "v_mean": (dv,), "v_std": (dv,), "u_s": (du,), "v_s": (dv,), "k": (1,)}
+        for l in range(2):
+            shapes.update({"mlp.layers.%d.u" % l: (D, 16), "mlp.layers.%d.v" % l: (16, D), "mlp.layers.%d.bias" % l: (D,),
+                           "mlp.layers.%d.mode_shift.weight" % l: (n_modes, D), "mlp.layers.%d.mode_scale.weight" % l: (n_modes, D)})
+        for leaf, shp in shapes.items():
+            tm["aux_models"]["%s.%s" % (key, leaf)] = torch.from_numpy(mend_aux_init("aux_models.%s.%s" % (key, leaf), shp, 7))
+    ed = MENDvl(vllm, cfg, "cuda:0", train_modules=tm)
+    oed = OracleMENDvl(orc, dict(edit_modules=mods, aux_model=aux, relia_lambda=0.1, gen_lambda=0.1, loc_lambda=0.1), tm)
+    r = rec["records"][0]["requests"][0]
+    ed.edit_one_piece(deepcopy(r))
+    oed.edit_one_piece(deepcopy(r))
+    ftol = 1e-3 if mode == "fp32" else 1.5e-1
+    for m in ed.modules:
+        ref = oed.last[m["name"]]["dw"].detach()
+        e = float((ed.delta_weight(m["name"]).cpu() - ref).abs().max() / ref.abs().max())
+        assert e < ftol, (m["name"], e)
+    ed.restore_to_original_model()
+    oed.restore_to_original_model()
+    # one training step (fp32: losses and gradient norm agree with the autograd oracle)
+    ed.set_train(True)
+    oed.set_train(1e-3, 1e-3)
+    d0 = deepcopy(rec["records"][1])
+    loss, log = ed.train_a_batch(ed.organize_batch_data([deepcopy(d0)]))
+    with torch.no_grad():
+        ob = (orc.prompts_imgs_target_to_xym([d0["requests"][0]["prompt"]], [d0["requests"][0]["image"]], [d0["requests"][0]["target_new"]]),
+              {k: orc.prompts_imgs_target_to_xym([d0["generality"][k][0]["prompt"]], [d0["generality"][k][0]["image"]],
+                                                 [d0["generality"][k][0]["target"]]) for k in d0["generality"]},
+              {k: orc.prompts_imgs_target_to_xym([d0["locality"][k][0]["prompt"]], [d0["locality"][k][0]["image"]],
+                                                 [d0["locality"][k][0]["target"]]) for k in d0["locality"]})
+    oloss, olog = oed.train_a_batch(ob)
+    print(mode, "train step loss %.5f (oracle %.5f) grad-norm %.4f (oracle %.4f)" % (loss, oloss, log["Grad-Norm"], olog["Grad-Norm"]))
+    ltol = 2e-4 if mode == "fp32" else 3e-2
+    assert abs(loss - oloss) < ltol * abs(oloss) and abs(log["Grad-Norm"] - olog["Grad-Norm"]) < 10 * ltol * olog["Grad-Norm"]
+    ed.set_train(False)
+    ed.restore_to_original_model()
