@@ -13,7 +13,9 @@
 // L2/MALL resident.  Per-row dot products are reduced with wavefront shuffles + one LDS hop.
 #include "common.h"
 
-template <int L, int ROWS>
+// NARROW (column-compacted matrices, Din of a few hundred): every WAVE owns its own ROWS rows (the workgroup 4 x ROWS) and
+// strides Din with its 64 lanes -- with 256 threads on one row group only Din/4 of them would have a float4 to work on.
+template <int L, int ROWS, bool NARROW = false>
 __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ w, float* __restrict__ m,
                                                             float* __restrict__ v, const float* __restrict__ w0,
                                                             const float* __restrict__ a, const float* __restrict__ dy,
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
     const float bc2_sqrt = sqrtf(bc2);
     const float decay = 1.f - lr * wd;
 
-    const int i0 = rb * ROWS;
+    const int i0 = NARROW ? (rb * 4 + (int)(threadIdx.x >> 6)) * ROWS : rb * ROWS;
     const int64_t mat = (int64_t)Dout * Din;
     float* we = w + (int64_t)e * mat;
     float* me = m + (int64_t)e * mat;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
         for (int l = 0; l < L; ++l) ysum[r][l] = 0.f;
 
     const int nv = Din >> 2;
-    for (int c = threadIdx.x; c < nv; c += 256) {
+    for (int c = NARROW ? (int)(threadIdx.x & 63) : (int)threadIdx.x; c < nv; c += (NARROW ? 64 : 256)) {
         float4 av[L];
 #pragma unroll
         for (int l = 0; l < L; ++l)
@@ -108,6 +110,16 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (NARROW) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const float s = wave_sum(ysum[r][l]);
+                if (lane == 0 && i0 + r < Dout && l < Lmax) y[((int64_t)e * Lmax + l) * Dout + i0 + r] = s;
+            }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
@@ -129,6 +141,13 @@ template <int L, int ROWS>
 static int launch_adamw(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
                         const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din, float lr,
                         float beta1, float beta2, float eps, float wd, float clamp_eps, int64_t w0_stride_e, hipStream_t st) {
+    if (Din <= 1024) {
+        const int row_blocks = (Dout + 4 * ROWS - 1) / (4 * ROWS);
+        hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS, true>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
+                           do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
+        DEVQA_LAUNCH_CHECK("ft_adamw_step");
+        return DEVQA_OK;
+    }
     const int row_blocks = (Dout + ROWS - 1) / ROWS;
     hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
                        do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
