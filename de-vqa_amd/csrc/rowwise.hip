@@ -20,65 +20,96 @@ extern "C" int devqa_abi_version(void) { return 1; }
 // LayerNorm forward: one wave per row, row held in registers (D <= 64*4*MAXV).
 // ------------------------------------------------------------------------------------------
 #define LN_MAXV 16
+typedef __bf16 ln_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float ln_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t ln_pack2(float a, float b) {   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    ln_f32x2_t f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, ln_bf16x2_t));
+}
+
+// One wave per row, RPW rows per wave with ALL their loads issued before the first reduction (bytes in flight are what an
+// HBM stream needs); NV = float4 pieces per lane (D <= 256 * NV), a template parameter so that no predicated iterations are
+// left.  Two-pass statistics from registers (mean, then centred sum of squares), as nn.LayerNorm.
+template <int NV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int M, int D, float eps, bf16_t* __restrict__ out_bf16,
                                                         float* __restrict__ out_f32) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= M) return;
     const int nv = D >> 2;
-    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
-    const float4* ar = add ? reinterpret_cast<const float4*>(add + (int64_t)row * D) : nullptr;
-    float4 v[LN_MAXV];
-    float s = 0.f;
+    float4 v[RPW][NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = i * 64 + lane;
-        if (c < nv) {
-            float4 t = xr[c];
-            if (ar) {
-                const float4 u = ar[c];
-                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, M - 1);     // a clamped duplicate row is computed and not stored
+        const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            v[r][i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (add) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float4* ar = reinterpret_cast<const float4*>(add + (int64_t)min(row0 + r, M - 1) * D);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 64 + lane;
+                if (c < nv) {
+                    const float4 u = ar[c];
+                    v[r][i].x += u.x; v[r][i].y += u.y; v[r][i].z += u.z; v[r][i].w += u.w;
+                }
             }
-            v[i] = t;
-            s += (t.x + t.y) + (t.z + t.w);
-        } else {
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = i * 64 + lane;
-        if (c < nv) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-            q += (a * a + b * b) + (cc * cc + d * d);
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = i * 64 + lane;
-        if (c < nv) {
-            const float4 g = g4[c], b = b4[c];
-            float4 o;
-            o.x = (v[i].x - mean) * rstd * g.x + b.x;
-            o.y = (v[i].y - mean) * rstd * g.y + b.y;
-            o.z = (v[i].z - mean) * rstd * g.z + b.z;
-            o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            if (out_f32) reinterpret_cast<float4*>(out_f32 + (int64_t)row * D)[c] = o;
-            if (out_bf16) {
-                uint2 p;
-                p.x = pack_bf16x2(o.x, o.y);
-                p.y = pack_bf16x2(o.z, o.w);
-                reinterpret_cast<uint2*>(out_bf16 + (int64_t)row * D)[c] = p;
+    for (int r = 0; r < RPW; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);   // padding pieces are zero
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (i * 64 + lane < nv) {
+                const float a = v[r][i].x - mean, b = v[r][i].y - mean, cc = v[r][i].z - mean, d = v[r][i].w - mean;
+                q += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+        const int row = row0 + r;
+        if (row >= M) continue;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) {
+                const float4 g = g4[c], b = b4[c];
+                float4 o;
+                o.x = (v[r][i].x - mean) * rstd * g.x + b.x;
+                o.y = (v[r][i].y - mean) * rstd * g.y + b.y;
+                o.z = (v[r][i].z - mean) * rstd * g.z + b.z;
+                o.w = (v[r][i].w - mean) * rstd * g.w + b.w;
+                if (out_f32) reinterpret_cast<float4*>(out_f32 + (int64_t)row * D)[c] = o;
+                if (out_bf16) {
+                    uint2 p;
+                    p.x = ln_pack2(o.x, o.y);
+                    p.y = ln_pack2(o.z, o.w);
+                    reinterpret_cast<uint2*>(out_bf16 + (int64_t)row * D)[c] = p;
+                }
             }
         }
     }
+}
+
+template <int NV, int RPW>
+static void launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, int M, int D, float eps,
+                             bf16_t* out_bf16, float* out_f32, hipStream_t st) {
+    hipLaunchKernelGGL((layernorm_kernel<NV, RPW>), dim3((M + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st, x, add, gamma, beta, M, D,
+                       eps, out_bf16, out_f32);
 }
 
 extern "C" int devqa_layernorm(const float* x, const float* add, const float* gamma, const float* beta, int M, int D,
@@ -86,8 +117,18 @@ extern "C" int devqa_layernorm(const float* x, const float* add, const float* ga
     DEVQA_CHECK_ARG(x && gamma && beta && (out_bf16 || out_f32), "layernorm: null pointer");
     if (M == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "layernorm: D=%d unsupported", D);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta, M, D,
-                       eps, out_bf16, out_f32);
+    hipStream_t st = (hipStream_t)stream;
+#define LN_ARGS x, add, gamma, beta, M, D, eps, out_bf16, out_f32, st
+    const int nvl = (D / 4 + 63) / 64;      // float4 pieces per lane
+    if (nvl <= 1) launch_layernorm<1, 4>(LN_ARGS);
+    else if (nvl <= 2) launch_layernorm<2, 4>(LN_ARGS);
+    else if (nvl <= 3) launch_layernorm<3, 2>(LN_ARGS);
+    else if (nvl <= 4) launch_layernorm<4, 2>(LN_ARGS);
+    else if (nvl <= 6) launch_layernorm<6, 2>(LN_ARGS);
+    else if (nvl <= 8) launch_layernorm<8, 2>(LN_ARGS);
+    else if (nvl <= 10) launch_layernorm<10, 2>(LN_ARGS);
+    else launch_layernorm<16, 1>(LN_ARGS);
+#undef LN_ARGS
     DEVQA_LAUNCH_CHECK("layernorm");
     return DEVQA_OK;
 }
