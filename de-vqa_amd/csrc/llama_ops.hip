@@ -128,20 +128,24 @@ __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 
+// One wave per row: lane -> (head slot = lane / half, j = lane % half); the angle depends on (pos[row], j) only, so sin / cos
+// are computed ONCE per row and lane (full-precision sincosf) and reused for every head the lane visits.
 template <typename T>
-__global__ void rope_kernel(T* __restrict__ x, int64_t ld, int R, const int32_t* __restrict__ pos, int n_heads, int dh,
-                            float log2_theta) {
+__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ x, int64_t ld, int R, const int32_t* __restrict__ pos, int n_heads,
+                                                   int dh, float log2_theta) {
     const int half = dh >> 1;
-    const int64_t total = (int64_t)R * n_heads * half;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i % half);
-        const int h = (int)((i / half) % n_heads);
-        const int64_t r = i / ((int64_t)half * n_heads);
-        const float inv_freq = exp2f(-log2_theta * (2.0f * (float)j / (float)dh));
-        const float ang = (float)pos[r] * inv_freq;
-        float sn, cs;
-        sincosf(ang, &sn, &cs);
-        T* p = x + r * ld + (int64_t)h * dh + j;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int hp = half >= 64 ? 1 : 64 / half;          // heads per pass (half <= 64: checked on the host)
+    const int slot = lane / half, j = lane - slot * half;
+    if (slot >= hp) return;
+    const float inv_freq = exp2f(-log2_theta * (2.0f * (float)j / (float)dh));
+    float sn, cs;
+    sincosf((float)pos[row] * inv_freq, &sn, &cs);
+    T* base = x + (int64_t)row * ld + j;
+    for (int h = slot; h < n_heads; h += hp) {
+        T* p = base + (int64_t)h * dh;
         const float a = ldf(p), b = ldf(p + half);
         stf(p, a * cs - b * sn);
         stf(p + half, b * cs + a * sn);
@@ -152,10 +156,9 @@ template <typename T>
 static int launch_rope(T* x, int64_t ld, int R, const int32_t* pos, int n_heads, int dh, float theta, void* stream) {
     DEVQA_CHECK_ARG(x && pos, "rope: null pointer");
     if (R == 0) return DEVQA_OK;
-    DEVQA_CHECK_SHAPE(R > 0 && n_heads > 0 && dh > 0 && dh % 2 == 0 && ld >= (int64_t)n_heads * dh && theta > 1.f, "rope: bad dims");
-    const int64_t total = (int64_t)R * n_heads * (dh / 2);
-    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(rope_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ld, R, pos, n_heads, dh, log2f(theta));
+    DEVQA_CHECK_SHAPE(R > 0 && n_heads > 0 && dh > 0 && dh % 2 == 0 && dh <= 128 && ld >= (int64_t)n_heads * dh && theta > 1.f,
+                      "rope: bad dims (dh even, <= 128)");
+    hipLaunchKernelGGL(rope_kernel<T>, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, R, pos, n_heads, dh, log2f(theta));
     DEVQA_LAUNCH_CHECK("rope");
     return DEVQA_OK;
 }
@@ -177,6 +180,27 @@ __global__ void swiglu_kernel(const T* __restrict__ gu, int R, int F, T* __restr
         stf(out + i, g / (1.f + __expf(-g)) * u);
     }
 }
+
+// bf16, F % 8 == 0: 16-byte accesses (8 gate + 8 up values in, 8 out per thread and step)
+__global__ __launch_bounds__(256) void swiglu_bf16x8_kernel(const bf16_t* __restrict__ gu, int R, int F8, bf16_t* __restrict__ out) {
+    const int64_t total = (int64_t)R * F8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % F8);
+        const int64_t r = i / F8;
+        const uint4 g4 = reinterpret_cast<const uint4*>(gu + r * 16 * F8)[j];
+        const uint4 u4 = reinterpret_cast<const uint4*>(gu + r * 16 * F8 + 8 * F8)[j];
+        const uint32_t gw[4] = {g4.x, g4.y, g4.z, g4.w}, uw[4] = {u4.x, u4.y, u4.z, u4.w};
+        uint32_t ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g0 = __uint_as_float(gw[k] << 16), g1 = __uint_as_float(gw[k] & 0xffff0000u);
+            const float u0 = __uint_as_float(uw[k] << 16), u1 = __uint_as_float(uw[k] & 0xffff0000u);
+            ow[k] = pack_bf16x2(g0 / (1.f + __expf(-g0)) * u0, g1 / (1.f + __expf(-g1)) * u1);
+        }
+        reinterpret_cast<uint4*>(out + r * 8 * F8)[j] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+}
+
 template <typename T>
 static int launch_swiglu(const T* gu, int R, int F, T* out, void* stream) {
     DEVQA_CHECK_ARG(gu && out, "swiglu: null pointer");
@@ -184,6 +208,15 @@ static int launch_swiglu(const T* gu, int R, int F, T* out, void* stream) {
     DEVQA_CHECK_SHAPE(R > 0 && F > 0, "swiglu: bad dims");
     const int64_t total = (int64_t)R * F;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if constexpr (sizeof(T) == 2) {
+        if (F % 8 == 0 && (((uintptr_t)gu | (uintptr_t)out) & 15) == 0) {
+            const int64_t tot8 = (int64_t)R * (F / 8);
+            const unsigned g8 = (unsigned)((tot8 + 255) / 256 < 65536 ? (tot8 + 255) / 256 : 65536);
+            hipLaunchKernelGGL(swiglu_bf16x8_kernel, dim3(g8), dim3(256), 0, (hipStream_t)stream, gu, R, F / 8, out);
+            DEVQA_LAUNCH_CHECK("swiglu");
+            return DEVQA_OK;
+        }
+    }
     hipLaunchKernelGGL(swiglu_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gu, R, F, out);
     DEVQA_LAUNCH_CHECK("swiglu");
     return DEVQA_OK;
