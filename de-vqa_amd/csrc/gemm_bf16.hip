@@ -284,6 +284,67 @@ static int launch_gemm(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ld
     return DEVQA_OK;
 }
 
+// ---- small-M GEMMs (M <= 64: B = 1 probes, the MEND / T-Patcher edit passes) are weight streams: with one 64x128 tile per
+// 128 output columns a [64 x 10240 x 2560] product runs on 80 workgroups and ~1 TB/s.  Split K over enough workgroups to fill
+// the chip (fp32 partials in a library-owned, per-stream workspace), then one pass sums the partials and applies the usual
+// epilogue (bias, alpha, activation, residual, bf16 / fp32 outputs).
+__global__ void splitk_reduce_epilogue_kernel(const float* __restrict__ part, int splits, int M, int N, const float* __restrict__ bias,
+                                              float alpha, int act, const float* residual, bf16_t* out_bf16, float* out_f32,
+                                              int64_t ldc) {
+    const int n4 = N >> 2;
+    const int64_t mn4 = (int64_t)M * n4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 s = reinterpret_cast<const float4*>(part)[i];
+        for (int k = 1; k < splits; ++k) {
+            const float4 p = reinterpret_cast<const float4*>(part)[(int64_t)k * mn4 + i];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + n);
+            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        }
+        s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
+        s = devqa_act4(s, act);
+        const int64_t o = (int64_t)m * ldc + n;
+        if (residual) {
+            const float4 r = *reinterpret_cast<const float4*>(residual + o);
+            s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+        }
+        if (out_f32) *reinterpret_cast<float4*>(out_f32 + o) = s;
+        if (out_bf16) {
+            uint2 p;
+            p.x = pack_bf16x2(s.x, s.y);
+            p.y = pack_bf16x2(s.z, s.w);
+            *reinterpret_cast<uint2*>(out_bf16 + o) = p;
+        }
+    }
+}
+
+namespace {
+struct SplitKWs { hipStream_t st; int dev; float* p; size_t bytes; };
+SplitKWs g_skws[8] = {};
+float* splitk_workspace(hipStream_t st, size_t bytes) {   // one buffer per (device, stream): concurrent streams never share
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    SplitKWs* slot = nullptr;
+    for (auto& w : g_skws)
+        if (w.p && w.st == st && w.dev == dev) { slot = &w; break; }
+    if (!slot)
+        for (auto& w : g_skws)
+            if (!w.p) { slot = &w; break; }
+    if (!slot) return nullptr;
+    if (slot->bytes < bytes) {
+        if (slot->p) { (void)hipStreamSynchronize(st); (void)hipFree(slot->p); }
+        slot->p = nullptr; slot->bytes = 0;
+        const size_t want = bytes < (32u << 20) ? (32u << 20) : bytes + (bytes >> 2);
+        if (hipMalloc(reinterpret_cast<void**>(&slot->p), want) != hipSuccess) { (void)hipGetLastError(); slot->p = nullptr; return nullptr; }
+        slot->bytes = want; slot->st = st; slot->dev = dev;
+    }
+    return slot->p;
+}
+}  // namespace
+
 extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64_t ldw, const float* bias,
                                int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
                                float* out_f32, int64_t ldc, void* stream) {
@@ -297,6 +358,32 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     DEVQA_CHECK_SHAPE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dims too small");
     DEVQA_CHECK_SHAPE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("DEVQA_GEMM");
+        g_gemm_mode = e ? atoi(e) : 0;
+    }
+    if (M <= 64 && g_gemm_mode == 0 && N % 4 == 0 && ldc % 4 == 0 &&
+        ((((uintptr_t)out_f32) | ((uintptr_t)residual) | ((uintptr_t)bias)) & 15) == 0 && (((uintptr_t)out_bf16) & 7) == 0) {
+        const int tiles_n = (N + 127) / 128, nk = (K + BK - 1) / BK;
+        int splits = 512 / tiles_n;
+        if (splits > nk / 4) splits = nk / 4;
+        if (splits >= 2) {
+            const int steps = (nk + splits - 1) / splits;
+            const int used = (nk + steps - 1) / steps;
+            float* ws = splitk_workspace(st, (size_t)used * M * N * sizeof(float));
+            if (ws) {
+                auto kern = gemm_bf16_tn_kernel<64, 128, 2, 2>;
+                hipLaunchKernelGGL(kern, dim3(tiles_n, used), dim3(256), 2 * (64 + 128) * BK * 2, st, A, lda, W, ldw, (const float*)nullptr,
+                                   M, N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, ws, (int64_t)N, 1, tiles_n, steps);
+                DEVQA_LAUNCH_CHECK("gemm_small_m_splitk");
+                const int64_t mn4 = (int64_t)M * N / 4;
+                hipLaunchKernelGGL(splitk_reduce_epilogue_kernel, dim3((unsigned)((mn4 + 255) / 256 < 2048 ? (mn4 + 255) / 256 : 2048)),
+                                   dim3(256), 0, st, ws, used, M, N, bias, alpha, act, residual, out_bf16, out_f32, ldc);
+                DEVQA_LAUNCH_CHECK("splitk_reduce_epilogue");
+                return DEVQA_OK;
+            }
+        }
+    }
     if (M <= 32) return launch_gemm<32, 128, 1, 4>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     // mode 0: LDS-DMA staging when K % 64 == 0, 256x256 tiles for large problems (default); 1: force the
     // register-staged kernels; 2: LDS-DMA staging but no 256x256 tiles; 10..17: experimental ring variants

@@ -42,3 +42,29 @@ def test_gemm_variants(L, mode, M, N, K, act, res):
     out = L.gemm(a.cuda(), w.cuda(), b.cuda(), 1.0, act, rd, out_f32=rd if res else None, want="f32")
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=3e-4, rtol=3e-4)
+
+
+@pytest.mark.parametrize("M,N,K,act,res,want", [
+    (48, 10240, 2560, 1, False, "bf16"),    # OPT fc1 at B = 1: auto split-K (80 column tiles -> 6 K-slices) + fused epilogue
+    (33, 2560, 10240, 0, True, "f32"),      # OPT fc2 with the in-place fp32 residual
+    (64, 7680, 2560, 0, False, "bf16"),     # fused qkv
+    (17, 4096, 11008, 0, True, "f32"),      # LLaMA down_proj
+    (48, 50272, 2560, 0, False, "f32"),     # lm_head rows: enough column tiles, no split
+])
+def test_small_m_splitk_epilogue(L, M, N, K, act, res, want):
+    L.gemm_set_mode(0)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if res else None
+    ref = a.float() @ w.float().T + b
+    if act == 1:
+        ref = torch.relu(ref)
+    if res:
+        ref = ref + r
+    rd = r.cuda() if res else None
+    out = L.gemm(a.cuda(), w.cuda(), b.cuda(), 1.0, act, rd, out_f32=rd if res else None, want=want)
+    torch.cuda.synchronize()
+    tol = 3e-4 if want == "f32" else 1.5e-2
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=tol, rtol=tol)
