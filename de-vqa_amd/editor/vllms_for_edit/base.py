@@ -119,8 +119,11 @@ class BaseVLLMForEdit(ABC):
         import numpy as np
         from collections import OrderedDict
         cache = self.__dict__.setdefault("_img_feat_cache", OrderedDict())
-        lm = self._lm_param_prefix()
-        stamp = tuple(p._version for n, p in self.model.named_parameters() if not n.startswith(lm))
+        watched = self.__dict__.get("_img_feat_watched")
+        if watched is None:     # the module tree is fixed after construction: walk it once
+            lm = self._lm_param_prefix()
+            watched = self._img_feat_watched = [p for n, p in self.model.named_parameters() if not n.startswith(lm)]
+        stamp = tuple(p._version for p in watched)
         if self.__dict__.get("_img_feat_stamp") != stamp:
             cache.clear()
             self._img_feat_stamp = stamp

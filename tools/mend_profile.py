@@ -41,6 +41,30 @@ def main():
         t1 = time.time()
         ed.restore_to_original_model()
         print("edit_one_piece %.1f ms" % ((t1 - t0) * 1e3), flush=True)
+    # evaluation phases of one cycle through the generic evaluator's batched-probe path
+    from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation as EV
+    d = recs[2]
+    loc = [(e["prompt"], e["image"], e["target"]) for k in d["locality"] for e in d["locality"][k]]
+    post = [(d["requests"][0]["prompt"], d["requests"][0]["image"], d["requests"][0]["target_new"])] + \
+        [(e["prompt"], e["image"], e["target"]) for k in d["generality"] for e in d["generality"][k]] + loc
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    EV._argmax_many(vllm, loc)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        EV._argmax_many(vllm, loc)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        EV._argmax_many(vllm, post)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        print("pre-edit phase (9 probes) %.1f ms, post-edit phase (12 probes) %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
 
 
 if __name__ == "__main__":
