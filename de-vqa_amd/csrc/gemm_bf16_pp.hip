@@ -63,15 +63,22 @@ __device__ __forceinline__ void pp_mfma_block(float4_t (&acc)[8][4], const short
 }
 
 // TAIL: 0 = tiles t+1 and t+2 exist, 1 = only t+1 exists, 2 = last tile
-template <int TAIL>
+// BAL (experimental): B0 of tile t+1 is read one phase early (phase 3 of tile t, which otherwise reads nothing) into b0n, so
+// the per-phase ds_read counts are 8/4/8/4 instead of 12/4/8/0; B0 is then staged before A0 (slots 4t-6 / 4t-5).
+template <int TAIL, bool BAL = false>
 __device__ __forceinline__ void pp_tile(const PPState& s, int t, float4_t (&acc)[8][4], short8_t (&a)[4][2], short8_t (&b0)[2][2],
-                                        short8_t (&b1)[2][2]) {
+                                        short8_t (&b1)[2][2], short8_t (&b0n)[2][2]) {
     const unsigned char* base = s.smem + (t & 1) * PP_BUF;
     // ---- phase 0: quadrant (a0, b0)
+    if constexpr (BAL) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        b0[j][0] = *reinterpret_cast<const short8_t*>(base + R_B0 * PP_HALF + j * 2048 + s.lb0);
-        b0[j][1] = *reinterpret_cast<const short8_t*>(base + R_B0 * PP_HALF + j * 2048 + s.lb1);
+        for (int j = 0; j < 2; ++j) { b0[j][0] = b0n[j][0]; b0[j][1] = b0n[j][1]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            b0[j][0] = *reinterpret_cast<const short8_t*>(base + R_B0 * PP_HALF + j * 2048 + s.lb0);
+            b0[j][1] = *reinterpret_cast<const short8_t*>(base + R_B0 * PP_HALF + j * 2048 + s.lb1);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -98,12 +105,20 @@ __device__ __forceinline__ void pp_tile(const PPState& s, int t, float4_t (&acc)
         a[i][0] = *reinterpret_cast<const short8_t*>(base + R_A1 * PP_HALF + i * 2048 + s.la0);
         a[i][1] = *reinterpret_cast<const short8_t*>(base + R_A1 * PP_HALF + i * 2048 + s.la1);
     }
-    if constexpr (TAIL == 0) { pp_stage<R_A0>(s, t + 2); pp_vmcnt<8>(); } else if constexpr (TAIL == 1) { pp_vmcnt<6>(); } else { pp_vmcnt<0>(); }
+    if constexpr (TAIL == 0) { pp_stage<BAL ? R_B0 : R_A0>(s, t + 2); pp_vmcnt<8>(); } else if constexpr (TAIL == 1) { pp_vmcnt<6>(); } else { pp_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();
     pp_mfma_block(acc, a, b1, 4, 2);
     __builtin_amdgcn_s_barrier();
     // ---- phase 3: quadrant (a1, b0)
-    if constexpr (TAIL == 0) { pp_stage<R_B0>(s, t + 2); pp_vmcnt<8>(); } else if constexpr (TAIL == 1) { pp_vmcnt<4>(); } else { pp_vmcnt<0>(); }
+    if constexpr (BAL && TAIL <= 1) {
+        const unsigned char* nb = s.smem + ((t + 1) & 1) * PP_BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            b0n[j][0] = *reinterpret_cast<const short8_t*>(nb + R_B0 * PP_HALF + j * 2048 + s.lb0);
+            b0n[j][1] = *reinterpret_cast<const short8_t*>(nb + R_B0 * PP_HALF + j * 2048 + s.lb1);
+        }
+    }
+    if constexpr (TAIL == 0) { pp_stage<BAL ? R_A0 : R_B0>(s, t + 2); pp_vmcnt<8>(); } else if constexpr (TAIL == 1) { pp_vmcnt<4>(); } else { pp_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();
     pp_mfma_block(acc, a, b0, 4, 0);
     __builtin_amdgcn_s_barrier();
@@ -167,6 +182,7 @@ __device__ __forceinline__ void pp_tile_coords(const PPArgs& g, int id, int& til
 }
 
 // K-tiles [k0, k0 + nk) of tile (tile_m, tile_n) -> acc.  Every wave executes the same number of barriers.
+template <bool BAL = false>
 __device__ __forceinline__ void pp_mainloop(const PPArgs& g, unsigned char* smem, int m0, int n0, int k0, int nk,
                                             float4_t (&acc)[8][4]) {
     const int tid = threadIdx.x;
@@ -202,28 +218,35 @@ __device__ __forceinline__ void pp_mainloop(const PPArgs& g, unsigned char* smem
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    short8_t a[4][2], b0[2][2], b1[2][2];
-    // prologue: slots -6..-1 = A0,B0,B1,A1 of tile 0 and A0,B0 of tile 1; A0(0), B0(0) must have landed
+    short8_t a[4][2], b0[2][2], b1[2][2], b0n[2][2];
+    // prologue: slots -6..-1 = A0,B0,B1,A1 of tile 0 and the first two half-tiles of tile 1; A0(0), B0(0) must have landed
     pp_stage<R_A0>(s, 0);
     pp_stage<R_B0>(s, 0);
     pp_stage<R_B1>(s, 0);
     pp_stage<R_A1>(s, 0);
     if (nk > 1) {
-        pp_stage<R_A0>(s, 1);
-        pp_stage<R_B0>(s, 1);
+        pp_stage<BAL ? R_B0 : R_A0>(s, 1);
+        pp_stage<BAL ? R_A0 : R_B0>(s, 1);
         pp_vmcnt<8>();
     } else {
         pp_vmcnt<4>();
     }
     __builtin_amdgcn_s_barrier();
+    if constexpr (BAL) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            b0n[j][0] = *reinterpret_cast<const short8_t*>(smem + R_B0 * PP_HALF + j * 2048 + s.lb0);
+            b0n[j][1] = *reinterpret_cast<const short8_t*>(smem + R_B0 * PP_HALF + j * 2048 + s.lb1);
+        }
+    }
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier interval behind waves 0-3
     int t = 0;
-    for (; t + 2 < nk; ++t) pp_tile<0>(s, t, acc, a, b0, b1);
+    for (; t + 2 < nk; ++t) pp_tile<0, BAL>(s, t, acc, a, b0, b1, b0n);
     if (t + 1 < nk) {
-        pp_tile<1>(s, t, acc, a, b0, b1);
+        pp_tile<1, BAL>(s, t, acc, a, b0, b1, b0n);
         ++t;
     }
-    pp_tile<2>(s, t, acc, a, b0, b1);
+    pp_tile<2, BAL>(s, t, acc, a, b0, b1, b0n);
     if (wr == 0) __builtin_amdgcn_s_barrier();   // match the extra barrier of waves 4-7
 }
 
@@ -290,7 +313,7 @@ __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem
     }
 }
 
-template <int ACT, bool SK>
+template <int ACT, bool SK, bool BAL = false>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4_t acc[8][4];
@@ -300,7 +323,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
         const int bid = blockIdx.x, nwg = g.dp_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         int tile_m, tile_n;
         pp_tile_coords(g, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx, tile_m, tile_n);
-        pp_mainloop(g, smem, tile_m * PP_BM, tile_n * PP_BN, 0, nk, acc);
+        pp_mainloop<BAL>(g, smem, tile_m * PP_BM, tile_n * PP_BN, 0, nk, acc);
         pp_epilogue<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
         return;
     }
@@ -383,10 +406,10 @@ struct PPWorkspace {
 PPWorkspace g_ppws[16];
 }  // namespace
 
-template <int ACT, bool SK>
+template <int ACT, bool SK, bool BAL = false>
 static int launch_pp_k(const PPArgs& g, hipStream_t st) {
     const size_t smem = 2 * PP_BUF;
-    auto kern = gemm_bf16_pp_kernel<ACT, SK>;
+    auto kern = gemm_bf16_pp_kernel<ACT, SK, BAL>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -399,6 +422,11 @@ static int launch_pp_k(const PPArgs& g, hipStream_t st) {
 
 template <int ACT>
 static int launch_pp(const PPArgs& g, hipStream_t st) {
+    if (g.group_m < 0) {      // variant 5: balanced ds_read schedule (experimental)
+        PPArgs h = g;
+        h.group_m = -g.group_m;
+        return launch_pp_k<ACT, false, true>(h, st);
+    }
     return g.sk_wgs > 0 ? launch_pp_k<ACT, true>(g, st) : launch_pp_k<ACT, false>(g, st);
 }
 
@@ -408,8 +436,8 @@ static int launch_pp(const PPArgs& g, hipStream_t st) {
 //       partial round it removes on every shape of this path: measured 0.50-0.93x, profiles/r01_summary.md)
 int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K, float alpha,
                    int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc, hipStream_t st) {
-    static const int gms[5] = {8, 1, 4, 16, 4};
-    if (id < 0 || id > 4) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
+    static const int gms[6] = {8, 1, 4, 16, 4, -4};
+    if (id < 0 || id > 5) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
     if (K % PP_BK != 0 || K < PP_BK) return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: K=%d must be a positive multiple of 64", K);
     if ((int64_t)M * lda * 2 >= (1ll << 32) || (int64_t)N * ldw * 2 >= (1ll << 32))
         return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: operands must span < 4 GiB (32-bit lane offsets)");
