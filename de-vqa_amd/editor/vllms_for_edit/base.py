@@ -112,7 +112,7 @@ class BaseVLLMForEdit(ABC):
     # ---- image-feature cache (native path only) --------------------------------------------------------------
     def image_features(self, imgs):
         """[len(imgs), n_img, d] fp32 features of images given as paths / PIL / arrays.  An image addressed by PATH is
-        encoded once and kept (64-entry LRU) for as long as no parameter outside the language model changes: the
+        encoded once and kept (160-entry LRU) for as long as no parameter outside the language model changes: the
         evaluator shows the same 4 images of a sample to 21 probes (R/evaluation/vllm_editor_eval.py:98-121) and every
         shipped editor edits language-model weights only.  The stamp below (version counters of all non-LLM
         parameters) drops the cache if an editor ever touches the vision side."""
@@ -140,7 +140,7 @@ class BaseVLLMForEdit(ABC):
             for r, j in enumerate(uniq):
                 if keys[j] is not None:
                     cache[keys[j]] = enc[r]
-                    while len(cache) > 64:
+                    while len(cache) > 160:
                         cache.popitem(last=False)
                 else:
                     feats[j] = enc[r]

@@ -255,38 +255,47 @@ class VLLMEditorEvaluation:
         return out
 
     def _run_splits(self, editor, result_data, eval_data):
+        """prepare -> edit -> test -> restore per split (vllm_editor_eval.py:94-123).  Every split starts from the restored
+        model, so the pre-edit locality probes of a GROUP of consecutive splits see the same (pristine) model: with the
+        batched-probe path they go through the decoder together, ahead of the group's edits."""
         tok = editor.vllm.get_llm_tokenizer()
         bp = self._can_batch_probes(editor) and os.environ.get("DEVQA_PROBE_BATCH", "1") != "0"
+        group = max(1, int(os.environ.get("DEVQA_PREEDIT_GROUP", "16"))) if bp else 1
         editor.restore_to_original_model()
         results = []
-        for split_rd, split_ed in zip(result_data, eval_data):
-            split_res = []
-            for rd, ed in zip(split_rd, split_ed):
-                rd["reliability"] = rd.pop("requests")
-                for r in rd["reliability"]:
-                    r["target"] = r.pop("target_new")
-                if bp:
-                    pairs = [(rdl, edl) for ln in ed["locality"] for rdl, edl in zip(rd["locality"][ln], ed["locality"][ln])]
-                    outs = self._argmax_many(editor.vllm, [(e["prompt"], e["image"], e["target"]) for _, e in pairs])
-                    for (rdl, edl), (pre, _, m) in zip(pairs, outs):
-                        rdl["predict_before_edit"] = tok.decode(pre[m.to(bool)])
-                        edl["before_edit_ids"] = pre
-                    continue
-                for loc_name in ed["locality"].keys():
-                    for rdl, edl in zip(rd["locality"][loc_name], ed["locality"][loc_name]):
-                        pre, _, m = self._argmax_last(editor.vllm, edl["prompt"], edl["image"], edl["target"])
-                        rdl["predict_before_edit"] = tok.decode(pre[m.to(bool)])
-                        edl["before_edit_ids"] = pre
-            for rd, ed in zip(split_rd, split_ed):
-                for rdr, edr in zip(rd["reliability"], ed["requests"]):
-                    start_t = time()
-                    editor.edit_one_piece(edr)
-                    rdr["edit_time"] = time() - start_t
-            for rd, ed in zip(split_rd, split_ed):
-                rd = self.__get_results_after_edit__(editor.vllm, ed, rd, bp)
-                split_res.append(rd)
-            editor.restore_to_original_model()
-            results.append(split_res)
+        for g0 in range(0, len(eval_data), group):
+            grp = list(zip(result_data[g0:g0 + group], eval_data[g0:g0 + group]))
+            pairs = []
+            for split_rd, split_ed in grp:
+                for rd, ed in zip(split_rd, split_ed):
+                    rd["reliability"] = rd.pop("requests")
+                    for r in rd["reliability"]:
+                        r["target"] = r.pop("target_new")
+                    if bp:
+                        pairs += [(rdl, edl) for ln in ed["locality"] for rdl, edl in zip(rd["locality"][ln], ed["locality"][ln])]
+                        continue
+                    for loc_name in ed["locality"].keys():
+                        for rdl, edl in zip(rd["locality"][loc_name], ed["locality"][loc_name]):
+                            pre, _, m = self._argmax_last(editor.vllm, edl["prompt"], edl["image"], edl["target"])
+                            rdl["predict_before_edit"] = tok.decode(pre[m.to(bool)])
+                            edl["before_edit_ids"] = pre
+            if pairs:
+                outs = self._argmax_many(editor.vllm, [(e["prompt"], e["image"], e["target"]) for _, e in pairs])
+                for (rdl, edl), (pre, _, m) in zip(pairs, outs):
+                    rdl["predict_before_edit"] = tok.decode(pre[m.to(bool)])
+                    edl["before_edit_ids"] = pre
+            for split_rd, split_ed in grp:
+                split_res = []
+                for rd, ed in zip(split_rd, split_ed):
+                    for rdr, edr in zip(rd["reliability"], ed["requests"]):
+                        start_t = time()
+                        editor.edit_one_piece(edr)
+                        rdr["edit_time"] = time() - start_t
+                for rd, ed in zip(split_rd, split_ed):
+                    rd = self.__get_results_after_edit__(editor.vllm, ed, rd, bp)
+                    split_res.append(rd)
+                editor.restore_to_original_model()
+                results.append(split_res)
         return results
 
     # -- vllm_editor_eval.py:177-229 ------------------------------------------------------------------
