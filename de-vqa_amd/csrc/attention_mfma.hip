@@ -16,6 +16,7 @@
 //                      image with ds_read_b64_tr_b16 (4 keys x 16 channels per 16-lane group).
 // head dims that are not multiples of 32 (88, 80) are zero-padded in LDS to DHP = 96.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((address_space(3))) short4_t* lds_s4_ptr;
@@ -99,21 +100,25 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
         kcol[j] = k + h * dh + cv * 8;
         vcol[j] = v + h * dh + cv * 8;
     }
-    auto fetch = [&](int c0) {   // chunk c0 -> registers (zero beyond n_keys / dh)
+    auto fetch = [&](int c0, auto full_tag) {   // chunk c0 -> registers (zero beyond n_keys / dh)
+        constexpr bool FULLC = decltype(full_tag)::value;   // every row of the chunk is a key: no row predicate
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
             const int kidx = c0 + st_row[j];
             kreg[j] = make_uint4(0, 0, 0, 0);
             vreg[j] = kreg[j];
-            if (kidx < n_keys && st_ch[j]) {
+            if ((FULLC || kidx < n_keys) && st_ch[j]) {
                 const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);
                 kreg[j] = *reinterpret_cast<const uint4*>(kcol[j] + grow * ldk);
                 vreg[j] = *reinterpret_cast<const uint4*>(vcol[j] + grow * ldv);
             }
         }
     };
+    auto fetch_any = [&](int c0) {
+        if (c0 + AM_KC <= n_keys) fetch(c0, std::true_type{}); else fetch(c0, std::false_type{});
+    };
     const bool wave_has_rows = q0 + wave * 16 < q_len;  // waves without a query still stage K/V and hit the barriers
-    if (n_keys > 0) fetch(0);
+    if (n_keys > 0) fetch_any(0);
     for (int c0 = 0; c0 < n_keys; c0 += AM_KC) {
         __syncthreads();  // previous chunk fully consumed
 #pragma unroll
@@ -122,98 +127,105 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
             *reinterpret_cast<uint4*>(Vs + st_off[j]) = vreg[j];
         }
         __syncthreads();
-        if (c0 + AM_KC < n_keys) fetch(c0 + AM_KC);  // next chunk's loads fly under this chunk's MFMAs
+        if (c0 + AM_KC < n_keys) fetch_any(c0 + AM_KC);  // next chunk's loads fly under this chunk's MFMAs
         if (!wave_has_rows) continue;
-        const int nt = min(4, (n_keys - c0 + 15) >> 4);  // 16-key tiles of this chunk that hold a key (uniform)
+        // FULL chunks (64 keys, none hidden by the causal rule) take a branch-free instantiation of the body
+        auto body = [&](auto full_tag) {
+            constexpr bool FULLC = decltype(full_tag)::value;
+        const int nt = FULLC ? 4 : min(4, (n_keys - c0 + 15) >> 4);  // 16-key tiles of this chunk that hold a key (uniform)
 
-        // ---- S^T tiles: keys 16t + (4fq + r), query fr ----
-        float4_t st[4];
+            // ---- S^T tiles: keys 16t + (4fq + r), query fr ----
+            float4_t st[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
-            if (t >= nt) continue;
+            for (int t = 0; t < 4; ++t) {
+                st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                if (!FULLC && t >= nt) continue;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const short8_t kf = *reinterpret_cast<const short8_t*>(Ks + (16 * t + fr) * STRIDE + (32 * ks + 8 * fq) * 2);
-                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[t], 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const short8_t kf = *reinterpret_cast<const short8_t*>(Ks + (16 * t + fr) * STRIDE + (32 * ks + 8 * fq) * 2);
+                    st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[t], 0, 0, 0);
+                }
             }
-        }
-        // ---- mask, online softmax for query fr.  Scores stay unscaled: with c = scale * log2(e) > 0,
-        // softmax(scale * s) = exp2(c * s - c * max s); masking is needed only in chunks that hold a key past the end
-        // or a causally hidden key (uniform per workgroup) ----
-        const bool need_mask = (c0 + AM_KC > n_keys) || (causal && c0 + AM_KC > kp_len);
-        if (need_mask) {
+            // ---- mask, online softmax for query fr.  Scores stay unscaled: with c = scale * log2(e) > 0,
+            // softmax(scale * s) = exp2(c * s - c * max s); masking is needed only in chunks that hold a key past the end
+            // or a causally hidden key (uniform per workgroup) ----
+            const bool need_mask = !FULLC && ((c0 + AM_KC > n_keys) || (causal && c0 + AM_KC > kp_len));
+            if (need_mask) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kidx = c0 + 16 * t + 4 * fq + r;
-                    bool ok = kidx < n_keys;
-                    if (causal && kidx >= kp_len) ok = ok && (kidx - kp_len) <= qrow + causal_off;
-                    st[t][r] = ok ? st[t][r] : -INFINITY;
-                }
-        }
-        float mloc = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
-                           fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
-        mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(st[2][0], st[2][1]), fmaxf(st[2][2], st[2][3])),
-                                 fmaxf(fmaxf(st[3][0], st[3][1]), fmaxf(st[3][2], st[3][3]))));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);          // running max of the UNSCALED scores
-        float alpha = 1.f, lloc = 0.f;
-        if (m_new != -INFINITY) {
-            const float mc = m_new * sc2;
-            alpha = __builtin_amdgcn_exp2f(m_run * sc2 - mc);   // m_run = -inf -> 0
+                    for (int r = 0; r < 4; ++r) {
+                        const int kidx = c0 + 16 * t + 4 * fq + r;
+                        bool ok = kidx < n_keys;
+                        if (causal && kidx >= kp_len) ok = ok && (kidx - kp_len) <= qrow + causal_off;
+                        st[t][r] = ok ? st[t][r] : -INFINITY;
+                    }
+            }
+            float mloc = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
+                               fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
+            mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(st[2][0], st[2][1]), fmaxf(st[2][2], st[2][3])),
+                                     fmaxf(fmaxf(st[3][0], st[3][1]), fmaxf(st[3][2], st[3][3]))));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);          // running max of the UNSCALED scores
+            float alpha = 1.f, lloc = 0.f;
+            if (m_new != -INFINITY) {
+                const float mc = m_new * sc2;
+                alpha = __builtin_amdgcn_exp2f(m_run * sc2 - mc);   // m_run = -inf -> 0
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], sc2, -mc));   // masked (-inf) -> 0
-                    st[t][r] = p;
-                    lloc += p;
-                }
-        } else {
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], sc2, -mc));   // masked (-inf) -> 0
+                        st[t][r] = p;
+                        lloc += p;
+                    }
+            } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        }
-        lloc += __shfl_xor(lloc, 16, 64);
-        lloc += __shfl_xor(lloc, 32, 64);
-        l_run = l_run * alpha + lloc;
-        m_run = m_new;
-        // ---- P fragments (A operand of O = P.V): k order = (tile 2s: r 0..3, tile 2s+1: r 0..3) ----
-        short8_t pf[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            uint4 u;
-            u.x = am_pack2(st[2 * s2][0], st[2 * s2][1]);
-            u.y = am_pack2(st[2 * s2][2], st[2 * s2][3]);
-            u.z = am_pack2(st[2 * s2 + 1][0], st[2 * s2 + 1][1]);
-            u.w = am_pack2(st[2 * s2 + 1][2], st[2 * s2 + 1][3]);
-            pf[s2] = *reinterpret_cast<short8_t*>(&u);
-        }
-        // ---- rescale O: its rows are queries 4fq + r, whose alpha lives in lane (fr' = 4fq + r) ----
-        float ar[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * fq + r, 64);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
-        // ---- O += P.V with transposed LDS reads of the row-major V image ----
-        const int tq = fr >> 2, tp = fr & 3;  // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
+                for (int t = 0; t < 4; ++t) st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            }
+            lloc += __shfl_xor(lloc, 16, 64);
+            lloc += __shfl_xor(lloc, 32, 64);
+            l_run = l_run * alpha + lloc;
+            m_run = m_new;
+            // ---- P fragments (A operand of O = P.V): k order = (tile 2s: r 0..3, tile 2s+1: r 0..3) ----
+            short8_t pf[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                if (2 * s2 >= nt) continue;   // both key tiles of this k-step are past the last key (P = 0 there)
-                const short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_s4_ptr)(Vs + (16 * (2 * s2) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
-                const short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_s4_ptr)(Vs + (16 * (2 * s2 + 1) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
-                const short8_t vf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[s2], vf, o[dt], 0, 0, 0);
+                uint4 u;
+                u.x = am_pack2(st[2 * s2][0], st[2 * s2][1]);
+                u.y = am_pack2(st[2 * s2][2], st[2 * s2][3]);
+                u.z = am_pack2(st[2 * s2 + 1][0], st[2 * s2 + 1][1]);
+                u.w = am_pack2(st[2 * s2 + 1][2], st[2 * s2 + 1][3]);
+                pf[s2] = *reinterpret_cast<short8_t*>(&u);
             }
-        }
+            // ---- rescale O: its rows are queries 4fq + r, whose alpha lives in lane (fr' = 4fq + r) ----
+            float ar[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * fq + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
+            // ---- O += P.V with transposed LDS reads of the row-major V image ----
+            const int tq = fr >> 2, tp = fr & 3;  // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (!FULLC && 2 * s2 >= nt) continue;   // both key tiles of this k-step are past the last key (P = 0 there)
+                    const short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (lds_s4_ptr)(Vs + (16 * (2 * s2) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
+                    const short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (lds_s4_ptr)(Vs + (16 * (2 * s2 + 1) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
+                    const short8_t vf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[s2], vf, o[dt], 0, 0, 0);
+                }
+            }
+        };
+        // ... also causal chunks that lie entirely at or below the diagonal of this tile's FIRST query (visible to all its rows)
+        const bool all_visible = !causal || c0 + AM_KC <= kp_len || (c0 + AM_KC - 1 - kp_len) <= q0 + causal_off;
+        if (c0 + AM_KC <= n_keys && all_visible) body(std::true_type{}); else body(std::false_type{});
     }
 
     // ---- normalise and store: O row = query 4fq + r, column = channel 16dt + fr ----
