@@ -255,9 +255,6 @@ int launch_gemm_glds_64x128(const bf16_t*, int64_t, const bf16_t*, int64_t, cons
                             bf16_t*, float*, int64_t, hipStream_t);
 int launch_gemm_glds_128x128(const bf16_t*, int64_t, const bf16_t*, int64_t, const float*, int, int, int, float, int, const float*,
                              bf16_t*, float*, int64_t, hipStream_t);
-int launch_gemm_glds_256x128(const bf16_t*, int64_t, const bf16_t*, int64_t, const float*, int, int, int, float, int, const float*,
-                             bf16_t*, float*, int64_t, hipStream_t);
-
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N,
                        int K, float alpha, int act, const float* residual, bf16_t* out_bf16, float* out_f32,

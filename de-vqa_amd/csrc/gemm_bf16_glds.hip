@@ -148,170 +148,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// 3-stage variant for ~1 workgroup/CU tiles (256x128, 8 waves): TWO tiles stay in flight across the
-// barrier.  A tile needs (BM+BN)*128 B per 2*BM*BN*64 FLOP; at 256x128 that is 48 KiB per step, and with
-// ~1 us of L2/HBM latency a CU must keep > 64 KiB in flight to feed its MFMAs -- one stage ahead is not
-// enough.  Waits are COUNTED (s_waitcnt vmcnt(IPW) leaves the newest tile's IPW LDS-DMA ops in flight) and
-// the barrier is the raw s_barrier: __syncthreads() would drain vmcnt(0).  A staged buffer is read only
-// in the iteration after the wait+barrier that retired it; it is refilled only after the barrier that
-// follows its last read.
-// ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds3_kernel(
-    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-    const float* __restrict__ bias, int M, int N, int K, float alpha, int act, const float* residual,
-    bf16_t* out_bf16, float* out_f32, int64_t ldc, int tiles_m, int tiles_n) {
-    constexpr int NW = WM * WN;
-    constexpr int TM = BM / WM / 16;
-    constexpr int TN = BN / WN / 16;
-    constexpr int SLOTS = (BM + BN) / 8;
-    constexpr int IPW = SLOTS / NW;
-    static_assert(SLOTS % NW == 0, "tile rows must split evenly over the waves");
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_m = bid % tiles_m;
-    const int tile_n = bid / tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int fr = lane & 15, fq = lane >> 4;
-
-    const bf16_t* src[IPW];
-#pragma unroll
-    for (int i = 0; i < IPW; ++i) {
-        const int s = wave * IPW + i;
-        const int row = s * 8 + (lane >> 3);
-        const int pc = lane & 7;
-        if (s * 8 < BM) {
-            const int c = pc ^ ((row >> 1) & 7);
-            src[i] = A + (int64_t)min(m0 + row, M - 1) * lda + c * 8;
-        } else {
-            const int rb = row - BM;
-            const int c = pc ^ ((rb >> 1) & 7);
-            src[i] = W + (int64_t)min(n0 + rb, N - 1) * ldw + c * 8;
-        }
-    }
-    auto issue = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            const int s = wave * IPW + i;
-            __builtin_amdgcn_global_load_lds((gptr_t)src[i], (lptr_t)(smem + stage * STAGE_BYTES + s * 1024), 16, 0, 0);
-            src[i] += GBK;
-        }
-    };
-
-    float4_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / GBK;
-    issue(0);
-    if (nk > 1) {
-        issue(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");  // tile 0 landed, tile 1 in flight
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-
-    int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int nxt2 = stage == 0 ? 2 : stage - 1;  // (stage + 2) % 3
-        if (kt + 2 < nk) issue(nxt2);                 // refills the buffer read in iteration kt-1 (all waves passed its barrier)
-        const unsigned char* sa = smem + stage * STAGE_BYTES;
-        const unsigned char* sb = sa + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < GBK / 32; ++ks) {
-            short8_t af[TM], bfr[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * (BM / WM) + i * 16 + fr;
-                const int c = ks * 4 + fq;
-                af[i] = *reinterpret_cast<const short8_t*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn * (BN / WN) + j * 16 + fr;
-                const int c = ks * 4 + fq;
-                bfr[j] = *reinterpret_cast<const short8_t*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        // tile kt+1 must have landed before anyone reads it; tile kt+2 (just issued) may stay in flight
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        stage = stage == 2 ? 0 : stage + 1;
-    }
-
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + fr;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
-            if (n >= N) continue;
-            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            if (bias) {
-                const float4 b = *reinterpret_cast<const float4*>(bias + n);
-                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-            }
-            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
-            v = devqa_act4(v, act);
-            const int64_t o = (int64_t)m * ldc + n;
-            if (residual) {
-                const float4 r = *reinterpret_cast<const float4*>(residual + o);
-                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-            }
-            if (out_f32) *reinterpret_cast<float4*>(out_f32 + o) = v;
-            if (out_bf16) {
-                uint2 p;
-                p.x = pack_bf16x2(v.x, v.y);
-                p.y = pack_bf16x2(v.z, v.w);
-                *reinterpret_cast<uint2*>(out_bf16 + o) = p;
-            }
-        }
-    }
-}
-
-template <int BM, int BN, int WM, int WN>
-static int launch_glds3(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K,
-                        float alpha, int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc,
-                        hipStream_t st) {
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const size_t smem = 3 * (BM + BN) * 128;
-    auto kern = gemm_bf16_glds3_kernel<BM, BN, WM, WN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), smem, st, A, lda, W, ldw, bias, M, N, K, alpha, act,
-                       residual, out_bf16, out_f32, ldc, tiles_m, tiles_n);
-    DEVQA_LAUNCH_CHECK("gemm_bf16_glds3");
-    return DEVQA_OK;
-}
-
 template <int BM, int BN, int WM, int WN>
 static int launch_glds(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K,
                        float alpha, int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc,
@@ -340,9 +176,4 @@ int launch_gemm_glds_64x128(const bf16_t* A, int64_t lda, const bf16_t* W, int64
                             float alpha, int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc,
                             hipStream_t st) {
     return launch_glds<64, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
-}
-int launch_gemm_glds_256x128(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K,
-                             float alpha, int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc,
-                             hipStream_t st) {
-    return launch_glds3<256, 128, 4, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
 }
