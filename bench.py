@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cycles-per-step", type=int, default=20)
+    ap.add_argument("--cycles-per-step", type=int, default=60)
     ap.add_argument("--seed", type=int, default=20251121)
     ap.add_argument("--layers", type=str, default=None, help="debug only: 'v,q,t' layer counts (INVALID as a benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

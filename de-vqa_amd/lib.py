@@ -109,17 +109,21 @@ EXPORTS = ["devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_ro
 
 def gemm_rows_longk(a, w):
     """fp32 [M,N] = a[M,K] @ w[N,K].T for a few rows and a very long K (dH = dlogits . E): split-K on the
-    bf16 MFMA kernel when M <= 64, else the plain GEMM (fp32 operands: exact-fp32 GEMM)."""
-    if a.dtype != torch.bfloat16 or a.shape[0] > 64:
+    bf16 MFMA kernel in row groups of <= 64 (fp32 operands: exact-fp32 GEMM)."""
+    if a.dtype != torch.bfloat16:
         return gemm(a, w, want="f32")
     M, K = a.shape
     N = w.shape[0]
+    if M > 256:
+        return gemm(a, w, want="f32")
     nk = (K + 63) // 64
     splits = max(1, min(nk, 640 // max(1, (N + 127) // 128)))
-    ws = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    _chk(load().devqa_gemm_bf16_splitk(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, splits, _p(ws), _p(out), _stream()),
-         "devqa_gemm_bf16_splitk")
+    ws = torch.empty((splits, min(M, 64), N), dtype=torch.float32, device=a.device)
+    for r0 in range(0, M, 64):
+        m = min(64, M - r0)
+        _chk(load().devqa_gemm_bf16_splitk(_p(a[r0:r0 + m]), a.stride(0), _p(w), w.stride(0), m, N, K, splits, _p(ws), _p(out[r0:r0 + m]),
+                                           _stream()), "devqa_gemm_bf16_splitk")
     return out
 
 
