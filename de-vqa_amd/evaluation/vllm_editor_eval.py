@@ -45,12 +45,13 @@ class VLLMEditorEvaluation:
         return pre.to(torch.long).unsqueeze(0), y, m
 
     @staticmethod
-    def _argmax_many(vllm, probes, max_rows=12288):
+    def _argmax_many(vllm, probes, max_rows=12288, prefix_fn=None):
         """[(prompt, image, target)] -> [(pre, y, m)], same values as _argmax_last per probe, but the probes of one
         evaluation phase (the model does not change inside a phase: 9 locality probes per sample before the edit, 12
         after, vllm_editor_eval.py:98-121) go through the decoder TOGETHER: inputs are built per probe through the
         plugin API (so editor hooks on get_llm_input_embeds still apply), right-padded into one batch, the decoder runs
-        once and logits are computed on the label rows only."""
+        once and logits are computed on the label rows only.  `prefix_fn(prompt, image, target)` (retrieval editors: LTE_VL's
+        `probe_prefix`) may return rows to put in front of a probe's input; label rows are the LAST L, so nothing else moves."""
         from .. import lib
         eng = vllm.engine
         out = [None] * len(probes)
@@ -62,7 +63,11 @@ class VLLMEditorEvaluation:
         for i, (prompt, image, target) in enumerate(probes):
             (x, vt), y, m = vllm.prompts_imgs_target_to_xym([prompt], [image], [target])
             assert len(y) == 1 and len(m) == 1
-            items.append((i, x["inputs_embeds"][0], y, m))
+            e = x["inputs_embeds"][0]
+            pfx = prefix_fn(prompt, image, target) if prefix_fn is not None else None
+            if pfx is not None:
+                e = torch.cat([pfx.to(e.dtype), e], 0)
+            items.append((i, e, y, m))
         start = 0
         while start < len(items):
             end, tmax = start, 0
@@ -96,22 +101,23 @@ class VLLMEditorEvaluation:
     @staticmethod
     def _can_batch_probes(editor):
         """Probe batching needs the native engine interface and an editor that does not read the per-probe
-        `query_triple` / `query_range` keys inside get_llm_outpt (retrieval editors such as LTE_VL do)."""
+        `query_triple` / `query_range` keys inside get_llm_outpt -- unless it offers the same decision as `probe_prefix`
+        (LTE_VL does)."""
         eng = getattr(editor.vllm, "engine", None)
         return (eng is not None and hasattr(eng, "pack_from_embeds") and hasattr(eng, "lm_head")
-                and not getattr(editor, "reads_query_hook", False))
+                and (not getattr(editor, "reads_query_hook", False) or hasattr(editor, "probe_prefix")))
 
     @staticmethod
     def _acc(pre_y, label_ids, label_masks):
         return float(((pre_y == label_ids) * label_masks).sum() / label_masks.sum())
 
-    def __get_results_after_edit__(self, vllm, ed, rd, batch_probes=False):
+    def __get_results_after_edit__(self, vllm, ed, rd, batch_probes=False, prefix_fn=None):
         tok = vllm.get_llm_tokenizer()
         if batch_probes:
             probes = [(e["prompt"], e["image"], e["target_new"]) for e in ed["requests"]]
             probes += [(e["prompt"], e["image"], e["target"]) for g in ed["generality"] for e in ed["generality"][g]]
             probes += [(e["prompt"], e["image"], e["target"]) for l in ed["locality"] for e in ed["locality"][l]]
-            res = iter(self._argmax_many(vllm, probes))
+            res = iter(self._argmax_many(vllm, probes, prefix_fn=prefix_fn))
             for rdr in rd["reliability"]:
                 pre, y, m = next(res)
                 rdr["predict_after_edit"] = tok.decode(pre[m.to(bool)])
@@ -261,6 +267,7 @@ class VLLMEditorEvaluation:
         tok = editor.vllm.get_llm_tokenizer()
         bp = self._can_batch_probes(editor) and os.environ.get("DEVQA_PROBE_BATCH", "1") != "0"
         group = max(1, int(os.environ.get("DEVQA_PREEDIT_GROUP", "16"))) if bp else 1
+        pfx = getattr(editor, "probe_prefix", None) if bp else None
         editor.restore_to_original_model()
         results = []
         for g0 in range(0, len(eval_data), group):
@@ -280,7 +287,7 @@ class VLLMEditorEvaluation:
                             rdl["predict_before_edit"] = tok.decode(pre[m.to(bool)])
                             edl["before_edit_ids"] = pre
             if pairs:
-                outs = self._argmax_many(editor.vllm, [(e["prompt"], e["image"], e["target"]) for _, e in pairs])
+                outs = self._argmax_many(editor.vllm, [(e["prompt"], e["image"], e["target"]) for _, e in pairs], prefix_fn=pfx)
                 for (rdl, edl), (pre, _, m) in zip(pairs, outs):
                     rdl["predict_before_edit"] = tok.decode(pre[m.to(bool)])
                     edl["before_edit_ids"] = pre
@@ -292,7 +299,7 @@ class VLLMEditorEvaluation:
                         editor.edit_one_piece(edr)
                         rdr["edit_time"] = time() - start_t
                 for rd, ed in zip(split_rd, split_ed):
-                    rd = self.__get_results_after_edit__(editor.vllm, ed, rd, bp)
+                    rd = self.__get_results_after_edit__(editor.vllm, ed, rd, bp, pfx)
                     split_res.append(rd)
                 editor.restore_to_original_model()
                 results.append(split_res)

@@ -88,4 +88,7 @@ def load_vllm_editor(editor_name: str, edit_model_name: str, device, extra_devic
     if editor_name == "tp_vl":   # needs locality_texts=[...] or locality_data_path=<text file> (the reference reads wikitext)
         from ..editor.vllm_editors.tp_vl.tp_vl import TPvl, TPvlConfig
         return TPvl(vllm, TPvlConfig.from_yaml(config_path), device, **editor_kwargs)
+    if editor_name == "lte_vl":  # needs encode=callable (the reference loads sentence_transformers' multi-qa-mpnet-base-dot-v1)
+        from ..editor.vllm_editors.lte_vl.lte_vl import LTEvl, LTEvlConfig
+        return LTEvl(vllm, LTEvlConfig.from_yaml(config_path), device, **editor_kwargs)
     raise RuntimeError("No such editor %s" % editor_name)

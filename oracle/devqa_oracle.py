@@ -368,6 +368,7 @@ def split_data(data, edit_n):  # vllm_editor_eval.py:74-87 (incomplete tail drop
 
 def _acc_pred(model, prompt, image, target, labels_override=None):
     (x, vt), y, m = model.prompts_imgs_target_to_xym([prompt], [image], [target])
+    x["query_triple"] = (prompt, image, target)   # dynamic-eval hook read by retrieval editors (vllm_editor_eval.py:140)
     logits = model.get_llm_outpt(x, vt)
     pre = torch.softmax(logits, -1).argmax(-1)[:, -y.shape[1]:]
     lab = y if labels_override is None else labels_override

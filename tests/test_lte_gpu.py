@@ -1,0 +1,181 @@
+"""GPU: LTE_VL (inference path) on the HIP engine against the CPU oracle (oracle/lte_oracle.py; composition parity
+unpinned, see its header) on the tiny BLIP-2, LLaVA and MiniGPT-4: stored prefixes and retrieval pool, per-probe hook logits on
+both sides of the threshold, batched probe path == per-probe hook, evaluator == oracle evaluator, weights untouched."""
+import json
+import os
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+from lte_common import DIM, bow_encode
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(name):
+    from devqa_amd.editor.vllm_editors.lte_vl.lte_vl import LTEvlConfig
+    from devqa_amd.utils import get_editor_config_path
+    return LTEvlConfig.from_yaml(get_editor_config_path("lte_vl", name))
+
+
+@pytest.fixture(scope="module", params=["blip2-fp32", "blip2-bf16", "llava-fp32", "minigpt4-fp32"])
+def lte(gold_dir, request):
+    import devqa_amd  # noqa: F401
+    from devqa_amd.editor.vllm_editors.lte_vl.lte_vl import LTEvl
+    from oracle.lte_oracle import OracleLTEvl
+    fam, mode = request.param.split("-")
+    if fam == "blip2":
+        from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+        from oracle.devqa_oracle import OracleBlip2
+        vllm = BLIP2OPTForEdit(os.path.join(gold_dir, "tiny_blip2"), "cuda:0", dtype=mode)
+        om = OracleBlip2.from_pretrained_dir(os.path.join(gold_dir, "tiny_blip2"))
+        cfg = _cfg("blip2")
+    elif fam == "minigpt4":     # seeded tiny model, as in tests/test_minigpt4_gpu.py
+        from transformers import AutoTokenizer
+        from devqa_amd import minigpt4_spec as S
+        from devqa_amd.synth import param_init
+        from devqa_amd.editor.vllms_for_edit.minigpt4.minigpt4 import MiniGPT4ForEdit
+        from devqa_amd.editor.vllms_for_edit.minigpt4.modeling import MiniGPT4Native
+        from oracle.devqa_oracle import OracleTokenizer
+        from oracle.minigpt4_oracle import OracleMiniGPT4
+        mcfg = S.TINY_MINIGPT4
+        model = MiniGPT4Native.from_synth(mcfg, 31, "unit", "cuda:0", mode)
+        tok = AutoTokenizer.from_pretrained(os.path.join(gold_dir, "tiny_llava"))
+        vllm = MiniGPT4ForEdit(None, "cuda:0", True, model=model, tokenizer=tok, dtype=mode)
+        w = {n: torch.from_numpy(param_init(n, s_, 31, "unit")) for n, s_ in S.param_shapes(mcfg).items()}
+        otok = OracleTokenizer(os.path.join(gold_dir, "tiny_llava", "tokenizer.json"), mcfg["text_config"]["pad_token_id"])
+        om = OracleMiniGPT4(w, mcfg, otok)
+        cfg = _cfg("minigpt4")
+    else:
+        from devqa_amd.editor.vllms_for_edit.llava.llava import LlavaForEdit
+        from oracle.llava_oracle import OracleLlava
+        vllm = LlavaForEdit(os.path.join(gold_dir, "tiny_llava"), "cuda:0", True, dtype=mode)
+        om = OracleLlava.from_pretrained_dir(os.path.join(gold_dir, "tiny_llava"))
+        cfg = _cfg("llava")
+    assert cfg.sim_threshold == 0.3 and cfg.retrieval_embed_dim == DIM
+    ed = LTEvl(vllm, cfg, "cuda:0", encode=bow_encode)
+    oed = OracleLTEvl(om, bow_encode, cfg.sim_threshold, cfg.retrieval_embed_dim)
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))["records"]
+    return vllm, ed, om, oed, rec, mode
+
+
+def _rel(a, g):
+    return float(np.abs(a - g).max() / max(np.abs(g).max(), 1e-30))
+
+
+def test_lte_needs_encoder(lte):
+    from devqa_amd.editor.vllm_editors.lte_vl.lte_vl import LTEvl
+    vllm, ed = lte[0], lte[1]
+    with pytest.raises(RuntimeError):
+        LTEvl(vllm, ed.cfg, "cuda:0")
+    ed.wrap_get_llm_outpt()     # the failed constructor never reached the hook; re-wrapping keeps ONE layer over the original
+    assert ed.name_of_editor_and_model()[0] == "lte_vl" and not ed.if_can_batch_edit()
+    with pytest.raises(NotImplementedError):
+        ed.set_train(True)
+
+
+def test_lte_edits_and_hook(lte, in_gold_dir):
+    vllm, ed, om, oed, rec, mode = lte
+    tol = 1e-3 if mode == "fp32" else 6e-2
+    w_before = {n: p.clone() for n, p in vllm.model.named_parameters()}
+    ed.restore_to_original_model()
+    oed.restore_to_original_model()
+    reqs = [rec[0]["requests"][0], rec[1]["requests"][0]]
+    probes = [(reqs[0]["prompt"], reqs[0]["image"], reqs[0]["target_new"]),
+              (reqs[1]["prompt"], reqs[1]["image"], reqs[1]["target_new"]),
+              ("zzqx vvk", reqs[0]["image"], "yes")]
+    probes += [(e["prompt"], e["image"], e["target"]) for g in rec[0]["generality"] for e in rec[0]["generality"][g]]
+    probes += [(e["prompt"], e["image"], e["target"]) for l in rec[0]["locality"] for e in rec[0]["locality"][l]][:4]
+
+    def hip_logits(p):
+        (x, vt), y, m = vllm.prompts_imgs_target_to_xym([p[0]], [p[1]], [p[2]])
+        x["query_triple"] = p
+        return vllm.get_llm_outpt(x, vt).logits.float().cpu().numpy(), x, y, m
+
+    def cpu_logits(p):
+        with torch.no_grad():
+            (x, vt), y, m = om.prompts_imgs_target_to_xym([p[0]], [p[1]], [p[2]])
+            x["query_triple"] = p
+            return om.get_llm_outpt(x, vt).numpy()
+    pre = [hip_logits(p)[0] for p in probes]            # empty pool: plain path
+    for r in reqs:
+        ed.edit_one_piece(deepcopy(r))
+        with torch.no_grad():
+            oed.edit_one_piece(deepcopy(r))
+    assert len(ed.edit_requests_pool) == 2 and tuple(ed.text_retr_pool.shape) == (2, DIM)
+    np.testing.assert_array_equal(ed.text_retr_pool.cpu().numpy(), oed.pool.numpy())
+    for a, b in zip(ed.edit_prefix_pool, oed.prefixes):
+        assert a["attention_mask"].cpu().tolist() == b["attention_mask"].tolist()
+        assert _rel(a["inputs_embeds"].float().cpu().numpy(), b["inputs_embeds"].numpy()) < tol
+    n_pref = 0
+    for p, l0 in zip(probes, pre):
+        got, x, y, m = hip_logits(p)
+        want = cpu_logits(p)
+        _, pf, sim = ed.retrieval([p[0]])
+        _, opf, osim = oed.retrieval([p[0]])
+        assert (pf[0] is None) == (opf is None)
+        np.testing.assert_allclose(sim.cpu().numpy().ravel()[0], float(osim.max()), atol=1e-5)
+        assert got.shape == want.shape == l0.shape          # prefix rows are dropped
+        assert _rel(got, want) < tol, (p[0], _rel(got, want))
+        if pf[0] is None:
+            np.testing.assert_array_equal(got, l0)          # below the threshold: exactly the unedited path
+        else:
+            n_pref += 1
+            assert _rel(got, l0) > 10 * tol or mode != "fp32"
+        # the batched probe path takes the same decision and yields the same predictions as the hook
+        from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation as E
+        (pb, yb, mb), = E._argmax_many(vllm, [p], prefix_fn=ed.probe_prefix)
+        ph, yh, mh = E._argmax_last(vllm, *p)
+        assert yb.tolist() == yh.tolist() and mb.tolist() == mh.tolist()
+        if mode == "fp32":
+            assert pb.tolist() == ph.tolist() == torch.from_numpy(want).argmax(-1)[:, -yh.shape[1]:].tolist()
+    assert 2 <= n_pref < len(probes)                        # both branches were exercised
+    ed.restore_to_original_model()
+    oed.restore_to_original_model()
+    for p, l0 in zip(probes[:3], pre[:3]):
+        np.testing.assert_array_equal(hip_logits(p)[0], l0)
+    for n, p_ in vllm.model.named_parameters():
+        assert torch.equal(p_, w_before[n])
+
+
+def test_lte_evaluator(lte, in_gold_dir, tmp_path):
+    from oracle import devqa_oracle as O
+    from devqa_amd.dataset.vllm import BaseVLLMEditData
+    from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation
+    vllm, ed, om, oed, rec, mode = lte
+
+    class Data(BaseVLLMEditData):
+        def dataset_name(self):
+            return "EVQA"
+    n = 4
+    ev = VLLMEditorEvaluation(ed, Data(deepcopy(rec[:n]), deepcopy(rec[:n])), "EVQA", str(tmp_path))
+    assert ev._can_batch_probes(ed)
+    res = ev.evaluate_sequential_edit(1, False, None)
+    os.environ["DEVQA_PROBE_BATCH"] = "0"
+    try:
+        res_hook = ev.evaluate_sequential_edit(1, False, None)      # per-probe get_llm_outpt hook, the reference's call order
+    finally:
+        del os.environ["DEVQA_PROBE_BATCH"]
+    with torch.no_grad():
+        ores, _ = O.evaluate_sequential_edit(om, oed, rec[:n], 1)
+    assert len(res) == len(res_hook) == len(ores) == n
+
+    def accs(r):
+        d = r[0]
+        return ([x["acc"] for x in d["reliability"]] + [x["acc"] for g in d["generality"] for x in d["generality"][g]]
+                + [x["acc"] for l in d["locality"] for x in d["locality"][l]])
+
+    def preds(r):
+        d = r[0]
+        return ([x["predict_after_edit"] for x in d["reliability"]] + [x["predict_after_edit"] for g in d["generality"] for x in d["generality"][g]]
+                + [x["predict_before_edit"] + "|" + x["predict_after_edit"] for l in d["locality"] for x in d["locality"][l]])
+    for a, b, c in zip(res, res_hook, ores):
+        if mode == "fp32":
+            assert preds(a) == preds(b) == preds(c)
+            assert accs(a) == pytest.approx(accs(c), abs=1e-6) and accs(b) == pytest.approx(accs(c), abs=1e-6)
+        else:
+            assert len(accs(a)) == len(accs(c))
+    d = os.path.join(str(tmp_path), "lte_vl", ed.cfg.edit_model_name, "EVQA", "sequential_edit_1")
+    assert os.path.exists(os.path.join(d, "mean_results.json"))

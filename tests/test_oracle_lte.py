@@ -1,0 +1,62 @@
+"""CPU: the LTE_VL oracle (oracle/lte_oracle.py) on the tiny BLIP-2 -- hook pass-through with an empty pool, prefix
+retrieval on both sides of the threshold, arg-max among several edits, prefix rows dropped, restore, and the oracle
+evaluator driving it.  The composition is PARITY UNPINNED (see the oracle's header); its parts are pinned elsewhere."""
+import json
+import os
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from lte_common import DIM, bow_encode
+
+
+def _model(gold_dir):
+    from oracle.devqa_oracle import OracleBlip2
+    return OracleBlip2.from_pretrained_dir(os.path.join(gold_dir, "tiny_blip2"))
+
+
+def test_lte_oracle(gold_dir, in_gold_dir):
+    from oracle import devqa_oracle as O
+    from oracle.lte_oracle import OracleLTEvl
+    model = _model(gold_dir)
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))["records"]
+    ed = OracleLTEvl(model, bow_encode, 0.3, DIM)
+    r0, r1 = rec[0]["requests"][0], rec[1]["requests"][0]
+
+    def logits(prompt, image, target):
+        (x, vt), y, m = model.prompts_imgs_target_to_xym([prompt], [image], [target])
+        x["query_triple"] = (prompt, image, target)
+        return model.get_llm_outpt(x, vt), x
+
+    with torch.no_grad():
+        plain, x0 = logits(r0["prompt"], r0["image"], r0["target_new"])
+        assert torch.equal(plain, ed.plain_get_llm_outpt(x0, None))            # empty pool: pass-through
+        ed.edit_one_piece(deepcopy(r0))
+        ed.edit_one_piece(deepcopy(r1))
+        assert ed.pool.shape == (2, DIM) and len(ed.prefixes) == 2
+        for i, r in enumerate((r0, r1)):                                       # the edit's own prompt retrieves its own prefix
+            req, pfx, sim = ed.retrieval([r["prompt"]])
+            assert req is ed.requests[i] and int(sim.argmax()) == i and float(sim.max()) > 0.3
+        got, x = logits(r0["prompt"], r0["image"], r0["target_new"])
+        P = ed.prefixes[0]["inputs_embeds"].shape[1]
+        cat = {"inputs_embeds": torch.cat([ed.prefixes[0]["inputs_embeds"], x["inputs_embeds"]], 1),
+               "attention_mask": torch.cat([ed.prefixes[0]["attention_mask"], x["attention_mask"]], 1)}
+        want = ed.plain_get_llm_outpt(cat, None)[:, P:]
+        assert got.shape == plain.shape and torch.equal(got, want) and not torch.allclose(got, plain)
+        # the prefix carries the edit's image tokens and the two signs
+        n_img = model.cfg["num_query_tokens"]
+        txt = ed.edit_sign + r0["prompt"] + " " + r0["target_new"] + ed.query_sign
+        assert P == n_img + len(model.tok.encode(txt))
+        # an unrelated prompt stays below the threshold -> plain path
+        far = "zzqx vvk"
+        assert ed.retrieval([far])[0] is None
+        lf, xf = logits(far, r0["image"], "yes")
+        assert torch.equal(lf, ed.plain_get_llm_outpt(xf, None))
+        ed.restore_to_original_model()
+        assert ed.pool.shape == (0, DIM) and torch.equal(logits(r0["prompt"], r0["image"], r0["target_new"])[0], plain)
+    # through the oracle evaluator: in-context edits must not lower reliability on the tiny model
+    res, ns = O.evaluate_sequential_edit(model, ed, rec[:2], 1)
+    assert ns == [1, 1] and len(res) == 2 and 0.0 <= res[0][0]["reliability"][0]["acc"] <= 1.0
+    ed.unhook()
+    assert "get_llm_outpt" not in model.__dict__
