@@ -399,6 +399,148 @@ __global__ __launch_bounds__(256) void tp_neuron_bwd_kernel(const float* __restr
     }
 }
 
+// ---- gated variant (LLaMA FFN: down(silu(gate(x)) * up(x)); R/configs/tp_vl/llava-v1.5-7b.yaml patches gate_proj AND up_proj) ----
+// The new neuron has two keys K2 = [k_gate; k_up] [2,d], biases B2 [2] and a value v [d_out]:
+//   pg = h.k_gate + b_gate, pu = h.k_up + b_up, act = silu(pg) * pu, y[r] = ybase[r] + act[lab[r]] * v.
+// The reference sums loss_a and loss_m over the in-layers (tp_vl.py:166-177): loss_a = mean exp(-pg) + mean exp(-pu), same for loss_m.
+// pre: [2,T] (gate row, up row); scratch: [2,T + Tm] laid out as dpg[T] | dpu[T] | dpmg[Tm] | dpmu[Tm].
+__device__ __forceinline__ float tp_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void tp_gated_fwd_kernel(const float* __restrict__ h, int T, int d, const float* __restrict__ K2,
+                                                           const float* __restrict__ B2, const int32_t* __restrict__ lab, int L,
+                                                           const float* __restrict__ v, const float* __restrict__ ybase, int d_out,
+                                                           float* __restrict__ pre, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < T; t += 4) {
+        float ag = 0.f, au = 0.f;
+        for (int c = lane; c < d; c += 64) {
+            const float hv = h[(int64_t)t * d + c];
+            ag += hv * K2[c];
+            au += hv * K2[d + c];
+        }
+        ag = wave_sum(ag);
+        au = wave_sum(au);
+        if (lane == 0) {
+            pre[t] = ag + B2[0];
+            pre[T + t] = au + B2[1];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * d_out; i += 256) {
+        const int r = i / d_out, c = i - r * d_out;
+        const float pg = pre[lab[r]], pu = pre[T + lab[r]];
+        y[i] = ybase[i] + pg * tp_sigmoid(pg) * pu * v[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void tp_gated_bwd_kernel(const float* __restrict__ h, const float* __restrict__ pre, int T, int d,
+                                                           const int32_t* __restrict__ lab, int L, const float* __restrict__ dy,
+                                                           int d_out, const float* __restrict__ hm, int Tm, const float* __restrict__ K2,
+                                                           const float* __restrict__ B2, const float* __restrict__ v, float la, float lm,
+                                                           float wd, float* __restrict__ scratch, float* __restrict__ GK2,
+                                                           float* __restrict__ GB2, float* __restrict__ gv, float* __restrict__ losses) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* dpg = scratch;
+    float* dpu = scratch + T;
+    float* dpmg = scratch + 2 * T;
+    float* dpmu = scratch + 2 * T + Tm;
+    float la_acc = 0.f, lm_acc = 0.f;
+    for (int t = tid; t < T; t += 256) {
+        const float eg = expf(-pre[t]), eu = expf(-pre[T + t]);
+        la_acc += eg + eu;
+        dpg[t] = -la * eg / (float)T;
+        dpu[t] = -la * eu / (float)T;
+    }
+    for (int t = wave; t < Tm; t += 4) {
+        float ag = 0.f, au = 0.f;
+        for (int c = lane; c < d; c += 64) {
+            const float hv = hm[(int64_t)t * d + c];
+            ag += hv * K2[c];
+            au += hv * K2[d + c];
+        }
+        ag = wave_sum(ag) + B2[0];
+        au = wave_sum(au) + B2[1];
+        if (lane == 0) {
+            const float eg = expf(ag > 0.f ? ag : 0.f), eu = expf(au > 0.f ? au : 0.f);
+            dpmg[t] = ag > 0.f ? lm * eg / (float)Tm : 0.f;
+            dpmu[t] = au > 0.f ? lm * eu / (float)Tm : 0.f;
+            lm_acc += eg + eu;
+        }
+    }
+    __syncthreads();
+    for (int r = wave; r < L; r += 4) {     // label rows: dact = dy[r] . v;  dpg += dact * silu'(pg) * pu;  dpu += dact * silu(pg)
+        float acc = 0.f;
+        for (int c = lane; c < d_out; c += 64) acc += dy[(int64_t)r * d_out + c] * v[c];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float pg = pre[lab[r]], pu = pre[T + lab[r]], sg = tp_sigmoid(pg);
+            atomicAdd(&dpg[lab[r]], acc * sg * (1.f + pg * (1.f - sg)) * pu);
+            atomicAdd(&dpu[lab[r]], acc * pg * sg);
+        }
+    }
+    la_acc = wave_sum(la_acc);
+    lm_acc = wave_sum(lm_acc);
+    if (lane == 0) red[wave] = la_acc;
+    __syncthreads();
+    const float la_tot = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    if (lane == 0) red[wave] = lm_acc;
+    __syncthreads();
+    const float lm_tot = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) {
+        losses[0] = la_tot / (float)T;
+        losses[1] = lm_tot / (float)Tm;
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * d; c += 256) {
+        const int which = c >= d, cc = c - which * d;
+        const float* dp = which ? dpu : dpg;
+        const float* dm = which ? dpmu : dpmg;
+        float acc = wd * K2[c];
+        for (int t = 0; t < T; ++t) acc += h[(int64_t)t * d + cc] * dp[t];
+        for (int t = 0; t < Tm; ++t) acc += hm[(int64_t)t * d + cc] * dm[t];
+        GK2[c] = acc;
+    }
+    for (int c = tid; c < d_out; c += 256) {
+        float acc = wd * v[c];
+        for (int r = 0; r < L; ++r) {
+            const float pg = pre[lab[r]];
+            acc += pg * tp_sigmoid(pg) * pre[T + lab[r]] * dy[(int64_t)r * d_out + c];
+        }
+        gv[c] = acc;
+    }
+    if (tid < 2) {
+        const float* dp = tid ? dpu : dpg;
+        const float* dm = tid ? dpmu : dpmg;
+        float acc = wd * B2[tid];
+        for (int t = 0; t < T; ++t) acc += dp[t];
+        for (int t = 0; t < Tm; ++t) acc += dm[t];
+        GB2[tid] = acc;
+    }
+}
+
+extern "C" int devqa_tp_gated_neuron_fwd(const float* h, int T, int d, const float* K2, const float* B2, const int32_t* lab, int L,
+                                         const float* v, const float* ybase, int d_out, float* pre, float* y, void* stream) {
+    DEVQA_CHECK_ARG(h && K2 && B2 && lab && v && ybase && pre && y && T > 0 && d > 0 && L > 0 && d_out > 0,
+                    "tp_gated_neuron_fwd: bad arguments");
+    hipLaunchKernelGGL(tp_gated_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, h, T, d, K2, B2, lab, L, v, ybase, d_out, pre, y);
+    DEVQA_LAUNCH_CHECK("tp_gated_neuron_fwd");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_tp_gated_neuron_bwd(const float* h, const float* pre, int T, int d, const int32_t* lab, int L, const float* dy,
+                                         int d_out, const float* hm, int Tm, const float* K2, const float* B2, const float* v,
+                                         float lambda_a, float lambda_m, float weight_decay, float* scratch, float* GK2, float* GB2,
+                                         float* gv, float* losses, void* stream) {
+    DEVQA_CHECK_ARG(h && pre && lab && dy && hm && K2 && B2 && v && scratch && GK2 && GB2 && gv && losses && T > 0 && Tm > 0 && L > 0,
+                    "tp_gated_neuron_bwd: bad arguments");
+    hipLaunchKernelGGL(tp_gated_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, h, pre, T, d, lab, L, dy, d_out, hm, Tm, K2, B2, v,
+                       lambda_a, lambda_m, weight_decay, scratch, GK2, GB2, gv, losses);
+    DEVQA_LAUNCH_CHECK("tp_gated_neuron_bwd");
+    return DEVQA_OK;
+}
+
 extern "C" int devqa_tp_neuron_fwd(const float* h, int T, int d, const float* k, const float* b, const int32_t* lab, int L,
                                    const float* v, const float* ybase, int d_out, float* pre, float* y, void* stream) {
     DEVQA_CHECK_ARG(h && k && b && lab && v && ybase && pre && y && T > 0 && d > 0 && L > 0 && d_out > 0, "tp_neuron_fwd: bad arguments");

@@ -15,8 +15,11 @@ its last-L rows; only step 0 sees the edit prompt (and image).
 
 The reference loads the memory texts with `datasets.load_dataset('data/wikitext/wikitext-103-raw-v1')` and filters them
 (:41-44); here they are passed in (`locality_texts`, a list of strings, or a text file with one per line) and filtered by
-the same rule.  Supported on this path: ONE in/out module pair = fc1/fc2 of the LAST decoder layer (what
-R/configs/tp_vl/blip2-opt-2.7b.yaml selects).
+the same rule.  Supported on this path, the LAST decoder layer's FFN in both shapes the shipped configs select:
+  * OPT (R/configs/tp_vl/blip2-opt-2.7b.yaml): in = fc1, out = fc2; neuron = relu(h.k + b) * v;
+  * LLaMA (R/configs/tp_vl/llava-v1.5-7b.yaml, minigpt-4-vicuna-7b.yaml): in = gate_proj AND up_proj, out = down_proj; the
+    hooks extend both projections' outputs, so the neuron is silu(h.k_gate + b_gate) * (h.k_up + b_up) * v and loss_a / loss_m
+    are summed over the two in-layers (tp_vl.py:164-177) -- `devqa_tp_gated_neuron_fwd/bwd`.
 """
 import re
 from dataclasses import dataclass
@@ -56,12 +59,16 @@ class TPvl(VLLMBaseEditor):
         self.verbose = verbose
         eng = self.vllm.engine
         self.dev = eng.dev
-        if len(config.mlp_in_module_tmps) != 1 or len(config.mlp_out_module_tmps) != 1:
-            raise NotImplementedError("native TP_VL patches one fc1/fc2 pair")
-        self.fc1 = config.mlp_in_module_tmps[0].format(config.edit_layer)
-        self.fc2 = config.mlp_out_module_tmps[0].format(config.edit_layer)
-        if config.edit_layer != eng.edit_layer or not self.fc1.endswith(".fc1") or not self.fc2.endswith(".fc2"):
-            raise NotImplementedError("native TP_VL patches fc1/fc2 of the LAST decoder layer (got %s)" % self.fc1)
+        ins = [t.format(config.edit_layer) for t in config.mlp_in_module_tmps]
+        outs = [t.format(config.edit_layer) for t in config.mlp_out_module_tmps]
+        if len(outs) != 1 or len(ins) not in (1, 2):
+            raise NotImplementedError("native TP_VL patches one FFN: fc1 -> fc2, or gate_proj + up_proj -> down_proj")
+        self.gated = len(ins) == 2
+        ok = (ins[0].endswith(".mlp.gate_proj") and ins[1].endswith(".mlp.up_proj") and outs[0].endswith(".mlp.down_proj")) \
+            if self.gated else (ins[0].endswith(".fc1") and outs[0].endswith(".fc2"))
+        if config.edit_layer != eng.edit_layer or not ok:
+            raise NotImplementedError("native TP_VL patches the FFN of the LAST decoder layer (got %s -> %s)" % (ins, outs))
+        self.fc1, self.fc2 = ins[0], outs[0]
         self.d_in = self.vllm.model.get(self.fc1 + ".weight").shape[1]
         self.d_out = self.vllm.model.get(self.fc2 + ".weight").shape[0]
         if locality_texts is None:
@@ -79,8 +86,9 @@ class TPvl(VLLMBaseEditor):
         return False
 
     def restore_to_original_model(self):
-        self.K = torch.zeros((0, self.d_in), dtype=torch.float32, device=self.dev)    # one ROW per neuron (newest first)
-        self.B = torch.zeros((0,), dtype=torch.float32, device=self.dev)
+        # one ROW per neuron (newest first); gated FFN: K [n, 2, d_in] (gate key, up key), B [n, 2]
+        self.K = torch.zeros((0, 2, self.d_in) if self.gated else (0, self.d_in), dtype=torch.float32, device=self.dev)
+        self.B = torch.zeros((0, 2) if self.gated else (0,), dtype=torch.float32, device=self.dev)
         self.V = torch.zeros((0, self.d_out), dtype=torch.float32, device=self.dev)
         self._install()
 
@@ -94,11 +102,20 @@ class TPvl(VLLMBaseEditor):
             eng.extra_neurons = {}
             return
         npad = (n + 7) // 8 * 8
+        op = (lambda t: lib.cast_f32_bf16(t.contiguous())) if eng.adt == torch.bfloat16 else (lambda t: t.contiguous())
+        if self.gated:
+            KGU = torch.zeros((2 * npad, self.d_in), dtype=torch.float32, device=self.dev)
+            BGU = torch.zeros((2 * npad,), dtype=torch.float32, device=self.dev)
+            VT = torch.zeros((self.d_out, npad), dtype=torch.float32, device=self.dev)
+            KGU[:n], KGU[npad:npad + n] = self.K[:, 0], self.K[:, 1]
+            BGU[:n], BGU[npad:npad + n] = self.B[:, 0], self.B[:, 1]
+            VT[:, :n] = self.V.t()
+            eng.extra_neurons = {self.cfg.edit_layer: {"KGU": op(KGU), "BGU": BGU, "VT": op(VT)}}
+            return
         K = torch.zeros((npad, self.d_in), dtype=torch.float32, device=self.dev)
         B = torch.zeros((npad,), dtype=torch.float32, device=self.dev)
         VT = torch.zeros((self.d_out, npad), dtype=torch.float32, device=self.dev)
         K[:n], B[:n], VT[:, :n] = self.K, self.B, self.V.t()
-        op = (lambda t: lib.cast_f32_bf16(t.contiguous())) if eng.adt == torch.bfloat16 else (lambda t: t.contiguous())
         eng.extra_neurons = {self.cfg.edit_layer: {"K": op(K), "B": B, "VT": op(VT)}}
 
     @torch.no_grad()
@@ -131,14 +148,16 @@ class TPvl(VLLMBaseEditor):
             rows += [b * tmax + T - L + j for j in range(L)]
         ridx = torch.tensor(rows, dtype=torch.int32, device=dev)
         ybase = lib.gather_rows(x_mid, ridx)
-        lib.gemm(lib.gather_rows(a, ridx), eng._w(self.fc2 + ".weight"), eng._p(self.fc2 + ".bias"), residual=ybase, out_f32=ybase)
+        lib.gemm(lib.gather_rows(a, ridx), eng._w(self.fc2 + ".weight"), None if self.gated else eng._p(self.fc2 + ".bias"),
+                 residual=ybase, out_f32=ybase)
         eng.add_extra_neurons(cfg.edit_layer, lib.gather_rows(h, ridx), ybase)          # earlier edits' neurons
         ybase = ybase.view(cfg.num_steps, L, self.d_out)
         labels = y[0].to(dev, torch.int32).contiguous()
         m = msk[0].to(dev, torch.float32)
         coef = (m / m.sum()).contiguous()
-        k = torch.zeros((self.d_in,), dtype=torch.float32, device=dev)
-        bb = torch.zeros((1,), dtype=torch.float32, device=dev)
+        k = torch.zeros((2, self.d_in) if self.gated else (self.d_in,), dtype=torch.float32, device=dev)
+        bb = torch.zeros((2 if self.gated else 1,), dtype=torch.float32, device=dev)
+        nfwd, nbwd = (lib.tp_gated_neuron_fwd, lib.tp_gated_neuron_bwd) if self.gated else (lib.tp_neuron_fwd, lib.tp_neuron_bwd)
         v = torch.zeros((self.d_out,), dtype=torch.float32, device=dev)
         mom = [torch.zeros_like(t) for t in (k, bb, v, k, bb, v)]
         losses = []
@@ -146,7 +165,7 @@ class TPvl(VLLMBaseEditor):
             T_e = seqs[i].shape[0]
             h_e = h32[i * tmax:i * tmax + T_e].contiguous()                # step 0: the edit sequence; then memory text i-1
             lab = torch.arange(T_e - L, T_e, dtype=torch.int32, device=dev)
-            pre, yrows = lib.tp_neuron_fwd(h_e, k, bb, lab, v, ybase[i].contiguous())
+            pre, yrows = nfwd(h_e, k, bb, lab, v, ybase[i].contiguous())
             logits = eng.lm_head(yrows)
             _, nll, dlog = lib.vocab_rows(logits, labels, coef, want_argmax=False, want_nll=True, want_dlogits=True,
                                           dlogits_dtype=eng.adt)
@@ -154,8 +173,7 @@ class TPvl(VLLMBaseEditor):
             dy = eng.final_norm_bwd(yrows, dH)
             T_m = seqs[i + 1].shape[0]
             h_m = h32[(i + 1) * tmax:(i + 1) * tmax + T_m].contiguous()
-            gk, gb, gv, la_lm = lib.tp_neuron_bwd(h_e, pre, lab, dy, h_m, k, bb, v, cfg.loss_a_lambda, cfg.loss_m_lambda,
-                                                  cfg.weight_decay)
+            gk, gb, gv, la_lm = nbwd(h_e, pre, lab, dy, h_m, k, bb, v, cfg.loss_a_lambda, cfg.loss_m_lambda, cfg.weight_decay)
             losses.append((nll, coef, la_lm))
             for p_, g_, m1, m2 in ((k, gk, mom[0], mom[3]), (bb, gb, mom[1], mom[4]), (v, gv, mom[2], mom[5])):
                 lib.adam_step_(p_, g_, m1, m2, cfg.lr, i + 1)
@@ -164,6 +182,6 @@ class TPvl(VLLMBaseEditor):
             for i, (le, la, lm) in enumerate(self.last_losses):
                 print(i, le + la * cfg.loss_a_lambda + lm * cfg.loss_m_lambda, "\n  loss_e: ", le, "\n  loss_a: ", la, "\n  loss_m: ", lm)
         self.K = torch.cat([k.unsqueeze(0), self.K], 0)                    # the new neuron goes in FRONT (:139-145)
-        self.B = torch.cat([bb, self.B], 0)
+        self.B = torch.cat([bb.unsqueeze(0) if self.gated else bb, self.B], 0)
         self.V = torch.cat([v.unsqueeze(0), self.V], 0)
         self._install()

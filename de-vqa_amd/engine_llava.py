@@ -179,7 +179,7 @@ class LlavaEngine:
 
     # ---- LLaMA decoder layers -----------------------------------------------------------------------------------
     @torch.no_grad()
-    def decoder_layers(self, ps, upto_layer=None, stop_before_fc2=False, save=None):
+    def decoder_layers(self, ps, upto_layer=None, stop_before_fc2=False, save=None, return_h=False):
         """save: None, or {"layers": set of layer ids}: filled with the activations decoder_backward needs.  Low-rank module
         deltas (set_module_deltas; MEND_VL's forward_edit_hook, mend_vl.py:73-80) are applied to gate / up / down outputs."""
         t, m = self.t, self.m
@@ -211,12 +211,23 @@ class LlavaEngine:
             if rec is not None:
                 rec.update(qkv=qkv, att=att, x_mid=x.clone(), h2=h, gu=gu, a=a)
             if stop_before_fc2 and i == last:
-                return x, a
+                return (x, a, h) if return_h else (x, a)
             lib.gemm(a, self._w(p + "mlp.down_proj.weight"), residual=x, out_f32=x)
             dd = deltas.get(p + "mlp.down_proj")
             if dd is not None:
                 lib.gemm(lib.gemm(a, dd["xt"]), dd["dtT"], residual=x, out_f32=x)
+            self.add_extra_neurons(i, h, x)
         return x, None
+
+    def add_extra_neurons(self, layer, h, x):
+        """x += (silu(h KG^T + BG) * (h KU^T + BU)) V for the patch neurons appended to `layer`'s FFN (TP_VL on the LLaMA FFN,
+        tp_vl.py:74-103 with gate_proj and up_proj as in-layers: the hooks concatenate the extra columns to both projections'
+        outputs, the MLP's silu(gate) * up acts on all of them and down_proj's hooks add extra_act @ extra_values).
+        self.extra_neurons[layer] = {"KGU": [2 n_pad, d] (gate keys, then up keys), "BGU": fp32 [2 n_pad], "VT": [d, n_pad]}
+        in the operand dtype; zero-padded neurons contribute silu(0) * 0."""
+        ent = (getattr(self, "extra_neurons", None) or {}).get(layer)
+        if ent is not None:
+            lib.gemm(lib.swiglu(lib.gemm(h, ent["KGU"], ent["BGU"])), ent["VT"], residual=x, out_f32=x)
 
     # ---- MEND_VL support: module kinds, delta installation, explicit backward ---------------------------------------------
     MEND_MODULE_RE = r"^(.*\.layers\.)(\d+)\.mlp\.(gate_proj|up_proj|down_proj)$"

@@ -90,6 +90,8 @@ def load():
     _sig(L.devqa_swiglu_bwd_f32, [P, P, I, I, P, P])
     _sig(L.devqa_tp_neuron_fwd, [P, I, I, P, P, P, I, P, P, I, P, P, P])
     _sig(L.devqa_tp_neuron_bwd, [P, P, I, I, P, I, P, I, P, I, P, P, P, F, F, F, P, P, P, P, P, P])
+    _sig(L.devqa_tp_gated_neuron_fwd, [P, I, I, P, P, P, I, P, P, I, P, P, P])
+    _sig(L.devqa_tp_gated_neuron_bwd, [P, P, I, I, P, I, P, I, P, I, P, P, P, F, F, F, P, P, P, P, P, P])
     _lib = L
     return L
 
@@ -104,6 +106,7 @@ EXPORTS = ["devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_ro
            "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_mend_normalize_concat",
            "devqa_mend_lrlinear_epilogue", "devqa_logit_kl_rows", "devqa_kl_dlogits", "devqa_welford_rows",
            "devqa_mend_lrlinear_bwd", "devqa_sumsq_f32", "devqa_adam_step", "devqa_tp_neuron_fwd", "devqa_tp_neuron_bwd",
+           "devqa_tp_gated_neuron_fwd", "devqa_tp_gated_neuron_bwd",
            "devqa_swiglu_bwd_bf16", "devqa_swiglu_bwd_f32"]
 
 
@@ -581,6 +584,36 @@ def tp_neuron_bwd(h, pre, lab, dy, hm, k, b, v, lambda_a, lambda_m, weight_decay
     _chk(load().devqa_tp_neuron_bwd(_p(h), _p(pre), T, d, _p(lab), L, _p(dy), d_out, _p(hm), Tm, _p(k), _p(b), _p(v), float(lambda_a),
                                     float(lambda_m), float(weight_decay), _p(scratch), _p(gk), _p(gb), _p(gv), _p(losses), _stream()),
          "devqa_tp_neuron_bwd")
+    return gk, gb, gv, losses
+
+
+def tp_gated_neuron_fwd(h, K2, B2, lab, v, ybase):
+    """LLaMA-FFN patch neuron: K2 [2,d] (gate key, up key), B2 [2] -> pre [2,T], y [L,d_out]"""
+    for t in (h, K2, B2, v, ybase):
+        _need(t, torch.float32, "tp_gated_neuron_fwd tensor")
+    T, d = h.shape
+    assert tuple(K2.shape) == (2, d) and B2.numel() == 2
+    L, d_out = ybase.shape
+    pre = torch.empty((2, T), dtype=torch.float32, device=h.device)
+    y = torch.empty_like(ybase)
+    _chk(load().devqa_tp_gated_neuron_fwd(_p(h), T, d, _p(K2), _p(B2), _p(lab), L, _p(v), _p(ybase), d_out, _p(pre), _p(y), _stream()),
+         "devqa_tp_gated_neuron_fwd")
+    return pre, y
+
+
+def tp_gated_neuron_bwd(h, pre, lab, dy, hm, K2, B2, v, lambda_a, lambda_m, weight_decay):
+    for t in (h, pre, dy, hm, K2, B2, v):
+        _need(t, torch.float32, "tp_gated_neuron_bwd tensor")
+    T, d = h.shape
+    assert tuple(K2.shape) == (2, d) and tuple(pre.shape) == (2, T)
+    L, d_out = dy.shape
+    Tm = hm.shape[0]
+    scratch = torch.empty((2 * (T + Tm),), dtype=torch.float32, device=h.device)
+    gk, gb, gv = torch.empty_like(K2), torch.empty_like(B2), torch.empty_like(v)
+    losses = torch.empty((2,), dtype=torch.float32, device=h.device)
+    _chk(load().devqa_tp_gated_neuron_bwd(_p(h), _p(pre), T, d, _p(lab), L, _p(dy), d_out, _p(hm), Tm, _p(K2), _p(B2), _p(v),
+                                          float(lambda_a), float(lambda_m), float(weight_decay), _p(scratch), _p(gk), _p(gb), _p(gv),
+                                          _p(losses), _stream()), "devqa_tp_gated_neuron_bwd")
     return gk, gb, gv, losses
 
 

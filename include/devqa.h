@@ -200,6 +200,18 @@ int devqa_tp_neuron_bwd(const float* h, const float* pre, int T, int d, const in
                         const float* hm, int Tm, const float* k, const float* b, const float* v, float lambda_a, float lambda_m,
                         float weight_decay, float* scratch, float* gk, float* gb, float* gv, float* losses, void* stream);
 
+/* Gated variant for the LLaMA FFN, down(silu(gate(x)) * up(x)) -- R/configs/tp_vl/llava-v1.5-7b.yaml:8-12 and
+ * minigpt-4-vicuna-7b.yaml patch gate_proj AND up_proj: the new neuron has keys K2 = [k_gate; k_up] [2,d], biases B2 [2], value
+ * v [d_out]; act = silu(h.k_gate + b_gate) * (h.k_up + b_up); loss_a / loss_m are summed over the two in-layers
+ * (tp_vl.py:164-177).  pre: fp32 [2,T] (gate row, up row); scratch: fp32 [2 * (T + Tm)]; GK2 [2,d], GB2 [2].
+ */
+int devqa_tp_gated_neuron_fwd(const float* h, int T, int d, const float* K2, const float* B2, const int32_t* lab, int L,
+                              const float* v, const float* ybase, int d_out, float* pre, float* y, void* stream);
+int devqa_tp_gated_neuron_bwd(const float* h, const float* pre, int T, int d, const int32_t* lab, int L, const float* dy, int d_out,
+                              const float* hm, int Tm, const float* K2, const float* B2, const float* v, float lambda_a,
+                              float lambda_m, float weight_decay, float* scratch, float* GK2, float* GB2, float* gv, float* losses,
+                              void* stream);
+
 /* ---- K2 patch-embed staging ---------------------------------------------------------------
  * im2col for Conv2d(3->D, k=P, s=P): pixels fp32 [B,3,S,S] -> bf16 [B*(S/P)^2, Kpad] with
  * column (c*P+py)*P+px, zero padded to Kpad (Kpad % 8 == 0).  HF Blip2VisionEmbeddings,

@@ -1,4 +1,5 @@
-"""CPU: the TP_VL oracle restatement against goldens produced by the reference's own TPvl (tools/make_goldens_tp.py)."""
+"""CPU: the TP_VL oracle restatement against goldens produced by the reference's own TPvl (tools/make_goldens_tp.py): the OPT
+FFN on the tiny BLIP-2 (fc1 -> fc2) and the gated LLaMA FFN on the tiny LLaVA (gate_proj + up_proj -> down_proj)."""
 import json
 import os
 from copy import deepcopy
@@ -19,14 +20,18 @@ class Draws:
         return np.array([v])
 
 
-@pytest.fixture(scope="module")
-def tp(gold_dir):
-    from oracle.devqa_oracle import OracleBlip2
+@pytest.fixture(scope="module", params=["blip2", "llava"])
+def tp(gold_dir, request):
     from oracle.tp_oracle import OracleTPvl
-    model = OracleBlip2.from_pretrained_dir(os.path.join(gold_dir, "tiny_blip2"))
-    cfg = yaml.safe_load(open(os.path.join(gold_dir, "tiny_tp_cfg.yaml")))
-    j = json.load(open(os.path.join(gold_dir, "tiny_tp_goldens.json")))
-    z = np.load(os.path.join(gold_dir, "tiny_tp_goldens.npz"))
+    if request.param == "blip2":
+        from oracle.devqa_oracle import OracleBlip2
+        model, tag = OracleBlip2.from_pretrained_dir(os.path.join(gold_dir, "tiny_blip2")), "tiny_tp"
+    else:
+        from oracle.llava_oracle import OracleLlava
+        model, tag = OracleLlava.from_pretrained_dir(os.path.join(gold_dir, "tiny_llava")), "tiny_tp_llava"
+    cfg = yaml.safe_load(open(os.path.join(gold_dir, tag + "_cfg.yaml")))
+    j = json.load(open(os.path.join(gold_dir, tag + "_goldens.json")))
+    z = np.load(os.path.join(gold_dir, tag + "_goldens.npz"))
     return model, OracleTPvl(model, cfg, j["sentences"], Draws(j["draws_edits"])), j, z
 
 
@@ -41,7 +46,9 @@ def test_tp_oracle_edits(tp, in_gold_dir):
     np.testing.assert_allclose(logits(), z["pre_logits"], atol=2e-4)
     for tag, r in zip("ab", j["requests"]):
         ed.edit_one_piece(deepcopy(r))
-        for key, got in (("k", ed.K), ("b", ed.B), ("v", ed.V)):
+        parts = ((("kg", ed.K[0]), ("bg", ed.B[0]), ("ku", ed.K[1]), ("bu", ed.B[1]), ("v", ed.V)) if ed.gated
+                 else (("k", ed.K[0]), ("b", ed.B[0]), ("v", ed.V)))
+        for key, got in parts:
             g = z["%s_%s" % (tag, key)]
             assert got.shape == g.shape
             assert np.abs(got.numpy() - g).max() < 2e-3 * np.abs(g).max(), (tag, key, np.abs(got.numpy() - g).max())

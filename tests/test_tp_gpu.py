@@ -1,5 +1,6 @@
 """GPU: TP_VL (T-Patcher) on the HIP engine against goldens produced by the reference's own TPvl
-(tools/make_goldens_tp.py): patch neurons after one / two sequential edits, post-edit and restored logits, evaluator."""
+(tools/make_goldens_tp.py): patch neurons after one / two sequential edits, post-edit and restored logits, evaluator -- the OPT
+FFN on the tiny BLIP-2 and the gated LLaMA FFN (gate_proj + up_proj -> down_proj) on the tiny LLaVA."""
 import json
 import os
 from copy import deepcopy
@@ -21,18 +22,25 @@ class Draws:
         return np.array([v])
 
 
-@pytest.fixture(scope="module", params=["fp32", "bf16"])
+@pytest.fixture(scope="module", params=["fp32", "bf16", "llava-fp32", "llava-bf16"])
 def tp(gold_dir, request):
     import devqa_amd  # noqa: F401
-    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
     from devqa_amd.editor.vllm_editors.tp_vl.tp_vl import TPvl, TPvlConfig
-    j = json.load(open(os.path.join(gold_dir, "tiny_tp_goldens.json")))
-    z = np.load(os.path.join(gold_dir, "tiny_tp_goldens.npz"))
-    vllm = BLIP2OPTForEdit(os.path.join(gold_dir, "tiny_blip2"), "cuda:0", dtype=request.param)
-    ed = TPvl(vllm, TPvlConfig.from_yaml(os.path.join(gold_dir, "tiny_tp_cfg.yaml")), "cuda:0", locality_texts=j["sentences"],
+    mode = request.param.split("-")[-1]
+    if request.param.startswith("llava"):
+        from devqa_amd.editor.vllms_for_edit.llava.llava import LlavaForEdit
+        tag = "tiny_tp_llava"
+        vllm = LlavaForEdit(os.path.join(gold_dir, "tiny_llava"), "cuda:0", True, dtype=mode)
+    else:
+        from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+        tag = "tiny_tp"
+        vllm = BLIP2OPTForEdit(os.path.join(gold_dir, "tiny_blip2"), "cuda:0", dtype=mode)
+    j = json.load(open(os.path.join(gold_dir, tag + "_goldens.json")))
+    z = np.load(os.path.join(gold_dir, tag + "_goldens.npz"))
+    ed = TPvl(vllm, TPvlConfig.from_yaml(os.path.join(gold_dir, tag + "_cfg.yaml")), "cuda:0", locality_texts=j["sentences"],
               rng=Draws(j["draws_edits"]))
     assert list(ed.locality_data) == j["sentences"]
-    return vllm, ed, j, z, request.param
+    return vllm, ed, j, z, mode
 
 
 def _rel(a, g):
@@ -50,7 +58,11 @@ def test_tp_edits(tp, in_gold_dir):
     assert _rel(logits(), z["pre_logits"]) < ltol
     for tag, r in zip("ab", j["requests"]):
         ed.edit_one_piece(deepcopy(r))
-        got = {"k": ed.K.t().cpu().numpy(), "b": ed.B.cpu().numpy(), "v": ed.V.cpu().numpy()}
+        if ed.gated:
+            got = {"kg": ed.K[:, 0].t().cpu().numpy(), "bg": ed.B[:, 0].cpu().numpy(), "ku": ed.K[:, 1].t().cpu().numpy(),
+                   "bu": ed.B[:, 1].cpu().numpy(), "v": ed.V.cpu().numpy()}
+        else:
+            got = {"k": ed.K.t().cpu().numpy(), "b": ed.B.cpu().numpy(), "v": ed.V.cpu().numpy()}
         errs = {key: _rel(got[key], z["%s_%s" % (tag, key)]) for key in got}
         e = _rel(logits(), z[tag + "_post_logits"])
         print(mode, tag, {k_: "%.2e" % v_ for k_, v_ in errs.items()}, "post-edit logits %.2e" % e, "losses[0], [-1]:", ed.last_losses[0], ed.last_losses[-1])
@@ -59,7 +71,7 @@ def test_tp_edits(tp, in_gold_dir):
         if mode == "fp32":      # Adam normalises every coordinate's step to ~lr: element-wise agreement is an fp32 property
             assert max(errs.values()) < 5e-3
         else:                   # bf16: direction of the neuron + its effect on the logits
-            for key in ("k", "v"):
+            for key in (("kg", "ku", "v") if ed.gated else ("k", "v")):
                 g = z["%s_%s" % (tag, key)]
                 cos = float((got[key] * g).sum() / (np.linalg.norm(got[key]) * np.linalg.norm(g)))
                 assert cos > 0.9, (tag, key, cos)

@@ -80,29 +80,9 @@ def build_model(spec, seed):
     return model.eval().requires_grad_(False)
 
 
-def main():
-    from copy import deepcopy
+def make_compat(model, tok, ip):
+    """The adapter the reference's editors / evaluator are driven on (also used by tools/make_goldens_tp.py --llava)."""
     from editor.vllms_for_edit.base import BaseVLLMForEdit
-    from editor.vllm_editors.ft_vl import ft_vl as ref_ft
-    from evaluation.vllm_editor_eval import VLLMEditorEvaluation
-    from dataset.vllm import BaseVLLMEditData
-    from transformers import CLIPImageProcessor
-
-    out_dir = os.path.join(GOLD, "tiny_llava")
-    if os.path.isdir(out_dir):
-        shutil.rmtree(out_dir)
-    os.makedirs(out_dir)
-    tok = build_tokenizer()
-    spec = deepcopy(TINY_LLAVA)
-    model = build_model(spec, seed=3)
-    S = spec["vision_config"]["image_size"]
-    ip = CLIPImageProcessor(size={"shortest_edge": S}, crop_size={"height": S, "width": S})
-    # fixture: weights under the OLD names (what the reference's YAML addresses), tokenizer, spec
-    from safetensors.torch import save_file
-    save_file({new_to_old_name(n): p.detach().clone().contiguous() for n, p in model.named_parameters()},
-              os.path.join(out_dir, "model.safetensors"))
-    tok.save_pretrained(out_dir)
-    json.dump(spec, open(os.path.join(out_dir, "devqa_llava_config.json"), "w"), indent=1)
 
     class HFLlavaCompat(BaseVLLMForEdit):
         """R/editor/vllms_for_edit/llava/llava.py:25-68 on transformers-5.15 attribute paths."""
@@ -152,8 +132,35 @@ def main():
         def is_q_former_based(self):
             return False
 
+    return HFLlavaCompat()
+
+
+def main():
+    from copy import deepcopy
+    from editor.vllms_for_edit.base import BaseVLLMForEdit
+    from editor.vllm_editors.ft_vl import ft_vl as ref_ft
+    from evaluation.vllm_editor_eval import VLLMEditorEvaluation
+    from dataset.vllm import BaseVLLMEditData
+    from transformers import CLIPImageProcessor
+
+    out_dir = os.path.join(GOLD, "tiny_llava")
+    if os.path.isdir(out_dir):
+        shutil.rmtree(out_dir)
+    os.makedirs(out_dir)
+    tok = build_tokenizer()
+    spec = deepcopy(TINY_LLAVA)
+    model = build_model(spec, seed=3)
+    S = spec["vision_config"]["image_size"]
+    ip = CLIPImageProcessor(size={"shortest_edge": S}, crop_size={"height": S, "width": S})
+    # fixture: weights under the OLD names (what the reference's YAML addresses), tokenizer, spec
+    from safetensors.torch import save_file
+    save_file({new_to_old_name(n): p.detach().clone().contiguous() for n, p in model.named_parameters()},
+              os.path.join(out_dir, "model.safetensors"))
+    tok.save_pretrained(out_dir)
+    json.dump(spec, open(os.path.join(out_dir, "devqa_llava_config.json"), "w"), indent=1)
+
     os.chdir(GOLD)
-    vllm = HFLlavaCompat()
+    vllm = make_compat(model, tok, ip)
     rec = json.load(open(os.path.join(GOLD, "evqa8_records.json")))
     records = rec["records"]
     t2n = lambda t: t.detach().cpu().numpy()  # noqa: E731
