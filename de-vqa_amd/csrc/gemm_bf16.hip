@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(
 }
 
 // ---- optional per-launch timing for bench.py's roofline (HIP events on the launch stream) ----------
+#include <mutex>
 #include <vector>
 #define PROF_VARIANTS 4
 #define PROF_MAX_PAIRS 49152
@@ -321,7 +322,9 @@ __global__ void splitk_reduce_epilogue_kernel(const float* __restrict__ part, in
 namespace {
 struct SplitKWs { hipStream_t st; int dev; float* p; size_t bytes; };
 SplitKWs g_skws[8] = {};
+std::mutex g_skws_mu;
 float* splitk_workspace(hipStream_t st, size_t bytes) {   // one buffer per (device, stream): concurrent streams never share
+    std::lock_guard<std::mutex> lock(g_skws_mu);          // host threads (the training prefetch thread) may race for a slot
     int dev = 0;
     (void)hipGetDevice(&dev);
     SplitKWs* slot = nullptr;

@@ -322,28 +322,37 @@ class MENDvl(VLLMBaseEditor):
 
     @staticmethod
     def _items(xym):
-        """((llm_inpt, vt), y, m) with batch B -> per-sequence (embeds [T,d] fp32, labels [L], mask [L])"""
+        """((llm_inpt, vt), y, m) with batch B -> per-sequence (embeds [T_b,d] fp32, labels [l], mask [l], positions [l]).
+        The label window is the LAST L columns of the right-padded batch (base.py:107-108, logits[:, -L:]): column j sits at
+        padded position T_pad - L + j; columns that fall into a shorter sequence's padding (mask 0 there) are dropped, so with
+        B = 1 this is the sequence's own last L rows."""
         (x, _vt), y, m = xym
         emb, am = x["inputs_embeds"], x["attention_mask"]
+        T_pad, L = emb.shape[1], y.shape[1]
         out = []
         for b in range(emb.shape[0]):
             T = int(am[b].sum())
-            out.append((emb[b, :T].to(torch.float32), y[b], m[b]))
+            keep = [j for j in range(L) if 0 <= T_pad - L + j < T]
+            if len(keep) < L and float(m[b][[j for j in range(L) if j not in keep]].sum()) != 0:
+                raise RuntimeError("label mask set on a padded position")
+            kj = torch.tensor(keep, dtype=torch.long, device=y.device)
+            out.append((emb[b, :T].to(torch.float32), y[b][kj], m[b][kj], [T_pad - L + j for j in keep]))
         return out
 
     def _pack(self, items):
         eng = self.vllm.engine
-        tmax = (max(e.shape[0] for e, _, _ in items) + 3) // 4 * 4
+        tmax = (max(it[0].shape[0] for it in items) + 3) // 4 * 4
         B, d = len(items), items[0][0].shape[1]
         emb = torch.zeros((B, tmax, d), dtype=torch.float32, device=self.dev)
         msk = torch.zeros((B, tmax), dtype=torch.int32, device=self.dev)
         rows, spans = [], []
-        for b, (e, y, m) in enumerate(items):
-            T, L = e.shape[0], y.shape[-1]
+        for b, (e, y, m, pos) in enumerate(items):
+            T = e.shape[0]
             emb[b, :T] = e
             msk[b, :T] = 1
-            spans.append((len(rows), len(rows) + L))
-            rows += [b * tmax + T - L + j for j in range(L)]
+            assert len(pos) == y.shape[-1] and all(0 <= p_ < T for p_ in pos), "label rows outside the sequence"
+            spans.append((len(rows), len(rows) + len(pos)))
+            rows += [b * tmax + p_ for p_ in pos]
         return eng.pack_from_embeds(emb, msk), torch.tensor(rows, dtype=torch.int32, device=self.dev), spans
 
     @torch.no_grad()
@@ -380,9 +389,9 @@ class MENDvl(VLLMBaseEditor):
         is_kl = torch.zeros((R,), dtype=torch.bool, device=dev)
         gi, layout = 0, []
         for kind, name, its, lam in groups:
-            tot = float(sum(float(m.sum()) for _, _, m in its))            # label_loss / logit_KL_loss average over the batch's mask
+            tot = float(sum(float(it[2].sum()) for it in its))             # label_loss / logit_KL_loss average over the batch's mask
             r0 = spans[gi][0]
-            for (_, y_, m_) in its:
+            for (_, y_, m_, _pos) in its:
                 a, b = spans[gi]
                 coef[a:b] = m_.to(dev, torch.float32) * (lam / tot)
                 labels[a:b] = y_.to(dev, torch.int32)
@@ -476,27 +485,38 @@ class MENDvl(VLLMBaseEditor):
                                                   [x["locality"][k][0]["target"] for x in d]) for k in d[0]["locality"]}
         return edit, gen, loc
 
-    def train(self, vllm_edit_data, total_epochs=1, batch_size=1, save_ckpt_path=None, seed=None, ema_alpha=0.1, log_fn=None):
-        """The reference's training loop (base.py:192-225) without TensorBoard and without the second-device producer
-        thread: shuffled batches, EMA loss, the best-EMA checkpoint saved under `save_ckpt_path` (`Best`)."""
+    def train(self, vllm_edit_data, total_epochs=1, batch_size=1, save_ckpt_path=None, seed=None, ema_alpha=0.1, log_fn=None,
+              data_buffer_size=8, prefetch=True):
+        """The reference's training loop (base.py:142-225) without TensorBoard: batches drawn by ParallelDataset in the
+        reference's order for `seed` (shuffled, epoch tails completed from the next permutation), EMA loss, the best-EMA
+        checkpoint saved under `save_ckpt_path` (`Best`).  With `prefetch` the next batches are organised (image encodes,
+        embeddings) by ParallelDataset's producer thread on a second HIP stream of the same GPU while this thread trains --
+        the reference does that on a second GPU with a second model copy (R/utils/__init__.py:149-156); the editor only
+        trains the hyper-network, so the frozen model serves both."""
+        from ....dataset import ParallelDataset
         data = vllm_edit_data.data if hasattr(vllm_edit_data, "data") else list(vllm_edit_data)
-        rng = np.random.default_rng(seed)
         self.set_train(True)
         if self.opt is None:
             self.opt = self.get_a_new_optimizer()
+
+        def get_data_by_ids(ids):
+            return self.organize_batch_data([data[int(j)] for j in ids])
+        gen = ParallelDataset(len(data), get_data_by_ids, batch_size, True, data_buffer_size if prefetch else 1, False, seed, True,
+                              device=self.device if prefetch and str(self.device).startswith("cuda") else None)
         ema, best, i = 1.0, float("inf"), 1
-        for epoch in range(1, total_epochs + 1):
-            order = rng.permutation(len(data))
-            for b0 in range(0, len(order) - batch_size + 1, batch_size):
-                batch = self.organize_batch_data([data[j] for j in order[b0:b0 + batch_size]])
-                loss, log = self.train_a_batch(batch)
-                ema = ema_alpha * loss + (1 - ema_alpha) * ema
-                if log_fn is not None:
-                    log_fn(i, dict(log, Loss=loss, **{"EMA Loss": ema, "Epoch": epoch}))
-                if ema < best:
-                    best = ema
-                    if save_ckpt_path is not None:
-                        self.save_ckpt(save_ckpt_path, i, epoch, loss, ema)
-                i += 1
+        try:
+            for epoch in range(1, total_epochs + 1):
+                for batch, _n in gen:
+                    loss, log = self.train_a_batch(batch)
+                    ema = ema_alpha * loss + (1 - ema_alpha) * ema
+                    if log_fn is not None:
+                        log_fn(i, dict(log, Loss=loss, **{"EMA Loss": ema, "Epoch": epoch}))
+                    if ema < best:
+                        best = ema
+                        if save_ckpt_path is not None:
+                            self.save_ckpt(save_ckpt_path, i, epoch, loss, ema)
+                    i += 1
+        finally:
+            gen.close()
         self.set_train(False)
         return ema

@@ -83,6 +83,7 @@ class Blip2Engine:
         if d is None:
             rows = [[i * q_len, q_len, i * kv_len, kv_len, 0, 0] for i in range(n_seq)]
             d = torch.tensor(rows, dtype=torch.int32, device=self.dev)
+            torch.cuda.current_stream(self.dev).synchronize()   # cached across streams (prefetch thread): publish it complete
             self._seq_desc_cache[key] = d
         return d
 

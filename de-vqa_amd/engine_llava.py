@@ -40,6 +40,7 @@ class LlavaEngine:
         d = self._desc_cache.get((n_seq, n))
         if d is None:
             d = torch.tensor([[i * n, n, i * n, n, 0, 0] for i in range(n_seq)], dtype=torch.int32, device=self.dev)
+            torch.cuda.current_stream(self.dev).synchronize()   # cached across streams (prefetch thread): publish it complete
             self._desc_cache[(n_seq, n)] = d
         return d
 

@@ -126,3 +126,29 @@ def test_read_res_table(tmp_path):
     assert (r["model"], r["data"], r["method"]) == ("blip2-opt-2.7b", "EVQA", "ft_vl")
     assert abs(float(r["t1i2"]) - (1 - loc["t1i2"]["acc"])) < 1e-12 and abs(float(r["t3i1"]) - loc["t3i1"]["acc"]) < 1e-12
     assert abs(float(r["text_loc"]) - loc["text_loc"]["acc"]) < 1e-12
+
+
+def test_parallel_dataset_matches_reference_id_sequences(gold_dir):
+    """ParallelDataset: same id batches as the reference's class for the same seed (goldens captured from it by
+    tools/make_goldens_parallel_dataset.py), over three consecutive passes; producer errors surface in the consumer."""
+    import json
+    import os
+    import pytest
+    from devqa_amd.dataset import ParallelDataset
+    cases = json.load(open(os.path.join(gold_dir, "parallel_dataset_ids.json")))
+    assert len(cases) == 6
+    for c in cases:
+        a = c["args"]
+        ds = ParallelDataset(a["sample_count"], lambda ids: [int(i) for i in ids], a["batch_size"], a["shuffle"], 4, a["drop_last"],
+                             a["random_seed"], True)
+        if isinstance(a["batch_size"], int):
+            assert len(ds) == c["len"]
+        for want in c["passes"]:
+            got = [[d, n] for d, n in ds]
+            assert got == want, (a, got, want)
+        ds.close()
+    ds = ParallelDataset(4, lambda ids: (_ for _ in ()).throw(ValueError("boom")), 2, False, 2, False, 0, False)
+    with pytest.raises(RuntimeError):
+        next(iter(ds))
+    with pytest.raises(Exception):
+        ParallelDataset(4, lambda ids: ids, 0)

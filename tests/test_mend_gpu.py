@@ -260,3 +260,29 @@ def test_mend_train_from_scratch_then_edit(gold_dir, in_gold_dir, tmp_path):
     ed2.edit_one_piece(deepcopy(rec[0]["requests"][0]))
     assert ed2.delta_weight(ed2.modules[0]["name"]) is not None
     ed2.restore_to_original_model()
+
+
+def test_mend_train_prefetch_equals_serial(gold_dir, in_gold_dir):
+    """ParallelDataset's producer thread on a second HIP stream (image encodes + embeddings of the next batches under the
+    training step) must not change a single loss: same seed, same batches, same values as with the producer kept one
+    batch ahead on the consumer's own thread order (prefetch=False)."""
+    import devqa_amd  # noqa: F401
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from devqa_amd.editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))["records"]
+    runs = []
+    for prefetch in (True, False):
+        vllm = BLIP2OPTForEdit(os.path.join(gold_dir, "tiny_blip2"), "cuda:0", dtype="fp32")
+        cfg = MENDvlConfig.from_yaml(os.path.join(gold_dir, "tiny_mend_cfg.yaml"))
+        cfg.aux_model.lr, cfg.init_edit_lr = 1e-3, 1e-3
+        ed = MENDvl(vllm, cfg, "cuda:0", for_train=True)
+        logs = []
+        ed.train([deepcopy(r) for r in rec[:5]], total_epochs=3, batch_size=2, seed=11, log_fn=lambda i, d: logs.append(d["Loss"]),
+                 data_buffer_size=4, prefetch=prefetch)
+        runs.append((logs, {k: v.clone() for k, v in ed.aux.items()}))
+    (la, sa), (lb, sb) = runs
+    assert len(la) == len(lb) == 9 and all(np.isfinite(la))      # ceil-less: 3 passes x (5 samples / batches of 2, tails carried over)
+    np.testing.assert_allclose(la, lb, rtol=1e-5, atol=1e-6)
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            torch.testing.assert_close(sa[k], sb[k], rtol=1e-4, atol=1e-6, equal_nan=True)

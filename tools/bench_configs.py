@@ -150,6 +150,21 @@ def blip2_mend_train(n=6):
     dt = (time.time() - t0) / n
     print(json.dumps({"config": "BLIP-2-OPT-2.7B + MEND_VL train_a_batch (B = 1: 1 edit + 12 post-edit probes + 9 pre-edit)",
                       "s_per_step": round(dt, 4), "steps_per_s": round(1 / dt, 2), "losses": losses, "grad_norm_last": log["Grad-Norm"]}))
+    # the training loop with ParallelDataset's producer thread on a second HIP stream vs. organising each batch in line
+    from collections import OrderedDict
+
+    class NoHit(OrderedDict):       # every image is encoded again, as in a real epoch over thousands of distinct images
+        def __contains__(self, k):
+            return False
+    vllm._img_feat_cache = NoHit()
+    for prefetch in (False, True):
+        stamps = []
+        ed.train(recs[1:], total_epochs=3, batch_size=1, seed=1, log_fn=lambda i, d: stamps.append(time.time()), data_buffer_size=4,
+                 prefetch=prefetch)
+        torch.cuda.synchronize()
+        k = len(stamps) // 3                     # skip the first pass
+        dt = (stamps[-1] - stamps[k]) / (len(stamps) - 1 - k)
+        print(json.dumps({"config": "MENDvl.train loop, prefetch=%s" % prefetch, "s_per_step": round(dt, 4), "steps_per_s": round(1 / dt, 2)}))
 
 
 def _hash_encode(sentences, dim=384):

@@ -66,5 +66,6 @@ if __name__ == "__main__":
     def log(i, d):
         if i % cfg.log_per_i == 0:
             print("iter %d  loss %.4f  ema %.4f  grad-norm %.3f" % (i, d["Loss"], d["EMA Loss"], d["Grad-Norm"]), flush=True)
-    ema = editor.train(train_data, cfg.epochs, cfg.batch_size, os.path.join(ckpt_dir, "Best"), cfg.random_seed, cfg.ema_alpha, log)
+    ema = editor.train(train_data, cfg.epochs, cfg.batch_size, os.path.join(ckpt_dir, "Best"), cfg.random_seed, cfg.ema_alpha, log,
+                       data_buffer_size=cfg.data_buffer_size)
     print("final EMA loss %.4f; checkpoint: %s" % (ema, os.path.join(ckpt_dir, "Best")))
