@@ -242,7 +242,7 @@ extern "C" int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const de
 
 static int g_gemm_mode = -1;
 extern "C" int devqa_gemm_set_mode(int mode) {
-    if (mode < 0 || (mode > 3 && (mode < 10 || mode > 25))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
+    if (mode < 0 || (mode > 3 && (mode < 10 || mode > 26))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
     g_gemm_mode = mode;
     return DEVQA_OK;
 }

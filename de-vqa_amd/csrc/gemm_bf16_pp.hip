@@ -169,6 +169,7 @@ struct PPArgs {
     int dp_tiles, sk_wgs, sk_per, sk_max_seg;
     float* ws;
     int* counters;
+    int bf16_fast;      // bf16-only output that qualifies for pp_epilogue_bf16
 };
 
 // tile id -> (tile_m, tile_n): grouped order (group_m row-tiles of one column-tile, then the next column-tile), so the
@@ -276,7 +277,9 @@ __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem
     for (int half = 0; half < 2; ++half) {
         const int gm0 = m0 + wr * 128 + half * 64 + (lane >> 4);   // + it * 4
         float4 rv[16];
-        if (residual != nullptr) {   // all 16 loads in flight before the first store (residual may alias out_f32)
+        if (residual != nullptr) {   // all 16 loads in flight before the first store (residual may alias out_f32).  Fetching the
+                                     // second half's rows under the first half's stores was measured 5-25 % SLOWER (loads
+                                     // queue behind the stores, profiles/r01_summary.md section G)
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int gm = gm0 + it * 4;
@@ -313,6 +316,56 @@ __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem
     }
 }
 
+// bf16-only outputs (no fp32 output, no residual: QKV, fc1, gate/up projections): bias / alpha / activation are applied in the
+// MFMA layout and the tile is transposed through LDS as packed bf16 -- half the LDS bytes of the fp32 transposition above and
+// 16-byte global stores (8 lanes cover the wave's 128-byte row segment).  Staging: per wave 2 x [64 rows][128 B], the 16-byte
+// chunk index XOR-swizzled with (row >> 1) & 7: the b64 writes of 16 rows x 2 lanes and the b128 reads of 2 rows x 8 lanes are
+// both bank-conflict-free.  Needs N % 8 == 0, ldc % 8 == 0 and a 16-byte aligned output (checked on the host: g.bf16_fast).
+template <int ACT>
+__device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char* smem, int m0, int n0, const float4_t (&acc)[8][4]) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    unsigned char* stg = smem + wave * 16384;
+    const float alpha = g.alpha;
+    float4 bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wc * 64 + j * 16 + fq * 4;
+        bj[j] = (g.bias != nullptr && col < g.N) ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int rrow = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        unsigned char* area = stg + half * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + fr;
+            const int sw = (row >> 1) & 7;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4_t a = acc[half * 4 + i][j];
+                const float v0 = pp_act<ACT>((a[0] + bj[j].x) * alpha), v1 = pp_act<ACT>((a[1] + bj[j].y) * alpha);
+                const float v2 = pp_act<ACT>((a[2] + bj[j].z) * alpha), v3 = pp_act<ACT>((a[3] + bj[j].w) * alpha);
+                uint2 p;
+                p.x = pp_pack2(v0, v1);
+                p.y = pp_pack2(v2, v3);
+                *reinterpret_cast<uint2*>(area + row * 128 + (((j * 2 + (fq >> 1)) ^ sw) << 4) + (fq & 1) * 8) = p;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + rrow;
+            const uint4 val = *reinterpret_cast<const uint4*>(area + row * 128 + (pc << 4));
+            const int gm = m0 + wr * 128 + half * 64 + row;
+            const int gcol = n0 + wc * 64 + ((pc ^ ((row >> 1) & 7)) << 3);
+            if (gm < g.M && gcol < g.N) *reinterpret_cast<uint4*>(g.out_bf16 + (int64_t)gm * g.ldc + gcol) = val;
+        }
+    }
+}
+
 template <int ACT, bool SK, bool BAL = false>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -324,7 +377,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
         int tile_m, tile_n;
         pp_tile_coords(g, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx, tile_m, tile_n);
         pp_mainloop<BAL>(g, smem, tile_m * PP_BM, tile_n * PP_BN, 0, nk, acc);
-        pp_epilogue<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
+        if (g.bf16_fast) pp_epilogue_bf16<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
+        else pp_epilogue<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
         return;
     }
     // Every workgroup walks a range [it, it1) of the (tile, K-tile) iteration space.  A data-parallel workgroup owns
@@ -430,14 +484,15 @@ static int launch_pp(const PPArgs& g, hipStream_t st) {
     return g.sk_wgs > 0 ? launch_pp_k<ACT, true>(g, st) : launch_pp_k<ACT, false>(g, st);
 }
 
+// id 6: group_m 4 with the fp32 LDS transposition for every output kind (A/B of pp_epilogue_bf16).
 // id: 0 group_m 8, 1 group_m 1 (plain column-major tile order), 2 group_m 4 (default), 3 group_m 16,
 //     4 group_m 4 + stream-K tail (experimental: the partial-tile hand-off -- 256 KiB per segment through HBM/L2 plus an
 //       agent-scope acq_rel RMW whose release/acquire writes back / invalidates the XCD's L2 -- costs more than the
 //       partial round it removes on every shape of this path: measured 0.50-0.93x, profiles/r01_summary.md)
 int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K, float alpha,
                    int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc, hipStream_t st) {
-    static const int gms[6] = {8, 1, 4, 16, 4, -4};
-    if (id < 0 || id > 5) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
+    static const int gms[7] = {8, 1, 4, 16, 4, -4, 4};
+    if (id < 0 || id > 6) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
     if (K % PP_BK != 0 || K < PP_BK) return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: K=%d must be a positive multiple of 64", K);
     if ((int64_t)M * lda * 2 >= (1ll << 32) || (int64_t)N * ldw * 2 >= (1ll << 32))
         return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: operands must span < 4 GiB (32-bit lane offsets)");
@@ -449,6 +504,9 @@ int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_
     g.group_m = gms[id];
     const int T = g.tiles_m * g.tiles_n, nk = K / PP_BK;
     g.dp_tiles = T; g.sk_wgs = 0; g.sk_per = 1; g.sk_max_seg = 1; g.ws = nullptr; g.counters = nullptr;
+    g.bf16_fast = out_bf16 != nullptr && out_f32 == nullptr && residual == nullptr && N % 8 == 0 && ldc % 8 == 0 &&
+                  (((uintptr_t)out_bf16) & 15) == 0 && (bias == nullptr || (((uintptr_t)bias) & 15) == 0);
+    if (id == 6) g.bf16_fast = 0;       // A/B: the fp32 transposition for every output kind
     if (id == 4) {
         int dev = 0;
         (void)hipGetDevice(&dev);

@@ -16,7 +16,7 @@ def L():
     lib.gemm_set_mode(0)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26])
 @pytest.mark.parametrize("M,N,K,act,res", [
     (4099, 4224, 1408, 0, False),     # 128x128 (mode 0/1) or 256x128 (mode 2); ragged M
     (16448, 1408, 6144, 0, True),     # ViT fc2 shape, in-place residual
@@ -68,3 +68,37 @@ def test_small_m_splitk_epilogue(L, M, N, K, act, res, want):
     torch.cuda.synchronize()
     tol = 3e-4 if want == "f32" else 1.5e-2
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("M,N,K,act,bias,alpha", [
+    (4099, 4224, 1408, 0, True, 1.0),      # ragged M, ViT QKV
+    (1000, 2568, 640, 2, True, 1.0),       # ragged N (2568 = 10 tiles + 8 columns), GELU
+    (2500, 10240, 2560, 1, True, 1.0),     # OPT fc1 + ReLU
+    (777, 264, 128, 3, False, 0.5),        # one ragged tile column, no bias, alpha, quick-GELU
+    (300, 4100, 256, 0, True, 1.0),        # N % 8 != 0: falls back to the fp32 transposition
+])
+def test_gemm_bf16_output_epilogues(L, M, N, K, act, bias, alpha):
+    """bf16-only outputs take pp_epilogue_bf16 (packed-bf16 LDS transposition, 16-byte stores); mode 26 forces the fp32
+    transposition: both must give the same bits, equal to the fp32 reference rounded to bf16 (up to one bf16 ulp where the
+    fp32 accumulation order matters)."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda() if bias else None
+    ref = a.float() @ w.float().T
+    if bias:
+        ref = ref + b
+    ref = ref * alpha
+    ref = {0: lambda t: t, 1: torch.relu, 2: torch.nn.functional.gelu, 3: lambda t: t * torch.sigmoid(1.702 * t)}[act](ref)
+    outs = {}
+    for mode in (22, 26):
+        L.gemm_set_mode(mode)
+        guard = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device="cuda")      # rows before / after must stay untouched
+        o = guard[1:M + 1]
+        L.gemm(a, w, b, alpha, act, None, out_bf16=o)
+        torch.cuda.synchronize()
+        assert float(guard[0].float().min()) == 7.0 and float(guard[M + 1].float().max()) == 7.0
+        outs[mode] = o.clone()
+    L.gemm_set_mode(0)
+    assert torch.equal(outs[22], outs[26])
+    np.testing.assert_allclose(outs[22].float().cpu().numpy(), ref.cpu().numpy(), atol=6e-3, rtol=8e-3)
