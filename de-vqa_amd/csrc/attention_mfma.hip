@@ -15,6 +15,7 @@
 //                      r=0..3) for lane group lane>>4; the matching B operand is read from the row-major V
 //                      image with ds_read_b64_tr_b16 (4 keys x 16 channels per 16-lane group).
 // head dims that are not multiples of 32 (88, 80) are zero-padded in LDS to DHP = 96.
+#include <stdlib.h>
 #include "common.h"
 #include <type_traits>
 
@@ -29,9 +30,38 @@ __device__ __forceinline__ uint32_t am_pack2(float a, float b) {   // v_cvt_pk_b
 }
 
 #define AM_KC 64  // keys per chunk
-#define AM_QT 64  // queries per workgroup
+#define AM_QT 64  // queries per workgroup and query block (QB blocks of 16 queries per wave: AM_QT * QB per workgroup)
 
-template <int DHP>
+// Reductions over the 4 lanes {fr, fr + 16, fr + 32, fr + 48} that hold one query's scores, on the VALU: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane halves between two registers, so a butterfly step is one swap + one
+// op instead of a ds_bpermute round trip through the LDS crossbar (8 of those sat on every chunk's critical path).
+// (Inline asm: clang 22 folds op(r[0], r[1]) of __builtin_amdgcn_permlane{16,32}_swap's two results into r[0] alone.)
+__device__ __forceinline__ void am_swap16(float x, float& a, float& b) {
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "=&v"(a), "=&v"(b) : "v"(x));
+}
+__device__ __forceinline__ void am_swap32(float x, float& a, float& b) {
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "=&v"(a), "=&v"(b) : "v"(x));
+}
+__device__ __forceinline__ float am_max4(float x) {
+    float a, b;
+    am_swap16(x, a, b);
+    x = fmaxf(a, b);
+    am_swap32(x, a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float am_sum4(float x) {
+    float a, b;
+    am_swap16(x, a, b);
+    x = a + b;
+    am_swap32(x, a, b);
+    return a + b;
+}
+
+// QB = query blocks (16 queries each) per wave.  QB = 1 (default): 64-query tiles, 3 workgroups per CU.  QB = 2 (experimental,
+// DEVQA_ATTENTION_QB=2): 128-query tiles -- every K / V fragment read from LDS feeds two MFMAs (half the LDS traffic per query) and
+// long sequences need fewer workgroups that each stream the whole K / V (ViT-g, 257 tokens: 3 instead of 5 per image and head);
+// measured slower, see launch_attention_mfma.
+template <int DHP, int QB>
 __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                              const bf16_t* __restrict__ k, int64_t ldk,
                                                              const bf16_t* __restrict__ v, int64_t ldv,
@@ -55,9 +85,9 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     const int s = bid / (q_tiles * H);
     const int32_t* d = seq_desc + s * 6;
     const int q_start = d[0], q_len = d[1], kp_start = d[2], kp_len = d[3], ko_start = d[4], ko_len = d[5];
-    const int q0 = qt * AM_QT;
+    const int q0 = qt * (AM_QT * QB);
     if (q0 >= q_len) return;  // uniform per workgroup
-    const int nq = min(AM_QT, q_len - q0);
+    const int nq = min(AM_QT * QB, q_len - q0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int causal_off = ko_len - q_len;  // query i sees own keys 0..i+causal_off
@@ -65,20 +95,28 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     const int n_keys = kp_len + own_hi;
 
     // ---- Q fragments (B operand of S^T = K.Q^T): query row = wave*16 + fr, channels 32ks + 8fq .. +8 ----
-    const int qrow = q0 + wave * 16 + fr;  // index inside the sequence
-    short8_t qf[KS];
+    const int qrow0 = q0 + wave * (16 * QB) + fr;  // block b: qrow0 + 16 b (index inside the sequence)
+    short8_t qf[QB][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int c = ks * 32 + fq * 8;
-        uint4 u = make_uint4(0, 0, 0, 0);
-        if (qrow < q_len && c < dh) u = *reinterpret_cast<const uint4*>(q + (int64_t)(q_start + qrow) * ldq + h * dh + c);
-        qf[ks] = *reinterpret_cast<short8_t*>(&u);
-    }
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = ks * 32 + fq * 8;
+            const int qrow = qrow0 + 16 * b;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (qrow < q_len && c < dh) u = *reinterpret_cast<const uint4*>(q + (int64_t)(q_start + qrow) * ldq + h * dh + c);
+            qf[b][ks] = *reinterpret_cast<short8_t*>(&u);
+        }
 
-    float4_t o[DT];
+    float4_t o[QB][DT];
+    float m_run[QB], l_run[QB];  // statistics of query fr of block b (replicated over the 4 lane groups)
 #pragma unroll
-    for (int i = 0; i < DT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;  // statistics of query fr (replicated over the 4 lane groups)
+    for (int b = 0; b < QB; ++b) {
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[b][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        m_run[b] = -INFINITY;
+        l_run[b] = 0.f;
+    }
     const float sc2 = scale * 1.44269504088896340736f;
 
     constexpr int CH = DHP / 8;  // 16-byte chunks per row
@@ -117,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     auto fetch_any = [&](int c0) {
         if (c0 + AM_KC <= n_keys) fetch(c0, std::true_type{}); else fetch(c0, std::false_type{});
     };
-    const bool wave_has_rows = q0 + wave * 16 < q_len;  // waves without a query still stage K/V and hit the barriers
+    const bool wave_has_rows = q0 + wave * (16 * QB) < q_len;  // waves without a query still stage K/V and hit the barriers
     if (n_keys > 0) fetch_any(0);
     for (int c0 = 0; c0 < n_keys; c0 += AM_KC) {
         __syncthreads();  // previous chunk fully consumed
@@ -135,21 +173,26 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
         const int nt = FULLC ? 4 : min(4, (n_keys - c0 + 15) >> 4);  // 16-key tiles of this chunk that hold a key (uniform)
 
             // ---- S^T tiles: keys 16t + (4fq + r), query fr ----
-            float4_t st[4];
+            float4_t st[QB][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < QB; ++b) st[b][t] = (float4_t){0.f, 0.f, 0.f, 0.f};
                 if (!FULLC && t >= nt) continue;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const short8_t kf = *reinterpret_cast<const short8_t*>(Ks + (16 * t + fr) * STRIDE + (32 * ks + 8 * fq) * 2);
-                    st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[t], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) st[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[b][ks], st[b][t], 0, 0, 0);
                 }
             }
             // ---- mask, online softmax for query fr.  Scores stay unscaled: with c = scale * log2(e) > 0,
             // softmax(scale * s) = exp2(c * s - c * max s); masking is needed only in chunks that hold a key past the end
             // or a causally hidden key (uniform per workgroup) ----
             const bool need_mask = !FULLC && ((c0 + AM_KC > n_keys) || (causal && c0 + AM_KC > kp_len));
+            short8_t pf[QB][2];
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
             if (need_mask) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -157,56 +200,63 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                     for (int r = 0; r < 4; ++r) {
                         const int kidx = c0 + 16 * t + 4 * fq + r;
                         bool ok = kidx < n_keys;
-                        if (causal && kidx >= kp_len) ok = ok && (kidx - kp_len) <= qrow + causal_off;
-                        st[t][r] = ok ? st[t][r] : -INFINITY;
+                        if (causal && kidx >= kp_len) ok = ok && (kidx - kp_len) <= (qrow0 + 16 * b) + causal_off;
+                        st[b][t][r] = ok ? st[b][t][r] : -INFINITY;
                     }
             }
-            float mloc = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
-                               fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
-            mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(st[2][0], st[2][1]), fmaxf(st[2][2], st[2][3])),
-                                     fmaxf(fmaxf(st[3][0], st[3][1]), fmaxf(st[3][2], st[3][3]))));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run, mloc);          // running max of the UNSCALED scores
+            float mloc = fmaxf(fmaxf(fmaxf(st[b][0][0], st[b][0][1]), fmaxf(st[b][0][2], st[b][0][3])),
+                               fmaxf(fmaxf(st[b][1][0], st[b][1][1]), fmaxf(st[b][1][2], st[b][1][3])));
+            mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(st[b][2][0], st[b][2][1]), fmaxf(st[b][2][2], st[b][2][3])),
+                                     fmaxf(fmaxf(st[b][3][0], st[b][3][1]), fmaxf(st[b][3][2], st[b][3][3]))));
+            mloc = am_max4(mloc);
+            float m_new = fmaxf(m_run[b], mloc);                // running max of the UNSCALED scores
+            // Lazy rescale: the reference point of the exponentials only has to be CLOSE to the running max.  Unless some query
+            // of this wave saw its max grow by more than 2^8 (always true for a query's first visible keys), every lane keeps
+            // its previous reference: p <= 256 is harmless in bf16 / fp32, l and O stay consistent, and the alpha broadcast
+            // (4 cross-lane gathers) plus the O rescale are skipped for the chunk.
+            const bool grow = (m_new - m_run[b]) * sc2 > 8.f;   // m_run[b] = -inf, m_new finite -> true; both -inf -> NaN -> false
+            const bool rescale = __builtin_amdgcn_ballot_w64(grow) != 0;   // wave-uniform
+            if (!rescale) m_new = m_run[b];
             float alpha = 1.f, lloc = 0.f;
             if (m_new != -INFINITY) {
                 const float mc = m_new * sc2;
-                alpha = __builtin_amdgcn_exp2f(m_run * sc2 - mc);   // m_run = -inf -> 0
+                if (rescale) alpha = __builtin_amdgcn_exp2f(m_run[b] * sc2 - mc);   // m_run[b] = -inf -> 0
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], sc2, -mc));   // masked (-inf) -> 0
-                        st[t][r] = p;
+                        const float p = __builtin_amdgcn_exp2f(fmaf(st[b][t][r], sc2, -mc));   // masked (-inf) -> 0
+                        st[b][t][r] = p;
                         lloc += p;
                     }
             } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < 4; ++t) st[b][t] = (float4_t){0.f, 0.f, 0.f, 0.f};
             }
-            lloc += __shfl_xor(lloc, 16, 64);
-            lloc += __shfl_xor(lloc, 32, 64);
-            l_run = l_run * alpha + lloc;
-            m_run = m_new;
+            lloc = am_sum4(lloc);
+            l_run[b] = l_run[b] * alpha + lloc;
+            m_run[b] = m_new;
             // ---- P fragments (A operand of O = P.V): k order = (tile 2s: r 0..3, tile 2s+1: r 0..3) ----
-            short8_t pf[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 uint4 u;
-                u.x = am_pack2(st[2 * s2][0], st[2 * s2][1]);
-                u.y = am_pack2(st[2 * s2][2], st[2 * s2][3]);
-                u.z = am_pack2(st[2 * s2 + 1][0], st[2 * s2 + 1][1]);
-                u.w = am_pack2(st[2 * s2 + 1][2], st[2 * s2 + 1][3]);
-                pf[s2] = *reinterpret_cast<short8_t*>(&u);
+                u.x = am_pack2(st[b][2 * s2][0], st[b][2 * s2][1]);
+                u.y = am_pack2(st[b][2 * s2][2], st[b][2 * s2][3]);
+                u.z = am_pack2(st[b][2 * s2 + 1][0], st[b][2 * s2 + 1][1]);
+                u.w = am_pack2(st[b][2 * s2 + 1][2], st[b][2 * s2 + 1][3]);
+                pf[b][s2] = *reinterpret_cast<short8_t*>(&u);
             }
             // ---- rescale O: its rows are queries 4fq + r, whose alpha lives in lane (fr' = 4fq + r) ----
-            float ar[4];
+            if (rescale) {
+                float ar[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * fq + r, 64);
+                for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * fq + r, 64);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
+                    for (int r = 0; r < 4; ++r) o[b][dt][r] *= ar[r];
+            }
+            }
             // ---- O += P.V with transposed LDS reads of the row-major V image ----
             const int tq = fr >> 2, tp = fr & 3;  // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
 #pragma unroll
@@ -219,7 +269,8 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                     const short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (lds_s4_ptr)(Vs + (16 * (2 * s2 + 1) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
                     const short8_t vf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[s2], vf, o[dt], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) o[b][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][s2], vf, o[b][dt], 0, 0, 0);
                 }
             }
         };
@@ -229,19 +280,22 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     }
 
     // ---- normalise and store: O row = query 4fq + r, column = channel 16dt + fr ----
-    float lr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run, 4 * fq + r, 64);
+    for (int b = 0; b < QB; ++b) {
+        float lr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + wave * 16 + 4 * fq + r;
-        if (qi >= q_len) continue;
-        const float inv = lr[r] > 0.f ? 1.f / lr[r] : 0.f;
-        bf16_t* orow = out + (int64_t)(q_start + qi) * ldo + h * dh;
+        for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run[b], 4 * fq + r, 64);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int c = 16 * dt + fr;
-            if (c < dh) orow[c] = f32_to_bf16(o[dt][r] * inv);
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + wave * (16 * QB) + 16 * b + 4 * fq + r;
+            if (qi >= q_len) continue;
+            const float inv = lr[r] > 0.f ? 1.f / lr[r] : 0.f;
+            bf16_t* orow = out + (int64_t)(q_start + qi) * ldo + h * dh;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int c = 16 * dt + fr;
+                if (c < dh) orow[c] = f32_to_bf16(o[b][dt][r] * inv);
+            }
         }
     }
 }
@@ -249,14 +303,25 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
 int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t ldk, const bf16_t* v, int64_t ldv, bf16_t* out,
                           int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale,
                           int causal, void* stream) {
-    const int q_tiles = (max_q_len + AM_QT - 1) / AM_QT;
+    const int dhp = (dh + 31) / 32 * 32;
+    // QB = 2 (128-query tiles) is built and tested (DEVQA_ATTENTION_QB=2) but NOT the default: on ViT-g (127 images x 16 heads x
+    // 257 tokens) it measured 223 us against 207 us for QB = 1 -- halving the LDS fragment traffic does not pay for the occupancy
+    // lost to 221 VGPRs; the kernel is bound by its ~19 VALU instructions per MFMA (SQ counters, profiles/r01_summary.md H).
+    const char* qb_env = getenv("DEVQA_ATTENTION_QB");     // read per launch: the tests flip it
+    const int qb = (qb_env && atoi(qb_env) == 2 && max_q_len > 2 * AM_QT && dhp <= 96) ? 2 : 1;
+    const int q_tiles = (max_q_len + AM_QT * qb - 1) / (AM_QT * qb);
     const long grid = (long)n_seq * H * q_tiles;
     DEVQA_CHECK_SHAPE(grid < 2147483647L, "attention: grid too large");
-    const int dhp = (dh + 31) / 32 * 32;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(D)                                                                                                      \
-    hipLaunchKernelGGL(attention_mfma_kernel<D>, dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, \
-                       seq_desc, H, dh, scale, causal, q_tiles)
+    do {                                                                                                               \
+        if (qb == 2)                                                                                                   \
+            hipLaunchKernelGGL((attention_mfma_kernel<D, 2>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, \
+                               ldo, seq_desc, H, dh, scale, causal, q_tiles);                                          \
+        else                                                                                                           \
+            hipLaunchKernelGGL((attention_mfma_kernel<D, 1>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, \
+                               ldo, seq_desc, H, dh, scale, causal, q_tiles);                                          \
+    } while (0)
     if (dhp == 32) LAUNCH(32);
     else if (dhp == 64) LAUNCH(64);
     else if (dhp == 96) LAUNCH(96);

@@ -157,6 +157,14 @@ def test_attention(L, name):
     d = torch.tensor(desc, dtype=torch.int32, device="cuda")
     out = L.attention(views[0], views[1], views[2], d, len(desc), max(x[1] for x in desc), H, dh, scale, causal)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=2e-2)
+    if name == "vit":   # the experimental 128-query-tile instantiation (two query blocks per wave) on the same inputs
+        import os
+        os.environ["DEVQA_ATTENTION_QB"] = "2"
+        try:
+            out2 = L.attention(views[0], views[1], views[2], d, len(desc), max(x[1] for x in desc), H, dh, scale, causal)
+        finally:
+            del os.environ["DEVQA_ATTENTION_QB"]
+        np.testing.assert_allclose(out2.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=2e-2)
 
 
 def test_patch_embed_and_assemble(L):
