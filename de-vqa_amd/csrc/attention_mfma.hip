@@ -122,50 +122,39 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     constexpr int CH = DHP / 8;  // 16-byte chunks per row
     constexpr int LD = AM_KC * CH / 256;  // 16-byte pieces of K (and of V) per thread and chunk
     static_assert(AM_KC * CH % 256 == 0, "chunk must split evenly over the workgroup");
-    uint4 kreg[LD], vreg[LD];
-    // loop-invariant part of this thread's LD staging pieces: LDS offset, channel base pointers, row inside the chunk
-    int st_off[LD], st_row[LD];
-    const bf16_t* kcol[LD];
-    const bf16_t* vcol[LD];
-    bool st_ch[LD];
+    typedef unsigned am_u32x4_t __attribute__((ext_vector_type(4)));   // (a struct uint4 copied straight from global memory is not
+    am_u32x4_t kreg[LD], vreg[LD];                                     //  promoted out of scratch by this compiler)
+    // loop-invariant part of this thread's LD staging pieces: LDS offset, channel base pointers, row inside the chunk.  The loads are
+    // UNPREDICATED: a row past the last key re-reads the last key (its scores are masked to -inf and p = 0 multiplies a finite V row),
+    // a 16-byte piece in the channel padding (dh..DHP) re-reads the last 8 real channels (K: multiplied by Q's zero padding; V: lands
+    // in output columns >= dh, which are never stored) -- no exec-masked branches around 2 x LD loads per chunk.
+    int st_off[LD], st_row[LD], st_col[LD];
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
         const int i = tid + j * 256;
         const int r = i / CH, cv = i - r * CH;
         st_row[j] = r;
         st_off[j] = r * STRIDE + cv * 16;
-        st_ch[j] = cv * 8 < dh;
-        kcol[j] = k + h * dh + cv * 8;
-        vcol[j] = v + h * dh + cv * 8;
+        st_col[j] = h * dh + min(cv * 8, dh - 8);
     }
-    auto fetch = [&](int c0, auto full_tag) {   // chunk c0 -> registers (zero beyond n_keys / dh)
-        constexpr bool FULLC = decltype(full_tag)::value;   // every row of the chunk is a key: no row predicate
-#pragma unroll
-        for (int j = 0; j < LD; ++j) {
-            const int kidx = c0 + st_row[j];
-            kreg[j] = make_uint4(0, 0, 0, 0);
-            vreg[j] = kreg[j];
-            if ((FULLC || kidx < n_keys) && st_ch[j]) {
-                const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);
-                kreg[j] = *reinterpret_cast<const uint4*>(kcol[j] + grow * ldk);
-                vreg[j] = *reinterpret_cast<const uint4*>(vcol[j] + grow * ldv);
-            }
-        }
-    };
-    auto fetch_any = [&](int c0) {
-        if (c0 + AM_KC <= n_keys) fetch(c0, std::true_type{}); else fetch(c0, std::false_type{});
-    };
+#define AM_FETCH(C0)                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < LD; ++j) {                                                                        \
+        const int kidx = min((C0) + st_row[j], n_keys - 1);                                                                 \
+        const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);            \
+        kreg[j] = *reinterpret_cast<const am_u32x4_t*>(k + grow * ldk + st_col[j]);                                         \
+        vreg[j] = *reinterpret_cast<const am_u32x4_t*>(v + grow * ldv + st_col[j]);                                         \
+    }
     const bool wave_has_rows = q0 + wave * (16 * QB) < q_len;  // waves without a query still stage K/V and hit the barriers
-    if (n_keys > 0) fetch_any(0);
+    if (n_keys > 0) { AM_FETCH(0) }
     for (int c0 = 0; c0 < n_keys; c0 += AM_KC) {
         __syncthreads();  // previous chunk fully consumed
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
-            *reinterpret_cast<uint4*>(Ks + st_off[j]) = kreg[j];
-            *reinterpret_cast<uint4*>(Vs + st_off[j]) = vreg[j];
+            *reinterpret_cast<am_u32x4_t*>(Ks + st_off[j]) = kreg[j];
+            *reinterpret_cast<am_u32x4_t*>(Vs + st_off[j]) = vreg[j];
         }
         __syncthreads();
-        if (c0 + AM_KC < n_keys) fetch_any(c0 + AM_KC);  // next chunk's loads fly under this chunk's MFMAs
+        if (c0 + AM_KC < n_keys) { AM_FETCH(c0 + AM_KC) }  // next chunk's loads fly under this chunk's MFMAs
         if (!wave_has_rows) continue;
         // FULL chunks (64 keys, none hidden by the causal rule) take a branch-free instantiation of the body
         auto body = [&](auto full_tag) {
