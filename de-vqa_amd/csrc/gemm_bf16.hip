@@ -204,7 +204,7 @@ extern "C" int devqa_profile_gemm_read(double* ms, double* flops, int64_t* launc
     return DEVQA_OK;
 }
 
-// ---- split-K for skinny problems with a very long K (dH = dlogits . E: M <= 64, N = 2560, K = 50272) ----
+// ---- split-K for skinny problems with a very long K (dH = dlogits . E: M <= 256, N = 2560, K = 50272) ----
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn4, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 s = reinterpret_cast<const float4*>(part)[i];
@@ -220,7 +220,7 @@ extern "C" int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const de
                                       int splits, float* partial_ws, float* out_f32, void* stream) {
     DEVQA_CHECK_ARG(A && W && partial_ws && out_f32, "gemm_splitk: null pointer");
     if (M == 0 || N == 0) return DEVQA_OK;
-    DEVQA_CHECK_SHAPE(M > 0 && M <= 64 && N > 0 && N % 4 == 0 && K > 0, "gemm_splitk: needs 0 < M <= 64, N %% 4 == 0");
+    DEVQA_CHECK_SHAPE(M > 0 && M <= 256 && N > 0 && N % 4 == 0 && K > 0, "gemm_splitk: needs 0 < M <= 256, N %% 4 == 0");
     DEVQA_CHECK_SHAPE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "gemm_splitk: bad K / leading dims");
     DEVQA_CHECK_SHAPE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm_splitk: operands must be 16-byte aligned");
     const int nk = (K + BK - 1) / BK;
@@ -229,9 +229,30 @@ extern "C" int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const de
     const int used = (nk + steps - 1) / steps;  // every launched split owns >= 1 step
     hipStream_t st = (hipStream_t)stream;
     const int tiles_n = (N + 127) / 128;
-    auto kern = gemm_bf16_tn_kernel<64, 128, 2, 2>;
-    hipLaunchKernelGGL(kern, dim3(tiles_n, used), dim3(256), 2 * (64 + 128) * BK * 2, st, A, lda, W, ldw, (const float*)nullptr, M,
-                       N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, partial_ws, (int64_t)N, 1, tiles_n, steps);
+    // one row tile covers all M rows, so W (the long operand: 257 MB for dH = dlogits . E) streams through the chip ONCE per call
+    if (M <= 64) {
+        auto kern = gemm_bf16_tn_kernel<64, 128, 2, 2>;
+        hipLaunchKernelGGL(kern, dim3(tiles_n, used), dim3(256), 2 * (64 + 128) * BK * 2, st, A, lda, W, ldw, (const float*)nullptr, M,
+                           N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, partial_ws, (int64_t)N, 1, tiles_n, steps);
+    } else if (M <= 128) {
+        auto kern = gemm_bf16_tn_kernel<128, 128, 2, 2>;
+        static bool attr128 = false;
+        if (!attr128) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * BK * 2);
+            attr128 = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(tiles_n, used), dim3(256), 2 * (128 + 128) * BK * 2, st, A, lda, W, ldw, (const float*)nullptr, M,
+                           N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, partial_ws, (int64_t)N, 1, tiles_n, steps);
+    } else {
+        auto kern = gemm_bf16_tn_kernel<256, 128, 2, 2>;
+        static bool attr256 = false;
+        if (!attr256) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * BK * 2);
+            attr256 = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(tiles_n, used), dim3(256), 2 * (256 + 128) * BK * 2, st, A, lda, W, ldw, (const float*)nullptr, M,
+                           N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, partial_ws, (int64_t)N, 1, tiles_n, steps);
+    }
     DEVQA_LAUNCH_CHECK("gemm_splitk");
     const int64_t mn4 = (int64_t)M * N / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256 < 1024 ? (mn4 + 255) / 256 : 1024)), dim3(256), 0, st,

@@ -112,7 +112,7 @@ EXPORTS = ["devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_ro
 
 def gemm_rows_longk(a, w):
     """fp32 [M,N] = a[M,K] @ w[N,K].T for a few rows and a very long K (dH = dlogits . E): split-K on the
-    bf16 MFMA kernel in row groups of <= 64 (fp32 operands: exact-fp32 GEMM)."""
+    bf16 MFMA kernel, all (<= 256) rows in one launch so that w streams once (fp32 operands: exact-fp32 GEMM)."""
     if a.dtype != torch.bfloat16:
         return gemm(a, w, want="f32")
     M, K = a.shape
@@ -122,11 +122,22 @@ def gemm_rows_longk(a, w):
     nk = (K + 63) // 64
     splits = max(1, min(nk, 640 // max(1, (N + 127) // 128)))
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    ws = torch.empty((splits, min(M, 64), N), dtype=torch.float32, device=a.device)
-    for r0 in range(0, M, 64):
-        m = min(64, M - r0)
+    # rows per launch: the kernel has 64 / 128 / 256-row tiles and w streams once per launch.  Measured on dH (K = 50272, N = 2560,
+    # tools/splitk_rows_bench.py): 64 rows 68 us, 100 rows 110 us (2 x 64: 138), 250 rows 234 us (4 x 64: 291); 129..192 rows are
+    # cheapest as 128 + rest (the 256-row tile is compute-limited when a third of it is padding).
+    env = os.environ.get("DEVQA_SPLITK_ROWS")
+    if env:
+        groups = [min(int(env), M - r0) for r0 in range(0, M, int(env))]
+    elif 128 < M <= 192:
+        groups = [128, M - 128]
+    else:
+        groups = [M]
+    ws = torch.empty((splits, max(groups), N), dtype=torch.float32, device=a.device)
+    r0 = 0
+    for m in groups:
         _chk(load().devqa_gemm_bf16_splitk(_p(a[r0:r0 + m]), a.stride(0), _p(w), w.stride(0), m, N, K, splits, _p(ws), _p(out[r0:r0 + m]),
                                            _stream()), "devqa_gemm_bf16_splitk")
+        r0 += m
     return out
 
 

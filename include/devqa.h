@@ -57,7 +57,7 @@ int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64
                     int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
                     float* out_f32, int64_t ldc, void* stream);
 
-/* Split-K form for skinny problems with a very long K (K10: dH = dlogits[rows,V] . E[V,d], rows <= 64):
+/* Split-K form for skinny problems with a very long K (K10: dH = dlogits[rows,V] . E[V,d], rows <= 256; one row tile of 64 / 128 / 256 so that W streams once):
  * the K range is cut into `splits` slices (one workgroup column each), raw fp32 partial slabs go to
  * partial_ws [splits][M][N] and a second launch sums them in slice order (deterministic).  No epilogue. */
 int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64_t ldw, int M, int N, int K,

@@ -1,4 +1,4 @@
-"""Split-K GEMM (dH = dlogits . E) against fp32 PyTorch."""
+"""Split-K GEMM (dH = dlogits . E) against fp32 PyTorch: the 64-, 128- and 256-row tiles and the 128 + rest grouping."""
 import numpy as np
 import pytest
 import torch
@@ -6,7 +6,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,N,K", [(48, 2560, 50272), (3, 40, 640), (64, 2560, 4096), (17, 136, 50272)])
+@pytest.mark.parametrize("M,N,K", [(48, 2560, 50272), (3, 40, 640), (64, 2560, 4096), (17, 136, 50272),
+                                   (100, 2560, 50272), (128, 264, 4096), (180, 2560, 50272), (250, 2560, 8192), (256, 40, 640)])
 def test_splitk(M, N, K):
     import devqa_amd  # noqa: F401
     from devqa_amd import lib
