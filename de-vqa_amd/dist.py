@@ -22,8 +22,12 @@ def init_from_env(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group(backend=backend)
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        # bind the communicator to this rank's GPU up front: no device guessing in barrier(), RCCL set-up happens here
+        dist.init_process_group(backend=backend, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
 
 

@@ -1,0 +1,56 @@
+"""GPU: the RCCL ("nccl") legs of the multi-GPU path on the one GPU of the test box -- a 1-rank process group exercises the same
+collectives bench.py and the evaluator issue at N > 1 (barrier, MAX all-reduce of the elapsed time, the all-gather of score rows and
+the ragged gather), so a broken RCCL / IPC setup fails here rather than in the 8-GPU run.  The N = 2 logic (sharding, ordering) is
+covered on CPU with gloo in tests/test_dist_cpu.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_rccl_single_rank_collectives():
+    import torch.distributed as dist
+    import devqa_amd  # noqa: F401
+    from devqa_amd.batched import BatchedEditEval
+    from devqa_amd.dist import gather_results, gather_results_ragged, init_from_env
+    from test_dist_cpu import _fake_result
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    old = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", world_size=1, rank=0)
+        assert init_from_env() == (0, 1)          # already initialised: returns the env's rank / world
+        dev = torch.device("cuda:0")
+        dist.barrier()
+        t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 1.25
+        n = 5
+        local = [_fake_result(i) for i in range(n)]
+        rows = BatchedEditEval.score_rows(local, [(25, 0.5)] * n, 0)
+        allres = gather_results(local, rows, n, 0, 1, dev)
+        assert [r["reliability"][0]["predict_after_edit"] for r in allres] == ["r%d" % i for i in range(n)]
+        allres = gather_results_ragged(local, np.asarray(rows, np.float32), 0, 1, dev)
+        assert len(allres) == n
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
