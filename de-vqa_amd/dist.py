@@ -13,10 +13,11 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* if WORLD_SIZE > 1."""
+def init_from_env(backend=None, min_world=2):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* if WORLD_SIZE >= min_world (2: a single process needs no group;
+    the GPU test passes 1 to drive this very code path with one rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 or dist.is_initialized():
+    if world < min_world or dist.is_initialized():
         return int(os.environ.get("RANK", "0")), world
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"

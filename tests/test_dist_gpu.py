@@ -31,9 +31,9 @@ def test_rccl_single_rank_collectives():
     old = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     try:
-        torch.cuda.set_device(0)
-        dist.init_process_group(backend="nccl", world_size=1, rank=0)
-        assert init_from_env() == (0, 1)          # already initialised: returns the env's rank / world
+        assert init_from_env(min_world=1) == (0, 1)      # the product's own initialisation (backend nccl, device bound)
+        assert dist.get_backend() == "nccl"
+        assert init_from_env() == (0, 1)                  # already initialised: returns the env's rank / world
         dev = torch.device("cuda:0")
         dist.barrier()
         t = torch.tensor([1.25], dtype=torch.float64, device=dev)
