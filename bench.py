@@ -135,7 +135,9 @@ def main():
     from devqa_amd.synth import IdTokenizer, evqa_cycles, synth_image_u8
     import torch.distributed as dist
 
-    rank, world = init_from_env()
+    # DEVQA_FORCE_DIST=1: build the process group (RCCL) even for one rank, so that a 1-GPU box walks the N > 1 branches below
+    rank, world = init_from_env(min_world=1 if os.environ.get("DEVQA_FORCE_DIST") else 2)
+    use_dist = dist.is_initialized()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(dev)
@@ -170,7 +172,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -188,7 +190,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     lib.profile_gemm(0)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -242,7 +244,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -54,3 +54,22 @@ def test_rccl_single_rank_collectives():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_bench_walks_the_distributed_branches_with_one_rank():
+    """bench.py under DEVQA_FORCE_DIST=1: RCCL process group, barrier-bracketed timed region, MAX all-reduce of the elapsed time,
+    the gather of score rows, destroy -- the code the 8-GPU launch runs, here with world size 1 and a 2-layer model."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               DEVQA_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--cycles-per-step", "4", "--layers", "2,2,2", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert {"roofline", "cpu_baseline", "config"} <= set(j) and j["roofline"]["bound"] == "mfma"
