@@ -383,19 +383,41 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
         const char* e = getenv("DEVQA_GEMM");
         g_gemm_mode = e ? atoi(e) : 0;
     }
-    if (M <= 64 && g_gemm_mode == 0 && N % 4 == 0 && ldc % 4 == 0 &&
+    // Skinny problems are weight streams: with one 64x128 (128x128) tile per 128 output columns a [64 x 10240 x 2560] product runs
+    // on 80 workgroups, and the 257-row GEMMs of a single-image ViT pass on 33-165.  When the tiles cover less than half the chip,
+    // split K over enough workgroups to fill it (fp32 partials in the per-stream workspace, one reduce + epilogue pass).
+    static int splitk_max_m = -1;     // DEVQA_SPLITK_MAXM (default 1024; 64 = the small-M rule only) for A/B runs
+    if (splitk_max_m < 0) {
+        const char* e = getenv("DEVQA_SPLITK_MAXM");
+        splitk_max_m = e ? atoi(e) : 1024;
+    }
+    if (M <= splitk_max_m && g_gemm_mode == 0 && N % 4 == 0 && ldc % 4 == 0 &&
         ((((uintptr_t)out_f32) | ((uintptr_t)residual) | ((uintptr_t)bias)) & 15) == 0 && (((uintptr_t)out_bf16) & 7) == 0) {
-        const int tiles_n = (N + 127) / 128, nk = (K + BK - 1) / BK;
-        int splits = 512 / tiles_n;
+        const int bm = M <= 64 ? 64 : 128;
+        const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + 127) / 128, nk = (K + BK - 1) / BK;
+        const int tiles = tiles_m * tiles_n;
+        int splits = (M <= 64 || tiles < 128) ? 512 / tiles : 1;
         if (splits > nk / 4) splits = nk / 4;
         if (splits >= 2) {
             const int steps = (nk + splits - 1) / splits;
             const int used = (nk + steps - 1) / steps;
             float* ws = splitk_workspace(st, (size_t)used * M * N * sizeof(float));
             if (ws) {
-                auto kern = gemm_bf16_tn_kernel<64, 128, 2, 2>;
-                hipLaunchKernelGGL(kern, dim3(tiles_n, used), dim3(256), 2 * (64 + 128) * BK * 2, st, A, lda, W, ldw, (const float*)nullptr,
-                                   M, N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, ws, (int64_t)N, 1, tiles_n, steps);
+                if (bm == 64) {
+                    auto kern = gemm_bf16_tn_kernel<64, 128, 2, 2>;
+                    hipLaunchKernelGGL(kern, dim3(tiles, used), dim3(256), 2 * (64 + 128) * BK * 2, st, A, lda, W, ldw, (const float*)nullptr,
+                                       M, N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, ws, (int64_t)N, tiles_m, tiles_n, steps);
+                } else {
+                    auto kern = gemm_bf16_tn_kernel<128, 128, 2, 2>;
+                    static bool attr_done = false;
+                    if (!attr_done) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  2 * (128 + 128) * BK * 2);
+                        attr_done = true;
+                    }
+                    hipLaunchKernelGGL(kern, dim3(tiles, used), dim3(256), 2 * (128 + 128) * BK * 2, st, A, lda, W, ldw, (const float*)nullptr,
+                                       M, N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, ws, (int64_t)N, tiles_m, tiles_n, steps);
+                }
                 DEVQA_LAUNCH_CHECK("gemm_small_m_splitk");
                 const int64_t mn4 = (int64_t)M * N / 4;
                 hipLaunchKernelGGL(splitk_reduce_epilogue_kernel, dim3((unsigned)((mn4 + 255) / 256 < 2048 ? (mn4 + 255) / 256 : 2048)),

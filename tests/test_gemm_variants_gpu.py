@@ -50,6 +50,11 @@ def test_gemm_variants(L, mode, M, N, K, act, res):
     (64, 7680, 2560, 0, False, "bf16"),     # fused qkv
     (17, 4096, 11008, 0, True, "f32"),      # LLaMA down_proj
     (48, 50272, 2560, 0, False, "f32"),     # lm_head rows: enough column tiles, no split
+    (257, 1408, 6144, 0, True, "f32"),      # single-image ViT fc2: 3 x 11 tiles of 128x128 -> 15 K-slices, in-place fp32 residual
+    (257, 4224, 1408, 0, False, "bf16"),    # single-image ViT QKV: 99 tiles -> 5 K-slices
+    (300, 1408, 1408, 0, True, "f32"),      # projection, ragged M
+    (512, 2560, 2560, 1, False, "bf16"),    # upper end of the split range (4 x 20 tiles)
+    (180, 2560, 1088, 0, False, "f32"),     # compacted-column fc2 rows of the FT loop
 ])
 def test_small_m_splitk_epilogue(L, M, N, K, act, res, want):
     L.gemm_set_mode(0)
