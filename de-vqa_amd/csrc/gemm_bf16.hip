@@ -366,6 +366,15 @@ float* splitk_workspace(hipStream_t st, size_t bytes) {   // one buffer per (dev
 }
 }  // namespace
 
+// shared with gemm_f32.hip: the per-(device, stream) partial-sum workspace and the reduce + epilogue pass
+float* devqa_splitk_workspace(hipStream_t st, size_t bytes) { return splitk_workspace(st, bytes); }
+void devqa_launch_splitk_reduce_epilogue(const float* ws, int splits, int M, int N, const float* bias, float alpha, int act,
+                                         const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc, hipStream_t st) {
+    const int64_t mn4 = (int64_t)M * N / 4;
+    hipLaunchKernelGGL(splitk_reduce_epilogue_kernel, dim3((unsigned)((mn4 + 255) / 256 < 2048 ? (mn4 + 255) / 256 : 2048)), dim3(256), 0,
+                       st, ws, splits, M, N, bias, alpha, act, residual, out_bf16, out_f32, ldc);
+}
+
 extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64_t ldw, const float* bias,
                                int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
                                float* out_f32, int64_t ldc, void* stream) {

@@ -107,3 +107,30 @@ def test_gemm_bf16_output_epilogues(L, M, N, K, act, bias, alpha):
     L.gemm_set_mode(0)
     assert torch.equal(outs[22], outs[26])
     np.testing.assert_allclose(outs[22].float().cpu().numpy(), ref.cpu().numpy(), atol=6e-3, rtol=8e-3)
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (48, 1920, 12800, 0, False),     # MEND hyper-network v-GEMM: 30 tiles -> 17 K-slices
+    (64, 2560, 10240, 0, True),      # OPT fc2 rows, in-place residual, split
+    (100, 200, 4096, 1, False),      # two row tiles, ragged N, ReLU, split
+    (48, 12800, 1920, 0, False),     # 200 tiles: no split
+    (7, 40, 640, 2, True),           # tiny: no split (K < 2048)
+])
+def test_gemm_f32_exact_and_splitk(L, M, N, K, act, res):
+    """The exact-fp32 GEMM (fp32 operands through lib.gemm), with and without its automatic split-K, against float64."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if res else None
+    ref = a.double() @ w.double().T + b.double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + r.double()
+    rd = r.cuda() if res else None
+    out = L.gemm(a.cuda(), w.cuda(), b.cuda(), 1.0, act, rd, out_f32=rd if res else None, want="f32")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=2e-5, rtol=2e-5)
