@@ -86,7 +86,7 @@ class BaseVLLMForEdit(ABC):
     def prompts_imgs_target_to_xym(self, prompts: List[str], imgs: List, targets: List[str]):
         input_strs, y, m, _ = self.xym_token_bookkeeping(prompts, targets)
         input_embeds, vt_range = self.get_llm_input_embeds(input_strs, imgs)
-        return (input_embeds, vt_range), y.to(self.device), m.to(self.device)
+        return (input_embeds, vt_range), lib.h2d(y, y.dtype, self.device), lib.h2d(m, m.dtype, self.device)
 
     # base.py:111-119 (K9) -- masked NLL on the HIP vocab-rows kernel (no autograd graph)
     def label_loss(self, logits, label_ids, label_masks, average=True):

@@ -73,12 +73,12 @@ class BLIP2OPTForEdit(BaseVLLMForEdit):
 
     def get_llm_input_embeds(self, texts: List[str], imgs: Optional[List] = None):
         tk = self.tokenizer(texts, return_tensors="pt", padding=True)
-        ids = tk["input_ids"].to(self.device)
-        msk = tk["attention_mask"].to(self.device)
-        emb_w = self.model.get("language_model.model.decoder.embed_tokens.weight")
-        B, T = ids.shape
         from .... import lib
-        emb = lib.gather_rows(emb_w, ids.reshape(-1).to(torch.int32).contiguous()).to(torch.float32).view(B, T, -1)
+        B, T = tk["input_ids"].shape
+        ids = lib.h2d(tk["input_ids"].reshape(-1), torch.int32, self.device)
+        msk = lib.h2d(tk["attention_mask"], torch.int64, self.device)
+        emb_w = self.model.get("language_model.model.decoder.embed_tokens.weight")
+        emb = lib.gather_rows(emb_w, ids).to(torch.float32).view(B, T, -1)
         if imgs is not None:
             if isinstance(imgs, list):
                 imgs = imgs[-1]  # quirk kept: only the LAST image of the list is used (blip2.py:54-55)

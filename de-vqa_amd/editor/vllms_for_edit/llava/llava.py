@@ -77,8 +77,8 @@ class LlavaForEdit(BaseVLLMForEdit):
     def get_llm_input_embeds(self, texts: List[str], imgs: Optional[List] = None):
         from .... import lib
         tk = self.tokenizer(texts, return_tensors="pt", padding=True)
-        ids = tk["input_ids"].to(self.device)
-        msk = tk["attention_mask"].to(self.device)
+        ids = lib.h2d(tk["input_ids"], tk["input_ids"].dtype, self.device)
+        msk = lib.h2d(tk["attention_mask"], tk["attention_mask"].dtype, self.device)
         B, T = ids.shape
         emb = lib.gather_rows(self.engine.embed_table(), ids.reshape(-1).to(torch.int32).contiguous()).to(torch.float32).view(B, T, -1)
         vt_range = None
@@ -86,7 +86,7 @@ class LlavaForEdit(BaseVLLMForEdit):
             if B != 1:
                 raise BaseException("LlavaForEdit (HIP path): image inputs are supported one text at a time")
             feats = self.image_features(imgs)                            # [1, n_img, d]
-            pos = int(torch.where(ids[0] == self.get_img_special_token_id())[0][0])
+            pos = int(torch.where(tk["input_ids"][0] == self.get_img_special_token_id())[0][0])   # host copy: no device sync
             emb = torch.cat([emb[:, :pos], feats, emb[:, pos + 1:]], dim=1)
             msk = torch.ones(emb.shape[:2], dtype=msk.dtype, device=self.device)
             vt_range = [pos, pos + self.get_img_token_n()]

@@ -68,7 +68,7 @@ class MiniGPT4ForEdit(BaseVLLMForEdit):
         emb_tab = self.engine.embed_table()
 
         def embed(ids):
-            t = torch.tensor(ids, dtype=torch.int32, device=self.device)
+            t = lib.h2d(ids, torch.int32, self.device)
             return lib.gather_rows(emb_tab, t).to(torch.float32)
         if imgs is not None:
             feats = self.image_features(imgs)                           # [B, 32, d]
@@ -85,10 +85,9 @@ class MiniGPT4ForEdit(BaseVLLMForEdit):
             llm_inpt = {"inputs_embeds": emb, "attention_mask": msk}
         else:
             tk = self.tokenizer(texts, return_tensors="pt", padding=True)
-            ids = tk["input_ids"].to(self.device)
-            B, T = ids.shape
-            emb = embed(ids.reshape(-1).tolist()).view(B, T, -1)
-            llm_inpt = {"attention_mask": tk["attention_mask"].to(self.device), "inputs_embeds": emb}
+            B, T = tk["input_ids"].shape
+            emb = embed(tk["input_ids"].reshape(-1)).view(B, T, -1)
+            llm_inpt = {"attention_mask": lib.h2d(tk["attention_mask"], tk["attention_mask"].dtype, self.device), "inputs_embeds": emb}
         if self.auto_add_img_special_token:
             vt_range = None if imgs is None else [1, self.get_img_token_n() + 1]
         else:

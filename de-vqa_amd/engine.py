@@ -173,20 +173,21 @@ class Blip2Engine:
     # K6: decoder input rows
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def pack_from_embeds(self, inputs_embeds, attention_mask):
+    def pack_from_embeds(self, inputs_embeds, attention_mask, lens=None):
         """[B,T,d] embeddings (+ right-padding mask) -> packed rows with OPT positions added.
-        Padded rows are kept (so logits come back as [B,T,V]) but never attended to."""
+        Padded rows are kept (so logits come back as [B,T,V]) but never attended to.  `lens` (host list of sequence lengths)
+        spares the device -> host read of the mask sums when the caller knows them."""
         B, T, d = inputs_embeds.shape
         am = attention_mask.to(torch.int64)
-        lens = am.sum(1).tolist()
+        if lens is None:
+            lens = am.sum(1).tolist()
         pos = (torch.cumsum(am, 1) * am - 1).to(torch.int32).reshape(-1).contiguous()
         rows = inputs_embeds.reshape(B * T, d).to(torch.float32).contiguous()
         src = torch.arange(B * T, dtype=torch.int32, device=self.dev)
         tok = torch.zeros(B * T, dtype=torch.int32, device=self.dev)
         x = lib.embed_rows(tok, src, pos.to(self.dev), self._p("language_model.model.decoder.embed_tokens.weight"), rows,
                            self._p("language_model.model.decoder.embed_positions.weight"))
-        desc = torch.tensor([[b * T, int(lens[b]), 0, 0, b * T, int(lens[b])] for b in range(B)], dtype=torch.int32,
-                            device=self.dev)
+        desc = lib.h2d([[b * T, int(lens[b]), 0, 0, b * T, int(lens[b])] for b in range(B)], torch.int32, self.dev)
         return PackedSeqs(x, [b * T for b in range(B)], [int(n) for n in lens], desc, T)
 
     @torch.no_grad()

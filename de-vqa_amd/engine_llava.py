@@ -90,13 +90,13 @@ class LlavaEngine:
 
     # ---- decoder input rows -----------------------------------------------------------------------------------
     @torch.no_grad()
-    def pack_from_embeds(self, inputs_embeds, attention_mask):
+    def pack_from_embeds(self, inputs_embeds, attention_mask, lens=None):
         B, T, d = inputs_embeds.shape
-        lens = attention_mask.to(torch.int64).sum(1).tolist()
+        if lens is None:
+            lens = attention_mask.to(torch.int64).sum(1).tolist()
         x = inputs_embeds.reshape(B * T, d).to(torch.float32).contiguous().clone()
         pos = torch.arange(T, dtype=torch.int32, device=self.dev).repeat(B).contiguous()   # LLaMA: arange positions
-        desc = torch.tensor([[b * T, int(lens[b]), 0, 0, b * T, int(lens[b])] for b in range(B)], dtype=torch.int32,
-                            device=self.dev)
+        desc = lib.h2d([[b * T, int(lens[b]), 0, 0, b * T, int(lens[b])] for b in range(B)], torch.int32, self.dev)
         ps = PackedSeqs(x, [b * T for b in range(B)], [int(n) for n in lens], desc, T)
         ps.pos = pos
         return ps

@@ -78,15 +78,16 @@ class VLLMEditorEvaluation:
             B, d = len(chunk), chunk[0][1].shape[1]
             emb = torch.zeros((B, tmax, d), dtype=torch.float32, device=chunk[0][1].device)
             msk = torch.zeros((B, tmax), dtype=torch.int32, device=emb.device)
-            rows = []
+            rows, lens = [], []
             for b, (_, e, y, m) in enumerate(chunk):
                 T, L = e.shape[0], y.shape[1]
                 emb[b, :T] = e
                 msk[b, :T] = 1
+                lens.append(T)
                 rows += [b * tmax + T - L + j for j in range(L)]
-            ps = eng.pack_from_embeds(emb, msk)
+            ps = eng.pack_from_embeds(emb, msk, lens=lens)
             x_fin, _ = eng.decoder_layers(ps)
-            idx = torch.tensor(rows, dtype=torch.int32, device=emb.device)
+            idx = lib.h2d(rows, torch.int32, emb.device)
             logits = eng.lm_head(lib.gather_rows(x_fin, idx))
             pre, _, _ = lib.vocab_rows(logits)
             pre = pre.to(torch.long)

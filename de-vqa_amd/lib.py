@@ -167,6 +167,19 @@ def _p(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+def h2d(data, dtype, device):
+    """Small host -> device transfer that does NOT wait for the stream: pinned staging + non_blocking copy.  `torch.tensor(list,
+    device=...)` / pageable `.to(device)` block the host until the queued GPU work has drained (~0.2 ms per call under load), which
+    serialises the per-probe bookkeeping of the generic evaluator with the GPU; the caching host allocator keeps the pinned block
+    alive until the copy has run."""
+    t = data if isinstance(data, torch.Tensor) else torch.as_tensor(data, dtype=dtype)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    if not torch.device(device).type == "cuda":
+        return t
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 def _stream():
     # raw handle of torch's CURRENT stream on the current device, without building a torch.cuda.Stream object
     # (torch.cuda.current_stream() costs ~10 us per call; this path is called once per kernel launch)
