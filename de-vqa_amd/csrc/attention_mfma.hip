@@ -289,10 +289,208 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     }
 }
 
+// ---- resident variant: non-causal self-attention over short sequences (ViT-g: 257 tokens) ------------------------------------
+// One workgroup of 8 waves per (sequence, head).  K and V of the WHOLE sequence are staged into LDS once (rows padded to a multiple
+// of 64: 320 x 224 B x 2 = 140 KiB for ViT-g), one barrier, then every wave streams the key chunks out of LDS for two 16-query blocks
+// at a time with no further workgroup synchronisation (the chunked kernel above pays two barriers and a staging round per 64 keys
+// and streams K / V once per 64-query tile: 5 workgroups per image and head).  Same S^T / P.V orientation, lazy rescale and
+// permlane reductions as above.
+template <int DHP>
+__global__ __launch_bounds__(512, 1) void attention_mfma_resident_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+                                                                          const bf16_t* __restrict__ k, int64_t ldk,
+                                                                          const bf16_t* __restrict__ v, int64_t ldv,
+                                                                          bf16_t* __restrict__ out, int64_t ldo,
+                                                                          const int32_t* __restrict__ seq_desc, int H, int dh,
+                                                                          float scale, int nkp) {
+    constexpr int STRIDE = 2 * DHP + 32;
+    constexpr int KS = DHP / 32;
+    constexpr int DT = DHP / 16;
+    constexpr int CH = DHP / 8;
+    constexpr int QB = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char am_smem[];
+    unsigned char* Ks = am_smem;
+    unsigned char* Vs = am_smem + (size_t)nkp * STRIDE;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int h = bid % H;
+    const int s = bid / H;
+    const int32_t* d = seq_desc + s * 6;
+    const int q_start = d[0], q_len = d[1], ko_start = d[4], n_keys = d[5];
+    if (n_keys <= 0 || q_len <= 0) return;   // uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    typedef unsigned am_u32x4_t __attribute__((ext_vector_type(4)));
+    // ---- stage K and V: rows >= n_keys re-read the last key (masked below), padding channels re-read the last real ones ----
+    for (int i = tid; i < nkp * CH; i += 512) {
+        const int r = i / CH, cv = i - r * CH;
+        const int64_t grow = ko_start + min(r, n_keys - 1);
+        const int col = h * dh + min(cv * 8, dh - 8);
+        *reinterpret_cast<am_u32x4_t*>(Ks + r * STRIDE + cv * 16) = *reinterpret_cast<const am_u32x4_t*>(k + grow * ldk + col);
+        *reinterpret_cast<am_u32x4_t*>(Vs + r * STRIDE + cv * 16) = *reinterpret_cast<const am_u32x4_t*>(v + grow * ldv + col);
+    }
+    __syncthreads();
+    const float sc2 = scale * 1.44269504088896340736f;
+    const int nblk = (q_len + 15) >> 4;
+    for (int blk0 = wave; blk0 < nblk; blk0 += 16) {     // this wave: query blocks blk0 and blk0 + 8
+        short8_t qf[QB][KS];
+        float4_t o[QB][DT];
+        float m_run[QB], l_run[QB];
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            const int qrow = (blk0 + 8 * b) * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c = ks * 32 + fq * 8;
+                uint4 u = make_uint4(0, 0, 0, 0);
+                if (qrow < q_len && c < dh) u = *reinterpret_cast<const uint4*>(q + (int64_t)(q_start + qrow) * ldq + h * dh + c);
+                qf[b][ks] = *reinterpret_cast<short8_t*>(&u);
+            }
+#pragma unroll
+            for (int i = 0; i < DT; ++i) o[b][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            m_run[b] = -INFINITY;
+            l_run[b] = 0.f;
+        }
+        for (int c0 = 0; c0 < n_keys; c0 += AM_KC) {
+            const unsigned char* Kc = Ks + c0 * STRIDE;
+            const unsigned char* Vc = Vs + c0 * STRIDE;
+            const bool full = c0 + AM_KC <= n_keys;
+            const int nt = full ? 4 : min(4, (n_keys - c0 + 15) >> 4);
+            float4_t st[QB][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int b = 0; b < QB; ++b) st[b][t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                if (t >= nt) continue;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const short8_t kf = *reinterpret_cast<const short8_t*>(Kc + (16 * t + fr) * STRIDE + (32 * ks + 8 * fq) * 2);
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) st[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[b][ks], st[b][t], 0, 0, 0);
+                }
+            }
+            short8_t pf[QB][2];
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                if (!full) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) st[b][t][r] = (c0 + 16 * t + 4 * fq + r < n_keys) ? st[b][t][r] : -INFINITY;
+                }
+                float mloc = fmaxf(fmaxf(fmaxf(st[b][0][0], st[b][0][1]), fmaxf(st[b][0][2], st[b][0][3])),
+                                   fmaxf(fmaxf(st[b][1][0], st[b][1][1]), fmaxf(st[b][1][2], st[b][1][3])));
+                mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(st[b][2][0], st[b][2][1]), fmaxf(st[b][2][2], st[b][2][3])),
+                                         fmaxf(fmaxf(st[b][3][0], st[b][3][1]), fmaxf(st[b][3][2], st[b][3][3]))));
+                mloc = am_max4(mloc);
+                float m_new = fmaxf(m_run[b], mloc);
+                const bool grow = (m_new - m_run[b]) * sc2 > 8.f;
+                const bool rescale = __builtin_amdgcn_ballot_w64(grow) != 0;
+                if (!rescale) m_new = m_run[b];
+                float alpha = 1.f, lloc = 0.f;
+                const float mc = m_new * sc2;      // n_keys > 0 and no causal mask: every query has seen a key after chunk 0
+                if (rescale) alpha = __builtin_amdgcn_exp2f(m_run[b] * sc2 - mc);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(st[b][t][r], sc2, -mc));
+                        st[b][t][r] = p;
+                        lloc += p;
+                    }
+                lloc = am_sum4(lloc);
+                l_run[b] = l_run[b] * alpha + lloc;
+                m_run[b] = m_new;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    uint4 u;
+                    u.x = am_pack2(st[b][2 * s2][0], st[b][2 * s2][1]);
+                    u.y = am_pack2(st[b][2 * s2][2], st[b][2 * s2][3]);
+                    u.z = am_pack2(st[b][2 * s2 + 1][0], st[b][2 * s2 + 1][1]);
+                    u.w = am_pack2(st[b][2 * s2 + 1][2], st[b][2 * s2 + 1][3]);
+                    pf[b][s2] = *reinterpret_cast<short8_t*>(&u);
+                }
+                if (rescale) {
+                    float ar[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * fq + r, 64);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[b][dt][r] *= ar[r];
+                }
+            }
+            const int tq = fr >> 2, tp = fr & 3;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (2 * s2 >= nt) continue;
+                    const short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (lds_s4_ptr)(Vc + (16 * (2 * s2) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
+                    const short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (lds_s4_ptr)(Vc + (16 * (2 * s2 + 1) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
+                    const short8_t vf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) o[b][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][s2], vf, o[b][dt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            float lr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run[b], 4 * fq + r, 64);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = (blk0 + 8 * b) * 16 + 4 * fq + r;
+                if (qi >= q_len) continue;
+                const float inv = lr[r] > 0.f ? 1.f / lr[r] : 0.f;
+                bf16_t* orow = out + (int64_t)(q_start + qi) * ldo + h * dh;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int c = 16 * dt + fr;
+                    if (c < dh) orow[c] = f32_to_bf16(o[b][dt][r] * inv);
+                }
+            }
+        }
+    }
+}
+
 int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t ldk, const bf16_t* v, int64_t ldv, bf16_t* out,
                           int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale,
                           int causal, void* stream) {
     const int dhp = (dh + 31) / 32 * 32;
+    hipStream_t st0 = (hipStream_t)stream;
+    // causal bit 2 (value 4, include/devqa.h): the caller asserts plain non-causal self-attention (kp_len == 0, ko_len == q_len) for
+    // EVERY sequence -> short sequences MAY take the K/V-resident kernel (opt-in: DEVQA_ATTENTION_RESIDENT=1)
+    const bool self_full = (causal & 4) != 0;
+    causal &= 3;
+    if (self_full && causal == 0 && max_q_len <= 320 && (dhp == 96 || dhp == 64) && (long)n_seq * H >= 128) {
+        // built, tested and NOT the default: 233 us against 214 us for the chunked kernel on ViT-g (127 x 16 x 257): one 8-wave
+        // workgroup per CU (140 KiB of LDS) hides less latency than three 4-wave ones, and the staging is not overlapped
+        const char* e = getenv("DEVQA_ATTENTION_RESIDENT");
+        if (e && atoi(e) == 1) {
+            const int nkp = (max_q_len + AM_KC - 1) / AM_KC * AM_KC;
+            const size_t smem = (size_t)2 * nkp * (2 * dhp + 32);
+            const long grid = (long)n_seq * H;
+            if (dhp == 96) {
+                auto kern = attention_mfma_resident_kernel<96>;
+                static bool attr96 = false;
+                if (!attr96) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr96 = true; }
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st0, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, nkp);
+            } else {
+                auto kern = attention_mfma_resident_kernel<64>;
+                static bool attr64 = false;
+                if (!attr64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr64 = true; }
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st0, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, nkp);
+            }
+            DEVQA_LAUNCH_CHECK("attention_mfma_resident");
+            return DEVQA_OK;
+        }
+    }
     // QB = 2 (128-query tiles) is built and tested (DEVQA_ATTENTION_QB=2) but NOT the default: on ViT-g (127 images x 16 heads x
     // 257 tokens) it measured 223 us against 207 us for QB = 1 -- halving the LDS fragment traffic does not pay for the occupancy
     // lost to 221 VGPRs; the kernel is bound by its ~19 VALU instructions per MFMA (SQ counters, profiles/r01_summary.md H).

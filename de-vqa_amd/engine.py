@@ -123,7 +123,7 @@ class Blip2Engine:
             p = "vision_model.encoder.layers.%d." % i
             h = self._ln(x, p + "layer_norm1.weight", p + "layer_norm1.bias", eps)
             qkv = lib.gemm(h, self._w(p + "self_attn.qkv.weight"), self._p(p + "self_attn.qkv.bias"))
-            att = lib.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], desc, B, N, H, dh, dh ** -0.5, 0)
+            att = lib.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], desc, B, N, H, dh, dh ** -0.5, 0, self_full=True)
             lib.gemm(att, self._w(p + "self_attn.projection.weight"), self._p(p + "self_attn.projection.bias"),
                      residual=x, out_f32=x)
             h = self._ln(x, p + "layer_norm2.weight", p + "layer_norm2.bias", eps)

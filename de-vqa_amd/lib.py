@@ -328,8 +328,12 @@ def layernorm_bwd_dx(x, gamma, dy, eps, add=None):
     return dx
 
 
-def attention(q, k, v, seq_desc, n_seq, max_q_len, H, dh, scale, causal, out=None):
-    """q,k,v: bf16 2-D views (rows x >=H*dh, unit inner stride). seq_desc int32 [n_seq,6] on device."""
+def attention(q, k, v, seq_desc, n_seq, max_q_len, H, dh, scale, causal, out=None, self_full=False):
+    """q,k,v: bf16 2-D views (rows x >=H*dh, unit inner stride). seq_desc int32 [n_seq,6] on device.
+    self_full=True promises plain non-causal self-attention for every sequence (kp_len == 0, ko_len == q_len): devqa.h, causal bit 2."""
+    if self_full:
+        assert not causal
+        causal = 4
     for t in (q, k, v):
         assert t.dtype == q.dtype and t.is_cuda and t.dim() == 2 and t.stride(1) == 1
     assert q.dtype in (torch.bfloat16, torch.float32)

@@ -117,6 +117,9 @@ int devqa_swiglu_f32(const float* gu, int R, int F, float* out, void* stream);
  * scores = (q.k) * scale; softmax in fp32; out bf16 [rows, H*dh] row stride ldo.
  * seq_desc: int32 [n_seq][6] = {q_start,q_len,kp_start,kp_len,ko_start,ko_len} (device).
  * max_q_len is the host-known max of q_len (grid sizing).  dh % 8 == 0, dh <= 128.
+ * `causal`: bit 0 = the causal rule above; bit 2 (value 4) = a promise by the caller that EVERY sequence is plain non-causal
+ * self-attention (kp_len == 0, ko_len == q_len, the ViT case), which lets short sequences take a kernel that keeps the whole
+ * K / V of a sequence in LDS (descriptors live on the device, so the library cannot check this itself).
  * Replaces eager/sdpa attention in HF Blip2Attention, Blip2QFormerMultiHeadAttention and
  * OPTAttention (same call sites as above).
  */

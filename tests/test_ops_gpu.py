@@ -157,6 +157,21 @@ def test_attention(L, name):
     d = torch.tensor(desc, dtype=torch.int32, device="cuda")
     out = L.attention(views[0], views[1], views[2], d, len(desc), max(x[1] for x in desc), H, dh, scale, causal)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=2e-2)
+    if name == "vit":   # the opt-in K/V-resident kernel (self_full promise; enough (sequence, head) pairs to be selected: 8 x 16)
+        qkv8 = bf(torch.randn(8 * n, 3 * H * dh, generator=g))
+        d8 = [(i * n, n, 0, 0, i * n, n) for i in range(8)]
+        ref8 = _ref_attention(qkv8[:, :H * dh], qkv8[:, H * dh:2 * H * dh], qkv8[:, 2 * H * dh:], d8, H, dh, scale, 0)
+        dq8 = dev(qkv8).to(torch.bfloat16)
+        dd8 = torch.tensor(d8, dtype=torch.int32, device="cuda")
+        import os
+        os.environ["DEVQA_ATTENTION_RESIDENT"] = "1"
+        try:
+            o8 = L.attention(dq8[:, :H * dh], dq8[:, H * dh:2 * H * dh], dq8[:, 2 * H * dh:], dd8, 8, n, H, dh, scale, 0, self_full=True)
+        finally:
+            del os.environ["DEVQA_ATTENTION_RESIDENT"]
+        np.testing.assert_allclose(o8.float().cpu().numpy(), ref8.numpy(), atol=2e-2, rtol=2e-2)
+        o8c = L.attention(dq8[:, :H * dh], dq8[:, H * dh:2 * H * dh], dq8[:, 2 * H * dh:], dd8, 8, n, H, dh, scale, 0)
+        np.testing.assert_allclose(o8.float().cpu().numpy(), o8c.float().cpu().numpy(), atol=1e-2, rtol=1e-2)
     if name == "vit":   # the experimental 128-query-tile instantiation (two query blocks per wave) on the same inputs
         import os
         os.environ["DEVQA_ATTENTION_QB"] = "2"

@@ -32,7 +32,7 @@ def main():
         q, k, v = qkv[:, :H * dh], qkv[:, H * dh:2 * H * dh], qkv[:, 2 * H * dh:]
         desc = torch.tensor([[i * T, T, 0, 0, i * T, T] for i in range(n_seq)], dtype=torch.int32, device="cuda")
         out = torch.zeros(M, H * dh, device="cuda", dtype=torch.bfloat16)
-        fn = lambda: lib.attention(q, k, v, desc, n_seq, T, H, dh, dh ** -0.5, causal, out=out)
+        fn = lambda: lib.attention(q, k, v, desc, n_seq, T, H, dh, dh ** -0.5, causal, out=out, self_full=not causal)
         fn()
         # reference on the first 3 sequences
         n = 3 * T
