@@ -47,6 +47,7 @@ class PackedSeqs:
     length: List[int]               # real (unpadded) length per sequence
     desc: torch.Tensor              # int32 [n_seq, 6] attention descriptor (device)
     max_len: int
+    dense: bool = False             # every row is a query row of some sequence (no padded rows): outputs need no zero fill
 
 
 class Blip2Engine:
@@ -221,7 +222,7 @@ class Blip2Engine:
         x = lib.embed_rows(t_tok, t_src, t_pos, self._p("language_model.model.decoder.embed_tokens.weight"), rows,
                            self._p("language_model.model.decoder.embed_positions.weight"))
         desc = torch.tensor([[s, n, 0, 0, s, n] for s, n in zip(start, length)], dtype=torch.int32, device=dev)
-        return PackedSeqs(x, start, length, desc, max(length))
+        return PackedSeqs(x, start, length, desc, max(length), True)
 
     def _pack_shared_prefix(self, seqs, img_tokens):
         """Same sequences, but the Q image-token rows of every distinct image are packed ONCE: a prefix
@@ -257,7 +258,7 @@ class Blip2Engine:
                            torch.tensor(pos, dtype=torch.int32, device=dev),
                            self._p("language_model.model.decoder.embed_tokens.weight"), rows,
                            self._p("language_model.model.decoder.embed_positions.weight"))
-        ps = PackedSeqs(x, start, length, torch.tensor(desc, dtype=torch.int32, device=dev), max(max(length), Qn))
+        ps = PackedSeqs(x, start, length, torch.tensor(desc, dtype=torch.int32, device=dev), max(max(length), Qn), True)
         ps.n_seq = len(desc)
         return ps
 
@@ -285,7 +286,7 @@ class Blip2Engine:
             h = self._ln(x, p + "self_attn_layer_norm.weight", p + "self_attn_layer_norm.bias", LN_EPS_OPT)
             qkv = lib.gemm(h, self.m.fused_qkv_w[str(i)], self.m.fused_qkv_b[str(i)])
             att = lib.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], ps.desc, n_seq, ps.max_len, H, dh, dh ** -0.5,
-                                1, out=torch.zeros((x.shape[0], d), dtype=self.adt, device=self.dev))
+                                1, out=(torch.empty if ps.dense else torch.zeros)((x.shape[0], d), dtype=self.adt, device=self.dev))
             lib.gemm(att, self._w(p + "self_attn.out_proj.weight"), self._p(p + "self_attn.out_proj.bias"), residual=x,
                      out_f32=x)
             h = self._ln(x, p + "final_layer_norm.weight", p + "final_layer_norm.bias", LN_EPS_OPT)
