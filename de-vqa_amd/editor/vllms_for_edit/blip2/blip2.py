@@ -88,6 +88,12 @@ class BLIP2OPTForEdit(BaseVLLMForEdit):
             emb = torch.cat([it, emb], dim=1)
             msk = torch.cat([torch.ones(it.shape[:2], dtype=msk.dtype, device=self.device), msk], dim=1)
         llm_inpt = {"attention_mask": msk, "inputs_embeds": emb}
+        if B == 1:   # hashable identity of every input row (image rows: (path, j); text rows: token id) -- lets the evaluator's
+            # batched probe path compute a prefix that several probes share only once (same mathematics: attention is causal)
+            ik = imgs if isinstance(imgs, str) else None
+            if imgs is None or ik is not None:
+                llm_inpt["row_keys"] = ([("img", ik, j) for j in range(self.get_img_token_n())] if imgs is not None else []) + \
+                    tk["input_ids"][0].tolist()
         vt_range = None if imgs is None else [0, self.get_img_token_n()]
         return llm_inpt, vt_range
 

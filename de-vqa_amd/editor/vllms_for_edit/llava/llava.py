@@ -90,7 +90,14 @@ class LlavaForEdit(BaseVLLMForEdit):
             emb = torch.cat([emb[:, :pos], feats, emb[:, pos + 1:]], dim=1)
             msk = torch.ones(emb.shape[:2], dtype=msk.dtype, device=self.device)
             vt_range = [pos, pos + self.get_img_token_n()]
-        return {"attention_mask": msk, "inputs_embeds": emb, "position_ids": None}, vt_range
+        out = {"attention_mask": msk, "inputs_embeds": emb, "position_ids": None}
+        if B == 1:   # see BLIP2OPTForEdit.get_llm_input_embeds: row identities for shared-prefix probe batching
+            ids_l = tk["input_ids"][0].tolist()
+            if imgs is None:
+                out["row_keys"] = ids_l
+            elif isinstance(imgs[0], str):
+                out["row_keys"] = ids_l[:pos] + [("img", imgs[0], j) for j in range(self.get_img_token_n())] + ids_l[pos + 1:]
+        return out, vt_range
 
     def get_llm_outpt(self, llm_inpt, vt_range=None):
         assert "inputs_embeds" in llm_inpt.keys()

@@ -83,11 +83,16 @@ class MiniGPT4ForEdit(BaseVLLMForEdit):
                 emb[b, :r.shape[0]] = r
                 msk[b, :r.shape[0]] = 1
             llm_inpt = {"inputs_embeds": emb, "attention_mask": msk}
+            if len(texts) == 1 and isinstance(imgs[0], str):   # row identities (see BLIP2OPTForEdit.get_llm_input_embeds)
+                s0, s1 = self._segments(texts[0])
+                llm_inpt["row_keys"] = list(s0) + [("img", imgs[0], j) for j in range(feats.shape[1])] + list(s1)
         else:
             tk = self.tokenizer(texts, return_tensors="pt", padding=True)
             B, T = tk["input_ids"].shape
             emb = embed(tk["input_ids"].reshape(-1)).view(B, T, -1)
             llm_inpt = {"attention_mask": lib.h2d(tk["attention_mask"], tk["attention_mask"].dtype, self.device), "inputs_embeds": emb}
+            if B == 1:
+                llm_inpt["row_keys"] = tk["input_ids"][0].tolist()
         if self.auto_add_img_special_token:
             vt_range = None if imgs is None else [1, self.get_img_token_n() + 1]
         else:

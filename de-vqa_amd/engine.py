@@ -192,6 +192,17 @@ class Blip2Engine:
         return PackedSeqs(x, [b * T for b in range(B)], [int(n) for n in lens], desc, T)
 
     @torch.no_grad()
+    def pack_rows(self, rows, pos, desc, max_len):
+        """Already-embedded rows [R,d] with explicit positions and attention descriptors (dense: every row belongs to a sequence):
+        the evaluator's shared-prefix packing of generic probes.  OPT's learned positions are added here."""
+        R = rows.shape[0]
+        src = torch.arange(R, dtype=torch.int32, device=self.dev)
+        tok = torch.zeros(R, dtype=torch.int32, device=self.dev)
+        x = lib.embed_rows(tok, src, lib.h2d(pos, torch.int32, self.dev), self._p("language_model.model.decoder.embed_tokens.weight"),
+                           rows.to(torch.float32).contiguous(), self._p("language_model.model.decoder.embed_positions.weight"))
+        return PackedSeqs(x, [d_[0] for d_ in desc], [d_[1] for d_ in desc], lib.h2d(desc, torch.int32, self.dev), max_len, True)
+
+    @torch.no_grad()
     def pack_from_tokens(self, seqs, img_tokens, share_prefix=False):
         """seqs: list of (image_index or None, token_id_list).  Each sequence becomes
         [Q image-token rows (if any)] + token embeddings, positions 0..len-1 (blip2.py:45-52)."""

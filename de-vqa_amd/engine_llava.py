@@ -102,6 +102,14 @@ class LlavaEngine:
         return ps
 
     @torch.no_grad()
+    def pack_rows(self, rows, pos, desc, max_len):
+        """See Blip2Engine.pack_rows; LLaMA: the positions feed RoPE."""
+        ps = PackedSeqs(rows.to(torch.float32).contiguous().clone(), [d_[0] for d_ in desc], [d_[1] for d_ in desc],
+                        lib.h2d(desc, torch.int32, self.dev), max_len, True)
+        ps.pos = lib.h2d(pos, torch.int32, self.dev)
+        return ps
+
+    @torch.no_grad()
     def pack_from_tokens(self, seqs, img_tokens, share_prefix=False):
         """seqs: (image index or None, token ids incl. ONE image placeholder id when an image is given).
         The placeholder expands to the image's n_img feature rows.  With share_prefix the rows up to and including

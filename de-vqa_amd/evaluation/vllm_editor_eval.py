@@ -45,17 +45,52 @@ class VLLMEditorEvaluation:
         return pre.to(torch.long).unsqueeze(0), y, m
 
     @staticmethod
+    def _plan_shared_prefixes(items, min_share=32):
+        """items: [(i, e, y, m, keys)].  Probes whose inputs start with the same rows (same image tokens, same in-context text:
+        IKE_VL puts the 32 retrieved demonstrations in front of every probe, LTE_VL the retrieved edit) form a group whose common
+        prefix is computed ONCE: attention is causal, so the hidden states of a prefix do not depend on what follows it.
+        -> ([(member positions, prefix length)], [positions packed on their own]).  A prefix never reaches into a member's label
+        window (the last L rows), and identities come from the wrappers' `row_keys` (none -> no sharing for that probe)."""
+        buckets, alone = {}, []
+        for pos, (_, e, y, _m, keys) in enumerate(items):
+            room = e.shape[0] - y.shape[1]
+            if keys is None or len(keys) != e.shape[0] or room < min_share:
+                alone.append(pos)
+            else:
+                buckets.setdefault(tuple(keys[:min_share]), []).append(pos)
+        groups = []
+        for members in buckets.values():
+            if len(members) < 2:
+                alone += members
+                continue
+            ks = [items[p_][4] for p_ in members]
+            lcp = min(items[p_][1].shape[0] - items[p_][2].shape[1] for p_ in members)
+            first = ks[0]
+            for k_ in ks[1:]:
+                n = 0
+                while n < lcp and k_[n] == first[n]:
+                    n += 1
+                lcp = n
+            if lcp >= min_share:
+                groups.append((members, lcp))
+            else:
+                alone += members
+        return groups, sorted(alone)
+
+    @staticmethod
     def _argmax_many(vllm, probes, max_rows=12288, prefix_fn=None):
         """[(prompt, image, target)] -> [(pre, y, m)], same values as _argmax_last per probe, but the probes of one
         evaluation phase (the model does not change inside a phase: 9 locality probes per sample before the edit, 12
         after, vllm_editor_eval.py:98-121) go through the decoder TOGETHER: inputs are built per probe through the
-        plugin API (so editor hooks on get_llm_input_embeds still apply), right-padded into one batch, the decoder runs
-        once and logits are computed on the label rows only.  `prefix_fn(prompt, image, target)` (retrieval editors: LTE_VL's
-        `probe_prefix`) may return rows to put in front of a probe's input; label rows are the LAST L, so nothing else moves."""
+        plugin API (so editor hooks on get_llm_input_embeds still apply), packed without padding rows -- common prefixes once,
+        see _plan_shared_prefixes -- the decoder runs once per <= max_rows rows and logits are computed on the label rows
+        only.  `prefix_fn(prompt, image, target)` (retrieval editors: LTE_VL's `probe_prefix`) may return rows to put in front
+        of a probe's input; label rows are the LAST L, so nothing else moves."""
         from .. import lib
         eng = vllm.engine
         out = [None] * len(probes)
         items = []
+        share = os.environ.get("DEVQA_PROBE_PREFIX_SHARE", "1") != "0"
         if hasattr(vllm, "image_features"):   # one batched encoder call for the phase's distinct images (fills the cache)
             uniq = list(dict.fromkeys(img for _, img, _ in probes if isinstance(img, str)))
             if uniq:
@@ -64,35 +99,54 @@ class VLLMEditorEvaluation:
             (x, vt), y, m = vllm.prompts_imgs_target_to_xym([prompt], [image], [target])
             assert len(y) == 1 and len(m) == 1
             e = x["inputs_embeds"][0]
+            keys = x.get("row_keys") if share else None
             pfx = prefix_fn(prompt, image, target) if prefix_fn is not None else None
             if pfx is not None:
                 e = torch.cat([pfx.to(e.dtype), e], 0)
-            items.append((i, e, y, m))
+                if keys is not None:   # the retrieved prefix is one tensor object per stored edit: its identity is the key
+                    keys = [("pfx", id(pfx), j) for j in range(pfx.shape[0])] + list(keys)
+            items.append((i, e, y, m, keys))
+        groups, alone = VLLMEditorEvaluation._plan_shared_prefixes(items) if share else ([], list(range(len(items))))
+        units = [(members, lcp) for members, lcp in groups] + [([p_], 0) for p_ in alone]   # (member positions, shared prefix rows)
         start = 0
-        while start < len(items):
-            end, tmax = start, 0
-            while end < len(items) and (end == start or max(tmax, items[end][1].shape[0]) * (end - start + 1) <= max_rows):
-                tmax = max(tmax, items[end][1].shape[0])
+        while start < len(units):
+            end, total = start, 0
+            while end < len(units):
+                members, lcp = units[end]
+                need = lcp + sum(items[p_][1].shape[0] - lcp for p_ in members)
+                if end > start and total + need > max_rows:
+                    break
+                total += need
                 end += 1
-            chunk = items[start:end]
-            B, d = len(chunk), chunk[0][1].shape[1]
-            emb = torch.zeros((B, tmax, d), dtype=torch.float32, device=chunk[0][1].device)
-            msk = torch.zeros((B, tmax), dtype=torch.int32, device=emb.device)
-            rows, lens = [], []
-            for b, (_, e, y, m) in enumerate(chunk):
-                T, L = e.shape[0], y.shape[1]
-                emb[b, :T] = e
-                msk[b, :T] = 1
-                lens.append(T)
-                rows += [b * tmax + T - L + j for j in range(L)]
-            ps = eng.pack_from_embeds(emb, msk, lens=lens)
+            parts, pos, desc, label_rows, order, max_len, r = [], [], [], [], [], 1, 0
+            for members, lcp in units[start:end]:
+                pstart = r
+                if lcp:
+                    parts.append(items[members[0]][1][:lcp])
+                    pos += list(range(lcp))
+                    desc.append([r, lcp, 0, 0, r, lcp])
+                    max_len = max(max_len, lcp)
+                    r += lcp
+                for p_ in members:
+                    _, e, y, _m, _k = items[p_]
+                    S, L = e.shape[0] - lcp, y.shape[1]
+                    parts.append(e[lcp:])
+                    pos += list(range(lcp, lcp + S))
+                    desc.append([r, S, pstart, lcp, r, S] if lcp else [r, S, 0, 0, r, S])
+                    label_rows += [r + S - L + j for j in range(L)]
+                    order.append(p_)
+                    max_len = max(max_len, S)
+                    r += S
+            rows = torch.cat(parts, 0)
+            ps = eng.pack_rows(rows, pos, desc, max_len)
             x_fin, _ = eng.decoder_layers(ps)
-            idx = lib.h2d(rows, torch.int32, emb.device)
+            idx = lib.h2d(label_rows, torch.int32, rows.device)
             logits = eng.lm_head(lib.gather_rows(x_fin, idx))
             pre, _, _ = lib.vocab_rows(logits)
             pre = pre.to(torch.long)
             r0 = 0
-            for (i, _, y, m) in chunk:
+            for p_ in order:
+                i, _, y, m, _k = items[p_]
                 L = y.shape[1]
                 out[i] = (pre[r0:r0 + L].unsqueeze(0), y, m)
                 r0 += L
@@ -105,7 +159,7 @@ class VLLMEditorEvaluation:
         `query_triple` / `query_range` keys inside get_llm_outpt -- unless it offers the same decision as `probe_prefix`
         (LTE_VL does)."""
         eng = getattr(editor.vllm, "engine", None)
-        return (eng is not None and hasattr(eng, "pack_from_embeds") and hasattr(eng, "lm_head")
+        return (eng is not None and hasattr(eng, "pack_rows") and hasattr(eng, "lm_head")
                 and (not getattr(editor, "reads_query_hook", False) or hasattr(editor, "probe_prefix")))
 
     @staticmethod

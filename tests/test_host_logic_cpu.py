@@ -152,3 +152,27 @@ def test_parallel_dataset_matches_reference_id_sequences(gold_dir):
         next(iter(ds))
     with pytest.raises(Exception):
         ParallelDataset(4, lambda ids: ids, 0)
+
+
+def test_plan_shared_prefixes():
+    """Grouping rule of the batched probe path: common leading rows (by the wrappers' row identities) are shared, never into a
+    member's label window, never below the minimum length, never without identities."""
+    import torch
+    from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation as E
+
+    def item(i, keys, L, with_keys=True):
+        return (i, torch.zeros(len(keys), 4), torch.zeros(1, L, dtype=torch.long), None, list(keys) if with_keys else None)
+    img_a = [("img", "a.png", j) for j in range(8)]
+    img_b = [("img", "b.png", j) for j in range(8)]
+    ctx = list(range(100, 140))                     # 40 in-context tokens
+    items = [item(0, img_a + ctx + [1, 2, 3], 2), item(1, img_a + ctx + [1, 9, 9, 9], 3), item(2, img_b + ctx + [1, 2, 3], 2),
+             item(3, img_b + ctx + [7], 1), item(4, ctx + [5, 6], 1), item(5, img_a + ctx + [1, 2, 3], 2, with_keys=False),
+             item(6, img_a[:4] + [9, 9], 1)]
+    groups, alone = E._plan_shared_prefixes(items, min_share=32)
+    g = {tuple(m): n for m, n in groups}
+    assert g == {(0, 1): 49, (2, 3): 48}            # a: image + context + the common "1"; b: capped at item 3's label window
+    assert alone == [4, 5, 6]
+    # identical probes: the prefix stops in front of the label window
+    same = [item(0, img_a + ctx + [1, 2, 3], 2), item(1, img_a + ctx + [1, 2, 3], 2)]
+    groups, alone = E._plan_shared_prefixes(same, min_share=32)
+    assert groups == [([0, 1], 49)] and alone == []
