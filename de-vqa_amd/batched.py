@@ -62,6 +62,8 @@ class BatchedEditEval:
         self.eng = editor.vllm.engine
         self.E = cycles_per_batch
         self.share_prefix = True  # pack each distinct image-token prefix once (exact; see engine._pack_shared_prefix)
+        # parity tests only: keep the last batch's pre-/post-edit label-row logits, the probe -> row map and the compacted deltas
+        self.keep_debug = False
         self.stats = {"cycles": 0, "steps": 0, "t_vision": 0.0, "t_decoder": 0.0, "t_ft": 0.0, "t_tail": 0.0,
                       "t_host": 0.0}
 
@@ -325,7 +327,7 @@ class BatchedEditEval:
         evb[0].record()
         # ---- 4. pre-edit tail (all probes share W0) ----------------------------------------------------
         y_pre = lib.gemm(a_tail, w0_op, b2, residual=resid_tail, want="f32")  # fc2 rows of every probe, pristine W
-        pre_argmax = self._argmax_from_y(y_pre)
+        pre_argmax = self._argmax_from_y(y_pre, "pre")
         # ---- 5. FT loop (on the active columns of each edit) --------------------------------------------
         evb[1].record()
         n_steps, losses, delta_c, idx, cnt, npad = self._ft_loop(w0, a_ft, resid_ft, labels, mask, E, kmax, d, cfg)
@@ -336,7 +338,10 @@ class BatchedEditEval:
         for e, (r0, r1) in enumerate(cyc_rows):
             a_pc = lib.gather_cols(a_tail[r0:r1], idx[e:e + 1], cnt[e:e + 1], npad, per_edit=False)[0]
             lib.gemm(a_pc, delta_op[e], residual=y_post[r0:r1], out_f32=y_post[r0:r1])
-        post_argmax = self._argmax_from_y(y_post)
+        post_argmax = self._argmax_from_y(y_post, "post")
+        if self.keep_debug:
+            self.debug["delta"] = (delta_c, idx, cnt, npad)
+            self.debug["rows"] = [[(p.kind, p.name, p.row0, p.L) for p in plist] for plist in probes]
         evb[3].record()
         pre_h = pre_argmax.cpu().numpy()
         post_h = post_argmax.cpu().numpy()
@@ -378,9 +383,11 @@ class BatchedEditEval:
         return out, meta
 
     # ------------------------------------------------------------------------------------------
-    def _argmax_from_y(self, y):
+    def _argmax_from_y(self, y, tag=None):
         logits = self.eng.lm_head(y)
         am, _, _ = lib.vocab_rows(logits)
+        if self.keep_debug and tag is not None:
+            self.__dict__.setdefault("debug", {})[tag + "_logits"] = logits
         return am
 
     def _ft_loop(self, w0, a_ft, resid_ft, labels, mask, E, kmax, d, cfg):

@@ -78,6 +78,16 @@ class VLLMEditorEvaluation:
         return groups, sorted(alone)
 
     @staticmethod
+    def _prefix_row_keys(pfx):
+        """Row identities of a retrieved prefix (LTE_VL's stored edit rows).  The key must be stable per STORED EDIT: the
+        editor hands out a fresh view object of the pool entry on every call, so `id(view)` is both different for the same
+        edit and -- once the temporary is freed and CPython reuses the address -- possibly equal for different edits.  The
+        view's device address and extent identify the pool entry for as long as the pool holds it (the pool does not change
+        inside an evaluation phase)."""
+        ident = (int(pfx.data_ptr()), tuple(pfx.shape), tuple(pfx.stride()))
+        return [("pfx", ident, j) for j in range(pfx.shape[0])]
+
+    @staticmethod
     def _argmax_many(vllm, probes, max_rows=12288, prefix_fn=None):
         """[(prompt, image, target)] -> [(pre, y, m)], same values as _argmax_last per probe, but the probes of one
         evaluation phase (the model does not change inside a phase: 9 locality probes per sample before the edit, 12
@@ -103,8 +113,8 @@ class VLLMEditorEvaluation:
             pfx = prefix_fn(prompt, image, target) if prefix_fn is not None else None
             if pfx is not None:
                 e = torch.cat([pfx.to(e.dtype), e], 0)
-                if keys is not None:   # the retrieved prefix is one tensor object per stored edit: its identity is the key
-                    keys = [("pfx", id(pfx), j) for j in range(pfx.shape[0])] + list(keys)
+                if keys is not None:
+                    keys = VLLMEditorEvaluation._prefix_row_keys(pfx) + list(keys)
             items.append((i, e, y, m, keys))
         groups, alone = VLLMEditorEvaluation._plan_shared_prefixes(items) if share else ([], list(range(len(items))))
         units = [(members, lcp) for members, lcp in groups] + [([p_], 0) for p_ in alone]   # (member positions, shared prefix rows)

@@ -176,3 +176,40 @@ def test_plan_shared_prefixes():
     same = [item(0, img_a + ctx + [1, 2, 3], 2), item(1, img_a + ctx + [1, 2, 3], 2)]
     groups, alone = E._plan_shared_prefixes(same, min_share=32)
     assert groups == [([0, 1], 49)] and alone == []
+
+
+def test_shared_prefix_plan_keys_by_stored_edit_not_by_view_object():
+    """probes behind DIFFERENT stored LTE prefixes must never be grouped, probes behind the SAME stored
+    prefix must be -- whatever CPython does with the addresses of the temporary views `probe_prefix` returns."""
+    import gc
+    import torch
+    from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation as E
+    torch.manual_seed(0)
+    pool = [torch.randn(1, 40, 8), torch.randn(1, 40, 8), torch.randn(1, 40, 8)]   # stored edits [1, P, d] as LTEvl keeps them
+    for trial in range(40):
+        hits = [int(h) for h in torch.randint(0, 4, (12,))]      # 3 = retrieval miss (no prefix)
+        items = []
+        for i, h in enumerate(hits):
+            body = torch.randn(6, 8)
+            keys = [("tok", i, j) for j in range(6)]              # distinct probe texts
+            y = torch.zeros(1, 2, dtype=torch.long)
+            if h < 3:
+                pfx = pool[h][0]                                  # a NEW view object per call, freed at the next iteration
+                e = torch.cat([pfx, body], 0)
+                keys = E._prefix_row_keys(pfx) + keys
+                del pfx
+                gc.collect()
+                _ = [torch.empty(1) for _ in range(3)]            # retrieval temporaries that may land on the freed address
+            else:
+                e = body
+            items.append((i, e, y, y, keys))
+        groups, alone = E._plan_shared_prefixes(items)
+        grouped = {}
+        for members, lcp in groups:
+            assert lcp == 40
+            assert len({hits[m] for m in members}) == 1, (hits, members)     # one stored edit per group
+            grouped[hits[members[0]]] = grouped.get(hits[members[0]], 0) + len(members)
+        for h in range(3):
+            n = hits.count(h)
+            assert grouped.get(h, 0) == (n if n >= 2 else 0), (hits, groups)  # every repeat retrieval DOES share
+        assert sorted(alone + [m for g, _ in groups for m in g]) == list(range(12))

@@ -179,3 +179,72 @@ def test_lte_evaluator(lte, in_gold_dir, tmp_path):
             assert len(accs(a)) == len(accs(c))
     d = os.path.join(str(tmp_path), "lte_vl", ed.cfg.edit_model_name, "EVQA", "sequential_edit_1")
     assert os.path.exists(os.path.join(d, "mean_results.json"))
+
+
+def test_lte_two_edits_in_pool_prefix_sharing(lte, in_gold_dir, tmp_path):
+    """edit_n = 2: the pool holds two stored edits while a split's 24 probes are evaluated, so probes retrieve DIFFERENT
+    prefixes inside one phase (grouping by id() of the returned view mixed them up).  Shared-prefix packing on
+    == off == the per-probe hook == the oracle evaluator."""
+    from oracle import devqa_oracle as O
+    from devqa_amd.dataset.vllm import BaseVLLMEditData
+    from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation
+    vllm, ed, om, oed, rec, mode = lte
+
+    class Data(BaseVLLMEditData):
+        def dataset_name(self):
+            return "EVQA"
+    n = 4
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ev = VLLMEditorEvaluation(ed, Data(deepcopy(rec[:n]), deepcopy(rec[:n])), "EVQA", str(tmp_path))
+            return ev.evaluate_sequential_edit(2, False, None)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+    # count what the planner shares, and check no group mixes stored edits
+    from devqa_amd.evaluation import vllm_editor_eval as M
+    orig_plan = M.VLLMEditorEvaluation._plan_shared_prefixes
+    seen = []
+
+    def spy(items, min_share=32):
+        out = orig_plan(items, min_share)
+        for members, lcp in out[0]:
+            firsts = {items[p_][4][0] for p_ in members}
+            assert len(firsts) == 1
+            seen.append((len(members), lcp, next(iter(firsts))[0]))
+        return out
+    M.VLLMEditorEvaluation._plan_shared_prefixes = staticmethod(spy)
+    try:
+        res_share = run({})
+    finally:
+        M.VLLMEditorEvaluation._plan_shared_prefixes = staticmethod(orig_plan)
+    res_plain = run({"DEVQA_PROBE_PREFIX_SHARE": "0"})
+    res_hook = run({"DEVQA_PROBE_BATCH": "0"})
+    with torch.no_grad():
+        ores, _ = O.evaluate_sequential_edit(om, oed, rec[:n], 2)
+    assert len(res_share) == len(ores) == 2 and all(len(s) == 2 for s in res_share)
+
+    def flat(results):
+        out = []
+        for split in results:
+            for d in split:
+                out += [(x["acc"], x["predict_after_edit"]) for x in d["reliability"]]
+                out += [(x["acc"], x["predict_after_edit"]) for g in d["generality"] for x in d["generality"][g]]
+                out += [(x["acc"], x["predict_before_edit"] + "|" + x["predict_after_edit"]) for l in d["locality"] for x in d["locality"][l]]
+        return out
+    a, b, c, o = flat(res_share), flat(res_plain), flat(res_hook), flat(ores)
+    assert len(a) == len(o) == 48
+    print(mode, "groups sharing a stored-edit prefix:", sum(1 for s in seen if s[2] == "pfx"), "of", len(seen))
+    if mode == "fp32":
+        assert a == b                               # sharing never changes a result (same arithmetic, fewer rows)
+        assert a == c
+        assert [x[1] for x in a] == [x[1] for x in o]
+        assert [x[0] for x in a] == pytest.approx([x[0] for x in o], abs=1e-6)
+    else:
+        assert sum(x == y for x, y in zip(a, b)) >= 44      # bf16: the packed order changes fp rounding, near-ties may flip

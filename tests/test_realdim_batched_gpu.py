@@ -1,0 +1,203 @@
+"""GPU parity of the BENCHMARKED code path -- BatchedEditEval: shared-prefix packing, column compaction (active_columns /
+gather_cols), the NARROW wave-per-row ft_adamw_step instantiation, device-side loop control, y_post = y_pre + a[:,J].dW[:,J]^T --
+at the true BLIP-2-OPT-2.7B per-layer dims (d 2560, FFN 10240, V 50272, head dims 88/64/80; 2 layers per tower), against goldens
+captured from the REFERENCE's own FTvl.execute_ft (realdim_goldens.*: per-step losses, step counts, weight deltas) and its own
+VLLMEditorEvaluation.evaluate_sequential_edit (realdim_eval_goldens.*: results.json + the top-8 logits of every evaluator forward).
+
+fp32 mode carries north_star's 1e-3 bar, bf16 mode (the benchmark's compute mode) the 1e-2 bar; where a quantity cannot
+meet 1e-2 in bf16 for a stated arithmetic reason, the measured value is asserted with a margin and the reason is given."""
+import json
+import os
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# relative bars (error / max |reference|), north_star: 1e-3 fp32, 1e-2 bf16
+BAR = {"fp32": 1e-3, "bf16": 1e-2}
+LOC = ["text_loc", "t3i3", "t1i4", "t2i4", "t1i2", "t1i3", "t2i1", "t2i2", "t3i1"]
+
+
+@pytest.fixture(scope="module", params=["fp32", "bf16"])
+def run(gold_dir, request):
+    import devqa_amd  # noqa: F401
+    from transformers import AutoTokenizer
+    from devqa_amd.batched import BatchedEditEval
+    from devqa_amd.editor.vllm_editors.ft_vl.ft_vl import FTvl, FTvlConfig
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from devqa_amd.editor.vllms_for_edit.blip2.modeling import Blip2Native
+    mode = request.param
+    rec = json.load(open(os.path.join(gold_dir, "realdim_records.json")))
+    cfg = {"vision_config": rec["spec"]["vision"], "qformer_config": rec["spec"]["qformer"],
+           "text_config": rec["spec"]["text"], "num_query_tokens": rec["spec"]["num_query_tokens"]}
+    model = Blip2Native.from_synth(cfg, rec["seed"], rec["style"], "cuda:0", mode)
+    tok = AutoTokenizer.from_pretrained(os.path.join(gold_dir, "tiny_blip2"))
+    vllm = BLIP2OPTForEdit(None, "cuda:0", model=model, tokenizer=tok)
+    ft = FTvlConfig(edit_model_name="blip2-opt-2.7b", rewrite_module_tmp="language_model.model.decoder.layers.{}.fc2.weight",
+                    layers=[1], num_steps=25, lr=1e-3, weight_decay=0, norm_constraint=False, batch_size=1)
+    ed = FTvl(vllm, ft, "cuda:0")
+    be = BatchedEditEval(ed, cycles_per_batch=2)
+    be.keep_debug = True
+    old = os.getcwd()
+    os.chdir(gold_dir)     # golden image paths are relative to tests/golden
+    try:
+        res = be.run([[deepcopy(r)] for r in rec["records"]], [[deepcopy(r)] for r in rec["records"]])
+        torch.cuda.synchronize()
+    finally:
+        os.chdir(old)
+    g4 = json.load(open(os.path.join(gold_dir, "realdim_goldens.json")))["g4"]
+    z4 = np.load(os.path.join(gold_dir, "realdim_goldens.npz"))
+    g5 = json.load(open(os.path.join(gold_dir, "realdim_eval_goldens.json")))
+    z5 = np.load(os.path.join(gold_dir, "realdim_eval_goldens.npz"))
+    return dict(mode=mode, be=be, res=res, rec=rec, g4=g4, z4=z4, g5=g5, z5=z5, Din=rec["spec"]["text"]["ffn_dim"])
+
+
+def test_compaction_is_active(run):
+    """The run really went through the column-compacted loop (what bench.py times), not the dense fallback."""
+    delta_c, idx, cnt, npad = run["be"].debug["delta"]
+    cnt = cnt.cpu().numpy()
+    print(run["mode"], "active columns per edit", cnt.tolist(), "npad", npad, "of", run["Din"])
+    assert npad < run["Din"] // 4 and (cnt > 0).all() and delta_c.shape == (2, 2560, npad)
+
+
+def test_ft_losses_and_steps(run):
+    """Per-step losses and executed-step counts of the device-side loop == the reference's execute_ft (g4[0], g4[1] are the
+    two records' requests)."""
+    be, mode = run["be"], run["mode"]
+    for e in range(2):
+        g = run["g4"][e]
+        assert g["request"] == run["rec"]["records"][e]["requests"][0]
+        n = int(be.last_steps[e])
+        ref = np.asarray(g["losses"])
+        got = be.last_losses[e, :n]
+        m = min(n, g["steps"])
+        # bar relative to the loss scale of the run (losses fall from ~15 to the 1e-2 floor): |err| <= bar * max(loss_ref, 1)
+        err = np.abs(got[:m] - ref[:m]) / np.maximum(ref[:m], 1.0)
+        print(mode, "edit", e, "steps", n, "ref", g["steps"], "max loss err (rel. to max(loss,1)) %.3g" % err.max())
+        assert err.max() < BAR[mode]
+        if mode == "fp32":
+            assert n == g["steps"]
+        else:
+            # the stop rule compares a loss of ~1e-2 with the 1e-2 floor: a bf16 loss within the bar of the reference's can cross
+            # the floor one step earlier / later.  Allowed only when the reference's loss at the deciding step is within 2x of
+            # the floor, i.e. the decision is inside the bf16 error band; otherwise the counts must be equal.
+            if n != g["steps"]:
+                k = min(n, g["steps"]) - 1
+                assert abs(n - g["steps"]) == 1 and ref[k] < 2e-2, (n, g["steps"], ref[k])
+
+
+def _dense_delta(run, e):
+    delta_c, idx, cnt, npad = run["be"].debug["delta"]
+    c = int(cnt[e])
+    d = torch.zeros((delta_c.shape[1], run["Din"]), dtype=torch.float32, device=delta_c.device)
+    d[:, idx[e, :c].long()] = delta_c[e, :, :c]
+    assert float(delta_c[e, :, c:].abs().max() if c < npad else 0.0) == 0.0    # padding columns never move
+    return d
+
+
+def test_weight_deltas(run):
+    """Edited-weight deltas (scattered back from the active columns) vs the reference's `deltas[w_name]`."""
+    mode = run["mode"]
+    for e in range(2):
+        g = run["g4"][e]
+        if int(run["be"].last_steps[e]) != g["steps"]:
+            continue   # bf16 one-step difference at the floor (see above): the delta has one more / fewer AdamW step
+        d = _dense_delta(run, e)
+        z = run["z4"]
+        rs = d.double().sum(1).cpu().numpy()
+        rel_rs = np.linalg.norm(rs - z["g4_delta_rowsum_%d" % e]) / np.linalg.norm(z["g4_delta_rowsum_%d" % e])
+        rel_l2 = abs(float(d.double().norm()) - g["delta_l2"]) / g["delta_l2"]
+        ii = torch.from_numpy(z["g4_delta_idx_%d" % e]).cuda()
+        got = d[ii[:, 0], ii[:, 1]].cpu().numpy()
+        gold = z["g4_delta_val_%d" % e]
+        rel_el = np.linalg.norm(got - gold) / max(np.linalg.norm(gold), 1e-30)
+        amax = abs(float(d.abs().max()) - g["delta_absmax"]) / g["delta_absmax"]
+        print(mode, "edit", e, "delta: rowsum rel %.3g  l2 rel %.3g  absmax rel %.3g  sampled-element rel_l2 %.3g"
+              % (rel_rs, rel_l2, amax, rel_el))
+        assert rel_rs < BAR[mode] and rel_l2 < BAR[mode] and amax < BAR[mode]
+        if mode == "fp32":
+            assert rel_el < BAR[mode]
+        # bf16: AdamW moves every element by ~ +-lr whatever the gradient's magnitude, so an element whose gradient is at bf16
+        # rounding-noise level may take the other sign; the elementwise comparison is therefore fp32-only, and bf16 is held to
+        # the aggregate quantities above (row sums, norm, max) and to the delta's EFFECT (post-edit logits below), all at 1e-2.
+
+
+def _probe_calls(run):
+    """(cycle, phase, kind, name, row0, L, reference call index)"""
+    out = []
+    for c, plist in enumerate(run["be"].debug["rows"]):
+        for (kind, name, row0, L) in plist:
+            if kind == "loc":
+                j = LOC.index(name)
+                out.append((c, "pre", kind, name, row0, L, c * 21 + j))
+                out.append((c, "post", kind, name, row0, L, c * 21 + 12 + j))
+            elif kind == "rel":
+                out.append((c, "post", kind, name, row0, L, c * 21 + 9))
+            else:
+                out.append((c, "post", kind, name, row0, L, c * 21 + 10 + ["text_rephrase", "image_rephrase"].index(name)))
+    return out
+
+
+def test_probe_logits_and_argmax(run):
+    """Pre- and post-edit logits of every probe's label rows vs the reference's evaluator forwards: the value of the reference's
+    top-8 logits, the row logsumexp and the argmax."""
+    mode, be, z = run["mode"], run["be"], run["z5"]
+    tv, ti, lse, rows = z["top_val"], z["top_idx"], z["lse"], int(run["g5"]["rows"])
+    worst, n_rows, n_agree, n_decided, n_decided_agree = 0.0, 0, 0, 0, 0
+    for (c, phase, kind, name, row0, L, call) in _probe_calls(run):
+        lg = be.debug[phase + "_logits"][row0:row0 + L]
+        Lr = min(L, rows)
+        lg = lg[L - Lr:]
+        ref_v = torch.from_numpy(tv[call, rows - Lr:]).cuda()
+        ref_i = torch.from_numpy(ti[call, rows - Lr:]).cuda().long()
+        got_v = torch.gather(lg, 1, ref_i)
+        scale = float(ref_v.abs().max())
+        err = float((got_v - ref_v).abs().max()) / scale
+        err_lse = float((torch.logsumexp(lg, 1).cpu() - torch.from_numpy(lse[call, rows - Lr:])).abs().max()) / scale
+        worst = max(worst, err, err_lse)
+        am = lg.argmax(1)
+        agree = (am == ref_i[:, 0])
+        margin = ref_v[:, 0] - ref_v[:, 1]
+        decided = margin > 2 * BAR[mode] * scale       # the reference's own top-1 margin exceeds twice the error bar
+        n_rows += Lr
+        n_agree += int(agree.sum())
+        n_decided += int(decided.sum())
+        n_decided_agree += int((agree & decided).sum())
+        assert bool(agree[decided].all()), (phase, kind, name, c)
+    print(mode, "label-row logits: worst rel err %.3g over %d rows; argmax agreement %d/%d (%d/%d where the reference margin "
+          "> 2 x bar)" % (worst, n_rows, n_agree, n_rows, n_decided_agree, n_decided))
+    assert worst < BAR[mode]
+    if mode == "fp32":
+        assert n_agree == n_rows
+
+
+def _flat(results):
+    out = []
+    for split in results:
+        for r in split:
+            rr = r["reliability"][0]
+            out.append(("rel", None, round(rr["acc"], 4), rr["predict_after_edit"], None))
+            for sec in ("generality", "locality"):
+                for sub in r[sec]:
+                    it = r[sec][sub][0]
+                    out.append((sec, sub, round(it["acc"], 4), it["predict_after_edit"], it.get("predict_before_edit")))
+    return out
+
+
+def test_results_vs_reference_results_json(run):
+    """acc + decoded predictions of all 2 x 12 probes vs the reference's results.json at real dims."""
+    mode = run["mode"]
+    got, ref = _flat(run["res"]), _flat(run["g5"]["g5_results_sen1"])
+    assert len(got) == len(ref) == 24
+    same = sum(a == b for a, b in zip(got, ref))
+    diff = [(a, b) for a, b in zip(got, ref) if a != b]
+    print(mode, "probes identical to the reference's results.json: %d/24" % same, diff[:3])
+    if mode == "fp32":
+        assert same == 24
+    else:
+        # bf16: a probe's strings differ only where a label row's reference margin is inside the error band
+        # (test_probe_logits_and_argmax asserts agreement on every decided row); measured 24/24 -- allow one
+        assert same >= 23
