@@ -19,6 +19,7 @@ Trained hyper-network state comes from a reference-format `Best` checkpoint (R/e
 read with torch.load(weights_only=True).  The training loop (train_init/train/train_a_batch) is not
 built; edited modules must be fc1/fc2 of decoder layers (what R/configs/mend_vl/blip2-opt-2.7b.yaml selects).
 """
+import os
 import re
 from collections import OrderedDict
 from dataclasses import dataclass
@@ -29,7 +30,7 @@ import torch
 import yaml
 
 from ...base import BaseConfig
-from ..base import VLLMBaseEditor
+from ..base import VLLMBaseEditorWithTraining
 from .... import lib
 
 
@@ -68,11 +69,54 @@ class MENDvlConfig(BaseConfig):
 
 
 
-class MENDvl(VLLMBaseEditor):
+class _AuxState:
+    """state_dict() / load_state_dict() face of the hyper-network tensors (the reference's `aux_models` ModuleDict) for
+    VLLMBaseEditorWithTraining.save_ckpt / load_ckpt; the tensors themselves are plain device buffers the HIP kernels read."""
+
+    def __init__(self, ed):
+        self.ed = ed
+
+    def state_dict(self):
+        return dict(self.ed.aux)
+
+    def load_state_dict(self, sd, strict=True):
+        self.ed._load_aux(sd, strict)
+
+
+class _EditLrState:
+    """The reference's `edit_lrs` ParameterList: keys '0' .. 'n-1'."""
+
+    def __init__(self, ed):
+        self.ed = ed
+
+    def state_dict(self):
+        return {str(i): self.ed.lr_t[i] for i in range(len(self.ed.modules))}
+
+    def load_state_dict(self, sd, strict=True):
+        self.ed._load_lrs(sd)
+
+
+class _AdamState(dict):
+    """Adam moments of the trainable tensors as plain device buffers ({"t", "m", "v"}) with the optimizer interface the
+    checkpoint code needs."""
+
+    def state_dict(self):
+        return {"t": self["t"], "m": dict(self["m"]), "v": dict(self["v"])}
+
+    def load_state_dict(self, sd):
+        if not (isinstance(sd, dict) and {"t", "m", "v"} <= set(sd)):
+            raise RuntimeError("checkpoint 'opt' is not a MEND_VL Adam state (a torch.optim state dict of the reference cannot be "
+                               "mapped onto the HIP buffers; load with load_opt=False)")
+        self["t"] = int(sd["t"])
+        for mv in ("m", "v"):
+            for k, v in sd[mv].items():
+                self[mv][k].copy_(v)
+
+
+class MENDvl(VLLMBaseEditorWithTraining):
     def __init__(self, vllm, config: MENDvlConfig, device="cuda:0", vllm_proc_data=None, device_proc_data=None,
                  ckpt_path=None, train_modules=None, for_train=False):
-        super().__init__(vllm, device)
-        self.cfg = config
+        super().__init__(vllm, config, device)
         eng = self.vllm.engine
         self.dev = eng.dev
         if config.aux_model.init != "id":
@@ -100,7 +144,7 @@ class MENDvl(VLLMBaseEditor):
         self.norm_init = {}     # GradientTransform.norm_init per shape: False after construction / load (see _transform)
         self.opt = None
         if ckpt_path is not None:
-            self.load_ckpt(ckpt_path)
+            self.load_ckpt(ckpt_path, True, False)
         elif train_modules is not None:
             self.load_train_modules(train_modules)
         elif for_train:
@@ -108,25 +152,30 @@ class MENDvl(VLLMBaseEditor):
         eng.set_module_deltas({})
 
     # ---- trained state ------------------------------------------------------------------------------------------
-    def load_ckpt(self, ckpt_path, restrict=True, load_opt=False):
-        """Reference checkpoint layout (base.py:237-268): {'i','epoch','loss','ema_loss','train_modules': {'aux_models':
-        state_dict, 'edit_lrs': state_dict}, 'opt', 'lr_scheduler'}.  weights_only=True: nothing from the file runs."""
-        ck = torch.load(ckpt_path, map_location="cpu", weights_only=True)
-        self.load_train_modules(ck["train_modules"])
-        return ck.get("i"), ck.get("epoch"), ck.get("loss"), ck.get("ema_loss")
-
     def load_train_modules(self, tm):
-        self.aux = {k: v.to(self.dev, torch.float32).contiguous() for k, v in tm["aux_models"].items()}
-        self.lr_t = torch.tensor([float(tm["edit_lrs"][str(i)]) for i in range(len(self.modules))], dtype=torch.float32,
-                                 device=self.dev)
-        for i, m in enumerate(self.modules):
-            m["lr"] = float(tm["edit_lrs"][str(i)])
+        """tm = the 'train_modules' entry of a reference-layout checkpoint: {'aux_models': state_dict, 'edit_lrs': state_dict}."""
+        self._load_aux(tm["aux_models"])
+        self._load_lrs(tm["edit_lrs"])
+
+    def _load_aux(self, sd, strict=True):
+        new = {k: v.to(self.dev, torch.float32).contiguous() for k, v in sd.items()}
+        if self.aux is not None and strict and set(new) != set(self.aux):
+            raise RuntimeError("aux_models state dict keys differ: %s" % sorted(set(new) ^ set(self.aux))[:4])
+        if self.aux is None or strict:
+            self.aux = new
+        else:
+            self.aux.update(new)
+        self._stats_finite = True
         for shape in {m["shape"] for m in self.modules}:
             for leaf in ("u_mean", "u_std", "v_mean", "v_std"):
                 t = self.aux["%s.%s" % (str(shape), leaf)]
                 if not bool(torch.isfinite(t).all()) and not self.training:
                     self._stats_finite = False
-        self._stats_finite = getattr(self, "_stats_finite", True)
+
+    def _load_lrs(self, sd):
+        self.lr_t = torch.tensor([float(sd[str(i)]) for i in range(len(self.modules))], dtype=torch.float32, device=self.dev)
+        for i, m in enumerate(self.modules):
+            m["lr"] = float(sd[str(i)])
 
     # ---- plugin API ---------------------------------------------------------------------------------------------
     def name_of_editor_and_model(self):
@@ -270,6 +319,8 @@ class MENDvl(VLLMBaseEditor):
         """Fresh hyper-network state as the reference constructs it (auxiliary_networks.py:31-38,45-52,99-105): u = 0,
         v ~ N(0, 1), bias = 0, mode shift 0 / scale 1, NaN normalisation buffers (filled by the first training rows),
         edit learning rates = cfg.init_edit_lr."""
+        if seed is None:
+            seed = getattr(self, "random_seed", None)
         g = torch.Generator().manual_seed(0 if seed is None else int(seed))
         rank = self.cfg.aux_model.rank
         tm = {"aux_models": {}, "edit_lrs": {str(i): torch.tensor(float(self.cfg.init_edit_lr)) for i in range(len(self.modules))}}
@@ -291,8 +342,14 @@ class MENDvl(VLLMBaseEditor):
         self.load_train_modules(tm)
 
     def get_modules_for_training(self):
-        """{'aux_models': state dict, 'edit_lrs': state dict} -- the two entries of the reference's checkpoint."""
-        return {"aux_models": self.aux, "edit_lrs": {str(i): self.lr_t[i] for i in range(len(self.modules))}}
+        """{'aux_models', 'edit_lrs'} -- the two entries of the reference's checkpoint (mend_vl.py:238-240)."""
+        return {"aux_models": _AuxState(self), "edit_lrs": _EditLrState(self)}
+
+    def preprocess_train_data(self, vllm_edit_data) -> List:   # mend_vl.py:245-246
+        return vllm_edit_data.data
+
+    def data_prefetch_device(self):
+        return self.device if getattr(self, "prefetch", True) and str(self.device).startswith("cuda") else None
 
     def _trainable(self):
         return [k for k in self.aux if ".mlp.layers." in k]
@@ -302,23 +359,13 @@ class MENDvl(VLLMBaseEditor):
 
     def get_a_new_optimizer(self):
         """torch.optim.Adam([{aux_models, lr = cfg.aux_model.lr}, {edit_lrs, lr = cfg.edit_lr_lr}]) (:293-296) as plain state."""
-        st = {"t": 0, "m": {}, "v": {}}
+        st = _AdamState(t=0, m={}, v={})
         for k in self._trainable():
             st["m"][k] = torch.zeros_like(self.aux[k])
             st["v"][k] = torch.zeros_like(self.aux[k])
         st["m"]["edit_lrs"] = torch.zeros_like(self.lr_t)
         st["v"]["edit_lrs"] = torch.zeros_like(self.lr_t)
         return st
-
-    def save_ckpt(self, path, i=0, epoch=0, loss=0.0, ema_loss=None):
-        """The reference's `Best` layout (base.py:237-252); optimizer moments under 'opt' in this implementation's own
-        form (the reference stores a torch.optim state dict there; load_ckpt of either side ignores a foreign 'opt')."""
-        tm = {"aux_models": {k: v.detach().cpu() for k, v in self.aux.items()},
-              "edit_lrs": {str(i_): self.lr_t[i_].detach().cpu() for i_ in range(len(self.modules))}}
-        opt = None if self.opt is None else {"t": self.opt["t"], "m": {k: v.cpu() for k, v in self.opt["m"].items()},
-                                            "v": {k: v.cpu() for k, v in self.opt["v"].items()}}
-        torch.save({"i": i, "epoch": epoch, "loss": loss, "ema_loss": ema_loss, "train_modules": tm, "opt": opt,
-                    "lr_scheduler": None}, path)
 
     @staticmethod
     def _items(xym):
@@ -485,38 +532,54 @@ class MENDvl(VLLMBaseEditor):
                                                   [x["locality"][k][0]["target"] for x in d]) for k in d[0]["locality"]}
         return edit, gen, loc
 
-    def train(self, vllm_edit_data, total_epochs=1, batch_size=1, save_ckpt_path=None, seed=None, ema_alpha=0.1, log_fn=None,
-              data_buffer_size=8, prefetch=True):
-        """The reference's training loop (base.py:142-225) without TensorBoard: batches drawn by ParallelDataset in the
-        reference's order for `seed` (shuffled, epoch tails completed from the next permutation), EMA loss, the best-EMA
-        checkpoint saved under `save_ckpt_path` (`Best`).  With `prefetch` the next batches are organised (image encodes,
-        embeddings) by ParallelDataset's producer thread on a second HIP stream of the same GPU while this thread trains --
-        the reference does that on a second GPU with a second model copy (R/utils/__init__.py:149-156); the editor only
-        trains the hyper-network, so the frozen model serves both."""
-        from ....dataset import ParallelDataset
-        data = vllm_edit_data.data if hasattr(vllm_edit_data, "data") else list(vllm_edit_data)
-        self.set_train(True)
-        if self.opt is None:
-            self.opt = self.get_a_new_optimizer()
+    def train_loop(self, vllm_edit_data, total_epochs=1, batch_size=1, save_ckpt_path=None, seed=None, ema_alpha=0.1, log_fn=None,
+                   data_buffer_size=8, prefetch=True):
+        """Convenience driver over the reference API: `train_init(...)` then `train(total_epochs)` (base.py:142-225) with the
+        records in a scratch directory, `log_fn(i, log_dict)` instead of the scalar writer, and the best-EMA `Best` checkpoint copied
+        to `save_ckpt_path`.  With `prefetch` the next batches are organised (image encodes, embeddings) by ParallelDataset's
+        producer thread on a second HIP stream of the same GPU while this thread trains -- the reference does that on a second
+        GPU with a second model copy (R/utils/__init__.py:149-156); the editor only trains the hyper-network, so the frozen
+        model serves both.  Returns the final EMA loss."""
+        import shutil
+        import tempfile
+        from ....dataset.vllm import BaseVLLMEditData
+        if not isinstance(vllm_edit_data, BaseVLLMEditData):
+            recs = list(vllm_edit_data)
 
-        def get_data_by_ids(ids):
-            return self.organize_batch_data([data[int(j)] for j in ids])
-        gen = ParallelDataset(len(data), get_data_by_ids, batch_size, True, data_buffer_size if prefetch else 1, False, seed, True,
-                              device=self.device if prefetch and str(self.device).startswith("cuda") else None)
-        ema, best, i = 1.0, float("inf"), 1
+            class _Data(BaseVLLMEditData):
+                def dataset_name(self):
+                    return "records"
+            vllm_edit_data = _Data(recs, recs)
+        self.prefetch = bool(prefetch)
+        tmp = tempfile.mkdtemp(prefix="devqa_mend_train_")
+        keep_state = self.aux
         try:
-            for epoch in range(1, total_epochs + 1):
-                for batch, _n in gen:
-                    loss, log = self.train_a_batch(batch)
-                    ema = ema_alpha * loss + (1 - ema_alpha) * ema
-                    if log_fn is not None:
-                        log_fn(i, dict(log, Loss=loss, **{"EMA Loss": ema, "Epoch": epoch}))
-                    if ema < best:
-                        best = ema
-                        if save_ckpt_path is not None:
-                            self.save_ckpt(save_ckpt_path, i, epoch, loss, ema)
-                    i += 1
+            self.train_init(vllm_edit_data, batch_size, records_dir=tmp, train_name="run", log_per_i=1, ema_alpha=ema_alpha,
+                            random_seed=seed, data_buffer_size=data_buffer_size if prefetch else 1,
+                            seed_init_train_params_if_no_ckpt_path=keep_state is None)
+            if log_fn is not None:
+                class _W:
+                    def __init__(self):
+                        self.cur, self.i = {}, None
+
+                    def add_scalar(self, name, value, i):
+                        if self.i is not None and i != self.i:
+                            log_fn(self.i, self.cur)
+                            self.cur = {}
+                        self.i = i
+                        self.cur[name] = value
+
+                    def flush(self):
+                        if self.i is not None:
+                            log_fn(self.i, self.cur)
+                w = self.log_writer = _W()
+            self.train(total_epochs)
+            if log_fn is not None:
+                w.flush()
+            self.data_generator.close()
+            best = os.path.join(self.save_ckpt_dir, "Best")
+            if save_ckpt_path is not None and os.path.exists(best):
+                shutil.copyfile(best, save_ckpt_path)
         finally:
-            gen.close()
-        self.set_train(False)
-        return ema
+            shutil.rmtree(tmp, ignore_errors=True)
+        return self.ema_loss

@@ -227,10 +227,14 @@ def test_mend_training_steps(gold_dir, in_gold_dir, mode):
                     gold = z["s%d_state_aux_models.%s.%s" % (si, key, leaf)]
                     assert _rel(ed.aux["%s.%s" % (key, leaf)].cpu().numpy(), gold) < 1e-3, (si, key, leaf)
     # checkpoint round trip in the reference's layout
-    path = "/tmp/devqa_mend_best.pt"
-    ed.save_ckpt(path, 2, 1, 0.0, 0.0)
+    ed.save_ckpt_dir = "/tmp/devqa_mend_ckpt"
+    os.makedirs(ed.save_ckpt_dir, exist_ok=True)
+    ed.save_ckpt(2, 1, 0.0, 0.0)               # the reference's signature (base.py:237): one file named `Best`
+    path = os.path.join(ed.save_ckpt_dir, "Best")
     ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"i", "epoch", "loss", "ema_loss", "train_modules", "opt", "lr_scheduler"} and ck["i"] == 2
     assert set(ck["train_modules"]) == {"aux_models", "edit_lrs"} and "(40, 80).mlp.layers.0.u" in ck["train_modules"]["aux_models"]
+    assert set(ck["opt"]) == {"t", "m", "v"}
     ed2 = MENDvl(vllm, cfg, "cuda:0", ckpt_path=path)
     assert torch.equal(ed2.aux["(40, 80).mlp.layers.1.v"], ed.aux["(40, 80).mlp.layers.1.v"])
 
@@ -250,7 +254,7 @@ def test_mend_train_from_scratch_then_edit(gold_dir, in_gold_dir, tmp_path):
         ed.edit_one_piece(deepcopy(rec[0]["requests"][0]))       # untrained: NaN buffers (auxiliary_networks.py:99-105)
     logs = []
     best = str(tmp_path / "Best")
-    ema = ed.train([deepcopy(r) for r in rec[:3]], total_epochs=2, batch_size=1, save_ckpt_path=best, seed=3,
+    ema = ed.train_loop([deepcopy(r) for r in rec[:3]], total_epochs=2, batch_size=1, save_ckpt_path=best, seed=3,
                    log_fn=lambda i, d: logs.append(d["Loss"]))
     assert len(logs) == 6 and all(np.isfinite(l) for l in logs) and np.isfinite(ema)
     for key in ("(40, 80)", "(80, 40)"):
@@ -277,7 +281,7 @@ def test_mend_train_prefetch_equals_serial(gold_dir, in_gold_dir):
         cfg.aux_model.lr, cfg.init_edit_lr = 1e-3, 1e-3
         ed = MENDvl(vllm, cfg, "cuda:0", for_train=True)
         logs = []
-        ed.train([deepcopy(r) for r in rec[:5]], total_epochs=3, batch_size=2, seed=11, log_fn=lambda i, d: logs.append(d["Loss"]),
+        ed.train_loop([deepcopy(r) for r in rec[:5]], total_epochs=3, batch_size=2, seed=11, log_fn=lambda i, d: logs.append(d["Loss"]),
                  data_buffer_size=4, prefetch=prefetch)
         runs.append((logs, {k: v.clone() for k, v in ed.aux.items()}))
     (la, sa), (lb, sb) = runs

@@ -159,7 +159,7 @@ def blip2_mend_train(n=6):
     vllm._img_feat_cache = NoHit()
     for prefetch in (False, True):
         stamps = []
-        ed.train(recs[1:], total_epochs=3, batch_size=1, seed=1, log_fn=lambda i, d: stamps.append(time.time()), data_buffer_size=4,
+        ed.train_loop(recs[1:], total_epochs=3, batch_size=1, seed=1, log_fn=lambda i, d: stamps.append(time.time()), data_buffer_size=4,
                  prefetch=prefetch)
         torch.cuda.synchronize()
         k = len(stamps) // 3                     # skip the first pass
