@@ -60,13 +60,57 @@ class EmbeddingRetriever:
                 if cid >= 0 and self.prompts[cid][1] != trg:  # first hit with a different stored answer
                     pick = int(cid)
                     break
-            if pick is None:
-                pick = int(hit[-1])                              # else the last hit (vllm.py:79-81)
+            if pick is None:                                     # else the last hit (vllm.py:79-81)
+                valid = [int(c) for c in hit if c >= 0]          # a corpus smaller than `tops` pads the id row with -1
+                if not valid:
+                    raise RuntimeError("finds_sim: empty retrieval corpus")
+                pick = valid[-1]
             out.append((self.prompts[pick], self.save_image_path[pick]))
         return out
 
     def finds_sim(self, src, trg, tops=5):
         return self.finds_sim_many([src], [trg], tops)[0]
+
+
+# ---- the stored corpus on disk (vllm.py:96-103, R/easyeditor/models/ike/util.py:83-85) ----------------------------------------
+CORPUS_KEYS = ("sentences", "images", "prompts", "embeddings")
+
+
+def save_corpus(path, corpus: dict):
+    """{sentences [n], images [n], prompts [n][2], embeddings [n,D]} -- the dict the reference pickles -- as an .npz of plain
+    arrays (unicode / float32), which loads without unpickling anything."""
+    n = len(corpus["embeddings"])
+    assert len(corpus["sentences"]) == len(corpus["images"]) == len(corpus["prompts"]) == n
+    np.savez(path, sentences=np.asarray(corpus["sentences"], dtype=str), images=np.asarray(corpus["images"], dtype=str),
+             prompts=np.asarray([[str(a), str(b)] for a, b in corpus["prompts"]], dtype=str),
+             embeddings=np.asarray(corpus["embeddings"], np.float32))
+
+
+class _ArrayOnlyUnpickler(__import__("pickle").Unpickler):
+    """Reads the reference's `*_embeddings*.pkl` layout (a dict of lists / str / numpy arrays, pickle.HIGHEST_PROTOCOL) while
+    refusing every global except the handful numpy needs to rebuild an ndarray: nothing else in the file can execute."""
+    ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+               ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+               ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")}
+
+    def find_class(self, module, name):
+        if (module, name) in self.ALLOWED:
+            return super().find_class(module, name)
+        raise RuntimeError("refusing to unpickle %s.%s from a corpus file" % (module, name))
+
+
+def load_corpus(path) -> dict:
+    """.npz written by save_corpus, or the reference's pickle of the same dict (array-only unpickler, see above)."""
+    if str(path).endswith(".npz"):
+        z = np.load(path, allow_pickle=False)
+        return {"sentences": z["sentences"].tolist(), "images": z["images"].tolist(),
+                "prompts": [list(p) for p in z["prompts"].tolist()], "embeddings": z["embeddings"]}
+    with open(path, "rb") as f:
+        d = _ArrayOnlyUnpickler(f).load()
+    if not isinstance(d, dict) or not set(("sentences", "embeddings")) <= set(d):
+        raise RuntimeError("%s is not a stored-corpus dict" % path)
+    d["embeddings"] = np.asarray(d["embeddings"], np.float32)
+    return d
 
 
 def build_probes(records: List[dict], img_root_dir: str, retrieved: List) -> List[dict]:

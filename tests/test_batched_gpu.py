@@ -59,7 +59,9 @@ def test_batched_matches_goldens_and_generic(gold_dir, in_gold_dir, tmp_path, dt
     if dtype == "fp32":
         assert same_generic == 96 and same_gold == 96  # accuracies AND decoded strings, exact
     else:
-        assert same_generic >= 90 and same_gold >= 80
+        # tiny d = 40 model in bf16: near-tie logits flip (see tests/test_blip2_gpu.py); measured 94/96 and 89/96.  The
+        # benchmarked path's parity at real dims is tests/test_realdim_batched_gpu.py (24/24 probes, logits at 1e-2).
+        assert same_generic >= 92 and same_gold >= 86
     # mean_results.json schema and values (floats rounded to 4 dp by save_results)
     mb = json.load(open(tmp_path / "b" / "ft_vl" / "blip2-opt-2.7b" / "EVQA" / "sequential_edit_1" / "mean_results.json"))
     gm = j["g5_mean_sen1"]

@@ -17,12 +17,16 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-# tolerance table: fp32 ("faithful") mode carries the 1e-3 bar incl. exact accuracies; bf16 mode is
-# checked at 1e-2 on forward tensors and losses.  The tiny model (d=40) has near-tie logits and
-# near-zero gradient components, so bf16 AdamW sign flips / argmax flips are bounded statistically
-# here and tightly on the real-dim model (test_realdim_gpu.py).
+# tolerance table: fp32 ("faithful") mode carries the 1e-3 bar incl. exact accuracies and decoded strings.  bf16 mode: 1e-2 on
+# forward tensors (measured 7e-3) and on per-step losses relative to max(loss, 1).  The TINY model (d = 40, 80-wide FFN) gives bf16
+# nothing to average over -- 8 mantissa bits on 40-term dot products, near-tie logits over a 640-word vocabulary, gradient
+# components at rounding-noise level whose AdamW step is +-lr regardless -- so three quantities are bounded at their measured
+# values plus a margin here, and at 1e-2 on the real-dim model (tests/test_realdim_batched_gpu.py, tests/test_realdim_gpu.py):
+#   delta_l2 (elementwise Frobenius error of the 40x80 delta): measured 1.5e-2 .. 3.2e-2 (clamp variant 7.7e-2)  -> 4e-2 (x2 there)
+#   frac_bad (share of elements off by > 1e-2 max|delta|):      measured 3.7e-2 .. 6.3e-2                         -> 8e-2
+#   agree    (probes equal to the reference's results.json):    measured 89/96, 67/72                              -> 0.9
 TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, delta_l2=1e-3, frac_bad=1e-3, agree=1.0, steps=0),
-       "bf16": dict(fwd=1e-2, loss=2e-2, delta_l2=5e-2, frac_bad=1e-1, agree=0.7, steps=1)}
+       "bf16": dict(fwd=1e-2, loss=1e-2, delta_l2=4e-2, frac_bad=8e-2, agree=0.9, steps=1)}
 
 
 @pytest.fixture(scope="module", params=["fp32", "bf16"])
@@ -81,7 +85,8 @@ def test_g4_ft_losses_steps_delta(tiny, in_gold_dir):
         deltas = ed.execute_ft([g["request"]])
         d = deltas[g["weight"]].cpu().numpy()
         assert len(ed.last_losses) == g["steps"]
-        np.testing.assert_allclose(ed.last_losses, g["losses"], rtol=vllm.tol["loss"], atol=vllm.tol["loss"])
+        lerr = float((np.abs(np.array(ed.last_losses) - np.array(g["losses"])) / np.maximum(np.array(g["losses"]), 1.0)).max())
+        assert lerr < vllm.tol["loss"], lerr
         gold = z["g4_delta_%d" % i]
         # AdamW moves every element by ~lr per step with the SIGN of a (possibly tiny) gradient, so a
         # handful of noise-dominated elements can differ by O(lr*steps) in bf16 mode; the bar is on the
@@ -112,7 +117,9 @@ def test_g4b_ft_variants(tiny, in_gold_dir):
         # early-stop step count is data dependent at the 1e-2 floor: allow +-1 step in bf16 mode
         assert abs(len(ed.last_losses) - g["steps"]) <= vllm.tol["steps"], (g["cfg"], ed.last_losses, g["losses"])
         n = min(len(ed.last_losses), g["steps"])
-        np.testing.assert_allclose(ed.last_losses[:n], g["losses"][:n], rtol=5 * vllm.tol["loss"], atol=vllm.tol["loss"])
+        lerr = float((np.abs(np.array(ed.last_losses[:n]) - np.array(g["losses"][:n])) / np.maximum(np.array(g["losses"][:n]), 1.0)).max())
+        print(g["cfg"], "loss err %.3g" % lerr)
+        assert lerr < 2 * vllm.tol["loss"], lerr      # lr x10 .. x30 variants amplify every rounding difference accordingly
         if len(ed.last_losses) == g["steps"]:
             rel_l2 = np.linalg.norm(d - gold) / np.linalg.norm(gold)
             print(g["cfg"], "delta rel_l2 %.4g" % rel_l2)
@@ -155,7 +162,11 @@ def test_g5_evaluator_generic(tiny, in_gold_dir, edit_n, tmp_path):
     print("per-probe acc agreement %d/%d" % (agree, tot))
     # per-probe accuracies are argmax agreements: exact except where bf16 flips a near-tie
     assert agree >= vllm.tol["agree"] * tot
+    worst = 0.0
     for sec in ("generality", "locality"):
         for sub in gm[sec]:
-            assert abs(mean["total_mean"][sec][sub]["acc"] - gm[sec][sub]["acc"]) < (1e-4 if vllm.tol["agree"] == 1.0 else 0.2)
+            worst = max(worst, abs(mean["total_mean"][sec][sub]["acc"] - gm[sec][sub]["acc"]))
+    print("worst sub-metric mean acc difference %.4f" % worst)
+    # fp32: the 4-dp means are identical; bf16: one flipped single-token probe moves a sub-metric's mean over 8 samples by 0.125
+    assert worst < (1e-4 if vllm.tol["agree"] == 1.0 else 0.13)
     assert mean["total_mean"]["total_edit_n"] == gm["total_edit_n"]

@@ -10,7 +10,12 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": dict(fwd=1e-3, loss=2e-3, delta=1e-3), "bf16": dict(fwd=1e-2, loss=5e-2, delta=5e-2)}
+# north_star: 1e-3 fp32 / 1e-2 bf16.  `loss` bounds |loss - ref| / max(ref, 1) per FT step; `rowsum` is the one bf16 quantity kept
+# above 1e-2: the per-output-row sum of the weight delta adds 10240 AdamW updates of ~ +-lr each, whose SIGNS follow gradients that
+# are at bf16 rounding-noise level for part of the columns; measured 0.97e-2 .. 1.6e-2 on this (generic) path and 0.9e-2 on the
+# batched path (tests/test_realdim_batched_gpu.py), so it is asserted at 2e-2; norm, max and the delta's effect stay at 1e-2.
+TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, delta=1e-3, rowsum=1e-3, post=1e-3),
+       "bf16": dict(fwd=1e-2, loss=1e-2, delta=1e-2, rowsum=2e-2, post=1e-2)}
 
 
 @pytest.fixture(scope="module", params=["fp32", "bf16"])
@@ -60,10 +65,15 @@ def test_realdim_ft(rd, in_gold_dir):
     for i, g in enumerate(j["g4"]):
         d = ed.execute_ft([g["request"]])[g["weight"]]
         n = min(len(ed.last_losses), g["steps"])
-        print(i, "steps", len(ed.last_losses), g["steps"], "loss err", np.abs(np.array(ed.last_losses[:n]) - np.array(g["losses"][:n])).max())
+        got_l, ref_l = np.array(ed.last_losses[:n]), np.array(g["losses"][:n])
+        lerr = float((np.abs(got_l - ref_l) / np.maximum(ref_l, 1.0)).max())
+        print(i, "steps", len(ed.last_losses), g["steps"], "loss err (rel. to max(loss, 1)) %.3g" % lerr)
         strict = vllm.tol["delta"] < 5e-3
-        assert abs(len(ed.last_losses) - g["steps"]) <= (0 if strict else 2)
-        np.testing.assert_allclose(ed.last_losses[:n], g["losses"][:n], rtol=vllm.tol["loss"], atol=vllm.tol["loss"])
+        if len(ed.last_losses) != g["steps"]:
+            # bf16 only: the stop rule compares a ~1e-2 loss with the 1e-2 floor; one step of difference is accepted when the
+            # reference's deciding loss lies within 2x of the floor (inside the bf16 error band), never in fp32
+            assert not strict and abs(len(ed.last_losses) - g["steps"]) == 1 and g["losses"][n - 1] < 2e-2
+        assert lerr < vllm.tol["loss"]
         if len(ed.last_losses) == g["steps"]:
             idx = torch.from_numpy(z["g4_delta_idx_%d" % i]).cuda()
             got = d[idx[:, 0], idx[:, 1]].cpu().numpy()
@@ -74,11 +84,12 @@ def test_realdim_ft(rd, in_gold_dir):
             print("   delta sample rel_l2 %.3g rowsum rel %.3g l2 %.5g vs %.5g" % (rel, rel_rs, float(d.norm()), g["delta_l2"]))
             # AdamW gives every element a +-lr step whatever the gradient magnitude, so in bf16 mode elements
             # whose gradient is at rounding-noise level may take the other sign: the elementwise bar is fp32-only;
-            # bf16 is held to the delta's norm, its row sums and its EFFECT (post-edit logits below).
+            # bf16 is held to the delta's norm, max, its row sums and its EFFECT (post-edit logits below).
             if strict:
                 assert rel < vllm.tol["delta"]
-            assert rel_rs < vllm.tol["delta"]
+            assert rel_rs < vllm.tol["rowsum"]
             assert abs(float(d.norm()) - g["delta_l2"]) < vllm.tol["delta"] * g["delta_l2"]
+            assert abs(float(d.abs().max()) - g["delta_absmax"]) < vllm.tol["delta"] * g["delta_absmax"]
         # post-edit logits on the edit prompt's label rows (the reference applied the same edit)
         ed.edit_one_piece(g["request"])
         (x, vt), y, m = vllm.prompts_imgs_target_to_xym([g["request"]["prompt"]], [g["request"]["image"]],
@@ -88,5 +99,5 @@ def test_realdim_ft(rd, in_gold_dir):
         gold = z["g4_post_logits_%d" % i]
         perr = np.abs(post - gold).max() / np.abs(gold).max()
         print("   post-edit logits rel err %.3g, argmax agree %s" % (perr, (post.argmax(-1) == gold.argmax(-1)).all()))
-        assert perr < (2e-3 if strict else 3e-2)
+        assert perr < vllm.tol["post"]
         assert (post.argmax(-1) == gold.argmax(-1)).all()
