@@ -1,20 +1,21 @@
 #!/usr/bin/env python3
-"""CLI of the editor-training path: same flags as R/train_vllm_editor.py:7-33 (-en -mn -dna -bs -dvc -dn -lkpt -eps
--tnp -ea -rs; -edvc / -sci / -lpi / -dbs are accepted and ignored: there is no second-device producer thread and no
-TensorBoard here), plus the dataset / retriever arguments of test_vllm_edit.py.  Trains the MEND_VL hyper-network
-(the trainable editor built on the HIP path) and writes the best-EMA checkpoint in the reference's `Best` layout to
-records/<editor>/<model>/<train name>/checkpoints/Best.
+"""CLI of the editor-training path: the flags of R/train_vllm_editor.py:14-29 (-en -mn -dna -bs -dvc -dn -lkpt -edvc -eps
+-tnp -sci -lpi -ea -rs -dbs) and its two calls, `editor.train_init(...)` then `editor.train(epochs)` (:85-89).
+-edvc is accepted and unused: the data-preparation producer runs on a second HIP stream of the SAME GPU, not on a second
+GPU with a second model copy (devqa_amd/dataset/__init__.py).  Dataset / encoder paths: optional flags, see devqa_amd/cli.py.
+Checkpoints go to records/<editor>/<model>/<train name>/checkpoints/Best in the reference's layout.
 """
 import argparse
 import os
 import sys
-from datetime import datetime
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def get_attr():
+def get_attr(argv=None):
+    from devqa_amd.cli import add_data_args
+
     def parse_lkpt(value):
         return None if value.lower() == "none" else value
     p = argparse.ArgumentParser()
@@ -33,39 +34,27 @@ def get_attr():
     p.add_argument("-ea", "--ema_alpha", type=float, default=0.1)
     p.add_argument("-rs", "--random_seed", type=int, default=None)
     p.add_argument("-dbs", "--data_buffer_size", type=int, default=4)
-    p.add_argument("--data_path", type=str, required=True)
-    p.add_argument("--img_root", type=str, required=True)
-    p.add_argument("--embeddings", type=str, required=True)
-    p.add_argument("--queries", type=str, required=True)
-    p.add_argument("--dtype", type=str, default="bf16")
-    return p.parse_args()
+    add_data_args(p)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    import devqa_amd  # noqa: F401
+    cfg = get_attr(argv)
+    from devqa_amd import cli
+    from devqa_amd.editor.vllm_editors.base import VLLMBaseEditorWithTraining
+    from devqa_amd.utils import load_vllm_editor
+    cfg.data_name = cfg.data_name.upper()
+    editor = load_vllm_editor(cfg.editor_name, cfg.edit_model_name, cfg.device, cfg.extra_devices, None, True, cfg.dtype,
+                              **cli.editor_kwargs(cfg))
+    if not isinstance(editor, VLLMBaseEditorWithTraining):   # the reference fails here too (FT_VL has no train_init)
+        raise BaseException("%s is not a trainable editor." % cfg.editor_name)
+    train_data = cli.build_dataset(cfg, "train")
+    editor.train_init(train_data, cfg.batch_size, train_name_prefix=cfg.train_name_prefix, load_ckpt_path=cfg.load_ckpt_path,
+                      save_ckpt_per_i=cfg.save_ckpt_per_i, log_per_i=cfg.log_per_i, ema_alpha=cfg.ema_alpha,
+                      random_seed=cfg.random_seed, data_buffer_size=cfg.data_buffer_size)
+    editor.train(cfg.epochs)
 
 
 if __name__ == "__main__":
-    cfg = get_attr()
-    import numpy as np
-    import devqa_amd  # noqa: F401
-    from devqa_amd.dataset.vllm import EVQA, VLKEB, EmbeddingRetriever
-    from devqa_amd.utils import get_full_model_name, load_vllm_editor
-    cfg.editor_name = cfg.editor_name.lower()
-    if cfg.editor_name != "mend_vl":
-        raise BaseException("Only mend_vl is a trainable editor on the HIP path (got %s)." % cfg.editor_name)
-    model_name = get_full_model_name(cfg.edit_model_name)
-    editor = load_vllm_editor(cfg.editor_name, model_name, cfg.device, None, cfg.load_ckpt_path, True, cfg.dtype)
-    corpus = np.load(cfg.embeddings, allow_pickle=False)
-    qz = np.load(cfg.queries, allow_pickle=False)
-    qmap = {s: e for s, e in zip(qz["sentences"].tolist(), qz["embeddings"])}
-    retriever = EmbeddingRetriever(lambda srcs: np.stack([qmap[s] for s in srcs]), corpus["embeddings"],
-                                   [tuple(p) for p in corpus["prompts"].tolist()], corpus["images"].tolist(), cfg.device)
-    ds = {"EVQA": EVQA, "VLKEB": VLKEB}[cfg.data_name.upper()]
-    train_data = ds(cfg.data_path, cfg.img_root, cfg.data_n, retriever)
-    name = ((cfg.train_name_prefix + "-") if cfg.train_name_prefix else "") + datetime.now().strftime("%Y.%m.%d-%H.%M.%S")
-    ckpt_dir = os.path.join("records", cfg.editor_name, model_name, name, "checkpoints")
-    os.makedirs(ckpt_dir, exist_ok=True)
-
-    def log(i, d):
-        if i % cfg.log_per_i == 0:
-            print("iter %d  loss %.4f  ema %.4f  grad-norm %.3f" % (i, d["Loss"], d["EMA Loss"], d["Grad-Norm"]), flush=True)
-    ema = editor.train(train_data, cfg.epochs, cfg.batch_size, os.path.join(ckpt_dir, "Best"), cfg.random_seed, cfg.ema_alpha, log,
-                       data_buffer_size=cfg.data_buffer_size)
-    print("final EMA loss %.4f; checkpoint: %s" % (ema, os.path.join(ckpt_dir, "Best")))
+    main()
