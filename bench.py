@@ -1,36 +1,120 @@
 #!/usr/bin/env python3
-"""bench.py -- edit+eval cycles/sec, BLIP-2-OPT-2.7B + FT_VL on synthetic EVQA-shaped inputs
-(BASELINE.json config[1]: 1000 synthetic edits, bf16, 1xMI355X; N ranks = weak scaling, one
-process per GPU, splits sharded with no data-path collective and one gather of score rows).
+"""bench.py -- edit+eval cycles/sec, BLIP-2-OPT-2.7B + FT_VL on synthetic EVQA-shaped inputs (BASELINE.json config[1]).
 
-A "step" = one batch of --cycles-per-step independent edit+eval cycles through the batched HIP
-engine (devqa_amd.batched.BatchedEditEval): 9 pre-edit locality probes -> FT_VL edit (<= 25 fused
-AdamW steps, early stop enabled) -> 12 post-edit probes, per cycle.  Inputs (pre-processed pixel
-values, token ids) are resident in HBM/host lists before the timed region starts.
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one batch of --cycles-per-step independent edit+eval cycles through the batched HIP engine
+(devqa_amd.batched.BatchedEditEval): 9 pre-edit locality probes -> FT_VL edit (<= 25 fused AdamW steps, early stop enabled) -> 12
+post-edit probes, per cycle.  Inputs (pre-processed pixel values, token ids) are resident in HBM / host lists before the timed
+region starts.  One process per GPU: with --gpus N > 1 and no WORLD_SIZE in the environment this script starts N child ranks
+itself (fresh processes, started BEFORE anything touches a GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and
+relays rank 0's JSON line; under torchrun it is one of the ranks.  Ranks shard the edit stream with no data-path collective and
+meet in ONE RCCL all-gather of per-cycle score rows.
+
+  --scaling weak    (default) every rank runs K steps of E cycles: per-GPU work fixed.
+  --scaling strong  K * E cycles in total, block-partitioned over the ranks ("-sen 1000 edit stream shards across the 8 GPUs").
+  --ffn sparse|dense|both   weight recipe of the decoder FFN.  "sparse" (the headline): devqa_amd.synth style "opt" -- fc1 bias
+                    -0.3 and a narrow fc1 so that ~2 % of the ReLU units fire, as in a trained OPT; the FT loop then runs on the
+                    active columns only.  "dense": SURVEY.md 8(d)'s recipe verbatim (N(0, 0.02) weights, biases 0): half of
+                    the units fire, no compaction.  "both" (default): the sparse headline plus a short dense leg reported beside it.
+  --selftest-cpu    no GPU, gloo: walks the launcher / sharding / collective / JSON code with fake cycles (tests/test_dist_cpu.py).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-# deduplicated algorithmic work per cycle (A_min) and its GEMM-shaped share
+# deduplicated algorithmic work per cycle (A_min)
 A_MIN_TFLOP_PER_CYCLE = 3.81
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+SPARSE_RECIPE = ("synthetic weights, numpy recipe 'opt' (devqa_amd/synth.py): decoder fc1 bias -0.3 and fc1 ~ N(0, 0.15/sqrt(d)) so that "
+                 "~2% of the ReLU FFN units fire (trained-OPT-like sparsity); the FT loop carries the active columns only")
+DENSE_RECIPE = "SURVEY 8(d) recipe verbatim: every weight N(0, 0.02), LayerNorm weight 1, all biases 0 (dense ReLU FFN, no column compaction)"
 
 
-def build_full_model(dev, seed, layers=None, threads=16, keep_host_copy=False):
-    """BLIP-2-OPT-2.7B dims, numpy-seeded synthetic weights ('opt' recipe), generated in parallel."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cycles-per-step", type=int, default=60)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--ffn", choices=["sparse", "dense", "both"], default="both")
+    ap.add_argument("--dense-steps", type=int, default=0, help="steps of the dense leg under --ffn both (default max(2, steps // 5))")
+    ap.add_argument("--seed", type=int, default=20251121)
+    ap.add_argument("--layers", type=str, default=None, help="debug only: 'v,q,t' layer counts (INVALID as a benchmark)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cycles", type=int, default=1, help="fully timed reference-style oracle cycles of the cpu_baseline leg")
+    ap.add_argument("--no-hbm-micro", action="store_true", help="skip the dense-AdamW / cosine top-k HBM measurements")
+    ap.add_argument("--no-pipeline", action="store_true", help="run the two stages of every batch back to back on one stream")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--selftest-cpu", action="store_true")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a torchrun environment
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """Start n fresh child processes of this script (one rank per GPU), wait for all of them, relay rank 0's stdout.  The parent
+    never initialises a GPU and never replaces itself (no exec).  Exit code: 0 only if every rank exited 0."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while True:     # a rank that dies would leave the others blocked in a collective until the store times out: end them at once
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=30)
+    sys.stdout.write("".join(c for c in chunks if c))
+    sys.stdout.flush()
+    if failed or any(codes):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# model / cpu baseline / HBM micro-measurements
+# ---------------------------------------------------------------------------------------------------------------------------------
+def build_full_model(dev, seed, layers=None, threads=16, keep_host_copy=False, style="opt"):
+    """BLIP-2-OPT-2.7B dims, numpy-seeded synthetic weights, generated in parallel."""
     from concurrent.futures import ThreadPoolExecutor
+    import torch
     import devqa_amd  # noqa: F401
     from devqa_amd import blip2_spec
     from devqa_amd.editor.vllms_for_edit.blip2.modeling import Blip2Native
@@ -40,7 +124,7 @@ def build_full_model(dev, seed, layers=None, threads=16, keep_host_copy=False):
     names = list(model._shapes.keys())
     kept = {} if keep_host_copy else None
     with ThreadPoolExecutor(threads) as ex:
-        futs = {n: ex.submit(param_init, n, model._shapes[n], seed, "opt") for n in names}
+        futs = {n: ex.submit(param_init, n, model._shapes[n], seed, style) for n in names}
         for n in names:
             arr = futs.pop(n).result()
             model.load_named_tensors(lambda _n, a=arr: torch.from_numpy(a), names=[n], refresh=False)
@@ -50,12 +134,12 @@ def build_full_model(dev, seed, layers=None, threads=16, keep_host_copy=False):
     return model, cfg, kept
 
 
-def cpu_baseline(cfg, seed, threads, arrays=None):
-    """The oracle (CPU restatement of the reference path, fp32, full BLIP-2-OPT-2.7B dims) timed on a
-    bounded sample: ONE image encode (ViT-g + Q-Former), ONE decoder forward at T=48 and ONE FT_VL step
-    (forward + backward onto layers.31.fc2.weight + torch.optim.AdamW).  A reference-style cycle executes
-    40 encodes + 46 decoder forwards (25 of them inside FT steps) -- SURVEY.md 3.1 -- so
-    cycles/s = 1 / (40*t_enc + 21*t_dec + 25*t_step)."""
+def cpu_baseline(cfg, seed, threads, arrays, cycles, n_cycles, style="opt"):
+    """The oracle (CPU restatement of the reference path, fp32, full BLIP-2-OPT-2.7B dims) timed on `n_cycles` COMPLETE
+    reference-style cycles (oracle.devqa_oracle.faithful_cycle_pretokenized: 9 pre-edit forwards, <= 25 x [image encode + forward +
+    backward + torch.optim.AdamW], 12 post-edit forwards; nothing cached -- SURVEY.md 3.1) after one un-timed warm-up call (one
+    image encode + one decoder forward), on the same synthetic cycles the GPU ran."""
+    import torch
     from oracle import devqa_oracle as O
     from devqa_amd import blip2_spec
     from devqa_amd.synth import param_init
@@ -63,37 +147,250 @@ def cpu_baseline(cfg, seed, threads, arrays=None):
     shapes = blip2_spec.param_shapes(cfg)
     t0 = time.time()
     if arrays is None:
-        arrays = {n: param_init(n, s, seed, "opt") for n, s in shapes.items()}
+        arrays = {n: param_init(n, s, seed, style) for n, s in shapes.items()}
     w = {n: torch.from_numpy(arrays[n]) for n in shapes}
     m = O.OracleBlip2(w, cfg, None, copy=False)
     gen_s = time.time() - t0
-    g = torch.Generator().manual_seed(0)
-    pix = torch.randn(1, 3, 224, 224, generator=g)
-    with torch.no_grad():
-        t0 = time.time()
-        it = m.image_tokens(pix)
-        t_enc = time.time() - t0
-        emb = torch.cat([it, torch.randn(1, 16, it.shape[-1], generator=g) * 0.05], 1)
-        msk = torch.ones(1, 48, dtype=torch.long)
-        t0 = time.time()
-        m.get_llm_outpt({"inputs_embeds": emb, "attention_mask": msk})
-        t_dec = time.time() - t0
-    name = "language_model.model.decoder.layers.%d.fc2.weight" % (cfg["text_config"]["num_hidden_layers"] - 1)
-    p = m.w[name].clone().requires_grad_(True)
-    m.w[name] = p
-    opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=0)
-    y = torch.randint(4, 50272, (1, 3), generator=g)
-    mk = torch.tensor([[1, 1, 0]])
+    wname = "language_model.model.decoder.layers.%d.fc2.weight" % (cfg["text_config"]["num_hidden_layers"] - 1)
+
+    def host(c):   # device pixel tensors -> host arrays (inputs only)
+        def conv(it):
+            return dict(it, image=None if it["image"] is None else it["image"].detach().float().cpu().numpy())
+        return {"requests": [conv(c["requests"][0])], "generality": {k: [conv(v[0])] for k, v in c["generality"].items()},
+                "locality": {k: [conv(v[0])] for k, v in c["locality"].items()}}
+    cyc = [host(c) for c in cycles[:n_cycles]]
+    with torch.no_grad():   # warm-up: thread pools, allocator, page-in of the weights
+        x, _, _ = O._pretok_xym(m, cyc[0]["requests"][0]["prompt"], cyc[0]["requests"][0]["image"], cyc[0]["requests"][0]["target_new"])
+        m.get_llm_outpt(x, None)
     t0 = time.time()
-    loss = O.label_loss(m.get_llm_outpt({"inputs_embeds": emb, "attention_mask": msk}), y, mk)
-    loss.backward()
-    opt.step()
-    t_step = time.time() - t0
-    cyc = 40 * t_enc + 21 * t_dec + 25 * t_step
-    return {"value": 1.0 / cyc, "unit": "cycles/s", "cores": threads, "kind": "port",
-            "sample": "1 ViT-g+Q-Former encode (%.2fs) + 1 OPT-2.7B forward T=48 (%.2fs) + 1 FT step fwd+bwd+AdamW (%.2fs), "
-                      "fp32 torch CPU oracle at full BLIP-2-OPT-2.7B dims; cycle = 40 enc + 21 fwd + 25 steps = %.1fs"
-                      % (t_enc, t_dec, t_step, cyc), "weight_gen_s": round(gen_s, 1)}
+    info = [O.faithful_cycle_pretokenized(m, c, wname, 25, 1e-3, 0.0) for c in cyc]
+    dt = time.time() - t0
+    return {"value": len(cyc) / dt, "unit": "cycles/s", "cores": threads, "kind": "port",
+            "sample": "%d complete reference-style cycle(s) (%d image encodes, %d decoder forwards, %d FT steps with backward + "
+                      "torch.optim.AdamW each), fp32 torch CPU oracle at full BLIP-2-OPT-2.7B dims, %.1f s after one warm-up "
+                      "encode + forward" % (len(cyc), info[0]["encodes"], info[0]["forwards"], info[0]["steps"], dt),
+            "seconds_per_cycle": round(dt / len(cyc), 2), "weight_gen_s": round(gen_s, 1)}
+
+
+def hbm_micro(dev, d_out=2560, d_in=10240):
+    """HBM-regime kernels measured on their own with HIP events (lib.profile slots): the DENSE ft_adamw_step sweep
+    (6 x 4 x 2560 x 10240 = 629 MB per edit-step) and cosine top-k over the VLKEB-shaped corpus 15000 x 384 (config #5)."""
+    import torch
+    from devqa_amd import lib
+    out = {}
+    E, L, steps = 8, 2, 6
+    g = torch.Generator(device=dev).manual_seed(1)
+    w0 = torch.randn((d_out, d_in), device=dev, generator=g) * 0.01
+    w = torch.empty((E, d_out, d_in), device=dev)
+    mom, var = torch.empty_like(w), torch.empty_like(w)
+    a = torch.rand((E, L, d_in), device=dev, generator=g)
+    dy = torch.randn((E, L, d_out), device=dev, generator=g) * 1e-3
+    y = torch.empty((E, L, d_out), device=dev)
+    one = torch.ones(E, dtype=torch.int32, device=dev)
+    t = torch.zeros(E, dtype=torch.int32, device=dev)
+    for it in range(steps + 2):
+        if it == 2:
+            torch.cuda.synchronize()
+            lib.profile(1)
+        t += 1
+        lib.ft_adamw_step(w, mom, var, w0, a, dy, y, one, t, 1e-3, 0.9, 0.999, 1e-8, 0.0, -1.0)
+    lib.profile(0)
+    ms, _, n = lib.profile_read(lib.PROF_FT_ADAMW)
+    per = 24.0 * d_out * d_in
+    out["ft_adamw_step_dense"] = {"kernel": "ft_adamw_step_kernel (dense [2560,10240] per edit)", "bytes_per_edit_step": per,
+                                  "edits": E, "launches": int(n), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
+                                  "achieved": round(per * E * n / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(per * E * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del w, mom, var
+    N, D, Q = 15000, 384, 1000
+    corpus = torch.randn((N, D), device=dev, generator=g)
+    corpus = corpus / corpus.norm(dim=1, keepdim=True)
+    for q_n in (1, Q):
+        queries = torch.randn((q_n, D), device=dev, generator=g)
+        for k in (5, 32):
+            for it in range(7):
+                if it == 2:
+                    torch.cuda.synchronize()
+                    lib.profile(1)
+                lib.cosine_topk(corpus, queries, k, True, True)
+            lib.profile(0)
+            ms, wk, n = lib.profile_read(lib.PROF_COSINE)
+            us = 1e3 * ms / max(n, 1)
+            out["cosine_topk_q%d_k%d" % (q_n, k)] = {
+                "kernel": "row_inv_norm + score_tile + topk_select", "corpus": [N, D], "queries": q_n, "k": k,
+                "bytes_per_query_batch": 4 * N * D, "avg_call_us": round(us, 1), "achieved": round(4.0 * N * D / (us * 1e-6) / 1e9, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(4.0 * N * D / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "gflops": round(2.0 * N * D * q_n / (us * 1e-6) / 1e9, 1)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# one timed leg (a model + its batches)
+# ---------------------------------------------------------------------------------------------------------------------------------
+class Leg:
+    def __init__(self, args, rank, world, dev, style, layers, keep_host_copy):
+        import torch
+        from devqa_amd.batched import BatchedEditEval, copy_sample, shard_range
+        from devqa_amd.editor.vllm_editors.ft_vl.ft_vl import FTvl, FTvlConfig
+        from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+        from devqa_amd.synth import IdTokenizer, evqa_cycles, synth_image_u8
+        self.args, self.rank, self.world, self.dev = args, rank, world, dev
+        t0 = time.time()
+        self.model, self.cfg, self.host_arrays = build_full_model(dev, args.seed, layers, keep_host_copy=keep_host_copy, style=style)
+        vllm = BLIP2OPTForEdit(None, dev, model=self.model, tokenizer=IdTokenizer())
+        ft_cfg = FTvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "ft_vl", "blip2-opt-2.7b.yaml"))
+        ft_cfg.layers = [self.cfg["text_config"]["num_hidden_layers"] - 1]
+        self.num_steps = ft_cfg.num_steps
+        self.editor = FTvl(vllm, ft_cfg, dev)
+        self.be = BatchedEditEval(self.editor, cycles_per_batch=args.cycles_per_step)
+        self.build_s = time.time() - t0
+        self.vllm = vllm
+        self.copy_sample, self.shard_range = copy_sample, shard_range
+        self._evqa_cycles, self._synth_image_u8 = evqa_cycles, synth_image_u8
+        self._img_cache = {}
+
+    def make_batches(self, K, W):
+        """-> (warm-up batches, timed batches, global id of this rank's first timed cycle, cycles of the timed region on this rank).
+        weak: every rank draws its own (W + K) * E cycles.  strong: ONE stream of K * E cycles (the same on every rank), rank r takes
+        its contiguous block and cuts it into batches of E."""
+        import torch
+        a, E = self.args, self.args.cycles_per_step
+        proc, size, vocab = self.vllm.image_processor, self.cfg["vision_config"]["image_size"], self.cfg["text_config"]["vocab_size"]
+
+        def image_of_factory(offset):
+            def image_of(s, tag):
+                key = (offset + s, tag)
+                if key not in self._img_cache:
+                    self._img_cache[key] = torch.from_numpy(proc(self._synth_image_u8(offset + s, tag, size, a.seed))).to(self.dev)
+                return self._img_cache[key]
+            return image_of
+        if a.scaling == "weak":
+            n = (K + W) * E
+            cyc = self._evqa_cycles(n, vocab, a.seed + 7919 * self.rank, image_of_factory(self.rank * n))
+            warm, timed, first = cyc[:W * E], cyc[W * E:], self.rank * K * E
+        else:
+            total = K * E
+            lo, hi = self.shard_range(total, self.rank, self.world)
+            stream = self._evqa_cycles(total, vocab, a.seed, None)       # ids only: images are materialised for this rank's block
+            warm_src = self._evqa_cycles(W * E, vocab, a.seed + 104729 * (self.rank + 1), image_of_factory(10 ** 7 + self.rank * W * E))
+            img = image_of_factory(0)
+
+            def with_images(s, c):
+                def fix(it):
+                    return dict(it, image=None if it["image"] is None else img(s, it["image"].split("_")[1]))
+                return {"requests": [fix(c["requests"][0])], "generality": {k: [fix(v[0])] for k, v in c["generality"].items()},
+                        "locality": {k: [fix(v[0])] for k, v in c["locality"].items()}}
+            timed = [with_images(s, stream[s]) for s in range(lo, hi)]
+            warm, first = warm_src, lo
+
+        def cut(cs):
+            return [([self.copy_sample(c) for c in cs[i:i + E]], cs[i:i + E]) for i in range(0, len(cs), E)]
+        torch.cuda.synchronize()
+        return cut(warm), cut(timed), first, timed
+
+    def sample_cycles(self, n):
+        """n cycles of this leg's workload (device pixel tensors), for the cpu_baseline leg."""
+        import torch
+        proc, size = self.vllm.image_processor, self.cfg["vision_config"]["image_size"]
+
+        def image_of(s, tag):
+            return torch.from_numpy(proc(self._synth_image_u8(s, tag, size, self.args.seed)))
+        return self._evqa_cycles(n, self.cfg["text_config"]["vocab_size"], self.args.seed + 7919 * self.rank, image_of)
+
+    def run(self, batches, pipelined):
+        outs, metas = [], []
+        for o, mt in self.be.run_batches(batches, pipelined=pipelined):
+            outs += o
+            metas += mt
+        return outs, metas
+
+    def reset_stats(self):
+        for k in list(self.be.stats):
+            self.be.stats[k] = 0
+
+    def close(self):
+        import torch
+        del self.be, self.editor, self.vllm, self.model
+        self._img_cache.clear()
+        torch.cuda.empty_cache()
+
+
+def timed_leg(leg, K, W, barrier, use_dist, rank, world, dev):
+    """W untimed warm-up steps, then the K-step timed region bracketed by barrier + synchronize; max over ranks."""
+    import torch
+    import torch.distributed as dist
+    from devqa_amd import lib
+    from devqa_amd.batched import BatchedEditEval
+    from devqa_amd.dist import gather_score_rows
+    a = leg.args
+    warm, timed, first, _ = leg.make_batches(K, W)
+    if warm:
+        leg.run(warm, not a.no_pipeline)
+    leg.reset_stats()
+    barrier()
+    lib.profile(1)
+    t0 = time.time()
+    outs, metas = leg.run(timed, not a.no_pipeline)
+    barrier()
+    elapsed = time.time() - t0
+    lib.profile(0)
+    n_local = len(outs)
+    n_total, ranks = n_local, 1
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(nt)
+        n_total = int(nt.item())
+        rows = BatchedEditEval.score_rows(outs, metas, first)
+        got = gather_score_rows(rows, n_total, rank, world, torch.device(dev))     # the single RCCL collective of the data path
+        ranks = dist.get_world_size()
+        if rank == 0:
+            assert got.shape == (n_total, 16) and [int(v) for v in got[:, 0]] == list(range(n_total))
+    return elapsed, n_local, n_total, ranks
+
+
+def gemm_roofline(K_E_local, elapsed):
+    from devqa_amd import lib
+    names = ["gemm_bf16_tn_kernel<32,128,1,4>", "gemm_bf16_glds_kernel<64,128,2,2>", "gemm_bf16_glds_kernel<128,128,2,2>",
+             "gemm_bf16_pp_kernel"]
+    prof = [lib.profile_read(i) for i in range(4)]
+    dom = max(range(4), key=lambda i: prof[i][0])
+    g_ms, g_fl, g_n = (sum(p[j] for p in prof) for j in range(3))
+    dms, dfl, dn = prof[dom]
+    exec_per_cycle = g_fl / max(K_E_local, 1) / 1e12
+    alg_scale = min(1.0, A_MIN_TFLOP_PER_CYCLE / exec_per_cycle) if exec_per_cycle > 0 else 0.0
+    achieved = (dfl * alg_scale / 1e12) / (dms / 1e3) if dms > 0 else 0.0
+    traffic = pmc_traffic(names[dom])
+    return {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None if traffic is None else traffic["hbm_bytes_per_launch"],
+            "traffic_detail": traffic, "avg_launch_us": round(1e3 * dms / max(dn, 1), 2), "launches": int(dn),
+            "executed_tflops": round((dfl / 1e12) / (dms / 1e3), 1) if dms > 0 else 0.0,
+            "all_gemm_executed_tflops": round((g_fl / 1e12) / (g_ms / 1e3), 1) if g_ms > 0 else 0.0,
+            "gemm_time_frac_of_step": round((g_ms / 1e3) / elapsed, 3), "executed_tflop_per_cycle": round(exec_per_cycle, 3),
+            "a_min_tflop_per_cycle": A_MIN_TFLOP_PER_CYCLE}
+
+
+def side_kernels(be, elapsed):
+    """HIP-event figures of the other instrumented kernels over the same timed region."""
+    from devqa_amd import lib
+    ms, fl, n = lib.profile_read(lib.PROF_ATTENTION)
+    att = {"kernel": "attention_mfma_kernel", "launches": int(n), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
+           "tflops_as_launched": round(fl / 1e12 / (ms / 1e3), 1) if ms > 0 else 0.0, "time_frac_of_step": round(ms / 1e3 / elapsed, 3)}
+    ms, by, n = lib.profile_read(lib.PROF_LAYERNORM)
+    ln = {"kernel": "layernorm_kernel", "launches": int(n), "gbps": round(by / 1e9 / (ms / 1e3), 1) if ms > 0 else 0.0,
+          "time_frac_of_step": round(ms / 1e3 / elapsed, 3)}
+    ms, _, n = lib.profile_read(lib.PROF_FT_ADAMW)
+    by = float(be.stats.get("ft_bytes", 0))
+    npad_mean = be.stats.get("npad_sum", 0) / max(be.stats.get("cycles", 1), 1)
+    ft = {"bound": "hbm", "kernel": "ft_adamw_step_kernel", "launches": int(n), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
+          "achieved": round(by / 1e9 / (ms / 1e3), 1) if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": round(by / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms > 0 else 0.0,
+          "algorithmic_bytes": by, "updates": int(be.stats.get("updates", 0)), "npad_mean": round(npad_mean, 1),
+          "bytes_rule": "fp32 [2560, npad] per edit: first update 4 tensors (read w0; write w, m, v), later updates 6 (read + write w, m, v)",
+          "time_frac_of_step": round(ms / 1e3 / elapsed, 3)}
+    return att, ln, ft
 
 
 def pmc_traffic(kernel):
@@ -107,33 +404,70 @@ def pmc_traffic(kernel):
             for r in json.load(open(f))["kernels"]:
                 if r["kernel"].replace(" ", "").startswith(key):
                     return {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "read": r["read_bytes_per_launch"],
-                            "write": r["write_bytes_per_launch"], "source": os.path.basename(f)}
+                            "write": r["write_bytes_per_launch"], "source": os.path.basename(f) + " (static: separate --pmc passes)"}
         except (OSError, KeyError, ValueError):
             continue
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=25)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cycles-per-step", type=int, default=60)
-    ap.add_argument("--seed", type=int, default=20251121)
-    ap.add_argument("--layers", type=str, default=None, help="debug only: 'v,q,t' layer counts (INVALID as a benchmark)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="run the two stages of every batch back to back on one stream")
-    ap.add_argument("--cpu-threads", type=int, default=0)
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------------------
+def selftest_cpu(args):
+    """The multi-rank plumbing without a GPU: gloo process group, barrier-bracketed timed region over fake cycles, MAX all-reduce,
+    the all-gather of score rows, rank 0's JSON line.  Not a benchmark."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import devqa_amd  # noqa: F401
+    from devqa_amd.batched import shard_range
+    from devqa_amd.dist import gather_score_rows, init_from_env
+    if "WORLD_SIZE" not in os.environ:      # --gpus 1 without a launcher: a one-rank group
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    rank, world = init_from_env("gloo", min_world=1)
+    if os.environ.get("DEVQA_BENCH_FAIL_RANK") == str(rank):
+        sys.exit(3)
+    E, K = args.cycles_per_step, args.steps
+    if args.scaling == "weak":
+        first, n_local = rank * K * E, K * E
+    else:
+        lo, hi = shard_range(K * E, rank, world)
+        first, n_local = lo, hi - lo
+    dist.barrier()
+    t0 = time.time()
+    rows = np.zeros((n_local, 16), np.float32)
+    rows[:, 0] = np.arange(first, first + n_local)
+    time.sleep(0.01 * K)
+    dist.barrier()
+    tt = torch.tensor([time.time() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    nt = torch.tensor([n_local], dtype=torch.int64)
+    dist.all_reduce(nt)
+    got = gather_score_rows(rows, int(nt.item()), rank, world, torch.device("cpu"))
+    if rank == 0:
+        assert [int(v) for v in got[:, 0]] == list(range(int(nt.item())))
+        print(json.dumps({"metric": "selftest (not a benchmark)", "value": round(int(nt.item()) / float(tt.item()), 3), "unit": "cycles/s",
+                          "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * float(tt.item()) / K, 2),
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "none", "data": "selftest",
+                          "rccl_ranks": dist.get_world_size(), "config": {"workload": "fake cycles", "cycles_total": int(nt.item())}}))
+    dist.barrier()
+    dist.destroy_process_group()
 
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus and not os.environ.get("DEVQA_FORCE_DIST"):
+        sys.stderr.write("bench.py: launched with WORLD_SIZE=%s but --gpus %d; refusing to report a mislabelled run\n" % (env_world, args.gpus))
+        sys.exit(2)
+    if args.selftest_cpu:
+        return selftest_cpu(args)
+
+    import torch
+    import torch.distributed as dist
     import devqa_amd  # noqa: F401
     from devqa_amd import lib
-    from devqa_amd.batched import BatchedEditEval
-    from devqa_amd.dist import gather_score_rows, init_from_env
-    from devqa_amd.editor.vllm_editors.ft_vl.ft_vl import FTvl, FTvlConfig
-    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
-    from devqa_amd.synth import IdTokenizer, evqa_cycles, synth_image_u8
-    import torch.distributed as dist
+    from devqa_amd.dist import init_from_env
 
     # DEVQA_FORCE_DIST=1: build the process group (RCCL) even for one rank, so that a 1-GPU box walks the N > 1 branches below
     rank, world = init_from_env(min_world=1 if os.environ.get("DEVQA_FORCE_DIST") else 2)
@@ -143,104 +477,67 @@ def main():
     torch.cuda.set_device(dev)
     lib.load()
     layers = None if args.layers is None else tuple(int(x) for x in args.layers.split(","))
-    t0 = time.time()
-    want_cpu = (not args.no_cpu_baseline) and world == 1
-    model, cfg, host_arrays = build_full_model(dev, args.seed, layers, keep_host_copy=want_cpu)
-    vllm = BLIP2OPTForEdit(None, dev, model=model, tokenizer=IdTokenizer())
-    ft_cfg = FTvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "ft_vl", "blip2-opt-2.7b.yaml"))
-    ft_cfg.layers = [cfg["text_config"]["num_hidden_layers"] - 1]
-    editor = FTvl(vllm, ft_cfg, dev)
-    be = BatchedEditEval(editor, cycles_per_batch=args.cycles_per_step)
-    build_s = time.time() - t0
-
-    # ---- synthetic inputs, resident before the timed region (pixel values pre-processed into HBM) ----
     E, K, W = args.cycles_per_step, args.steps, args.warmup
-    n_cyc = (K + W) * E
-    proc = vllm.image_processor
-    img_cache = {}
-
-    def image_of(s, tag):
-        key = (s, tag)
-        if key not in img_cache:
-            gs = rank * n_cyc + s  # distinct samples per rank (weak scaling: per-GPU work fixed)
-            img_cache[key] = torch.from_numpy(proc(synth_image_u8(gs, tag, cfg["vision_config"]["image_size"], args.seed))).to(dev)
-        return img_cache[key]
-    cycles = evqa_cycles(n_cyc, cfg["text_config"]["vocab_size"], args.seed + 7919 * rank, image_of)
-    from devqa_amd.batched import copy_sample
-    batches = [([copy_sample(c) for c in cycles[i * E:(i + 1) * E]], [c for c in cycles[i * E:(i + 1) * E]])
-               for i in range(K + W)]
-    torch.cuda.synchronize()
+    want_cpu = (not args.no_cpu_baseline) and world == 1
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if W:
-        be.run_batches(batches[:W], pipelined=not args.no_pipeline)
-    for k in be.stats:
-        be.stats[k] = 0
-    barrier()
-    lib.profile_gemm(1)
-    t0 = time.time()
-    outs, metas = [], []
-    for o, mt in be.run_batches(batches[W:W + K], pipelined=not args.no_pipeline):
-        outs += o
-        metas += mt
-    barrier()
-    elapsed = time.time() - t0
-    lib.profile_gemm(0)
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        rows = BatchedEditEval.score_rows(outs, metas, rank * K * E)
-        gather_score_rows(rows, world * K * E, rank, world, torch.device(dev))  # the single RCCL gather
-    prof = lib.profile_gemm_read()
-    steps_mean = be.stats["steps"] / max(be.stats["cycles"], 1)
-
+    head_style = "survey" if args.ffn == "dense" else "opt"
+    leg = Leg(args, rank, world, dev, head_style, layers, keep_host_copy=want_cpu)
+    elapsed, n_local, n_total, ranks = timed_leg(leg, K, W, barrier, use_dist, rank, world, dev)
+    out = None
     if rank == 0:
-        total_cycles = world * K * E
-        value = total_cycles / elapsed
-        names = ["gemm_bf16_tn_kernel<32,128,1,4>", "gemm_bf16_glds_kernel<64,128,2,2>", "gemm_bf16_glds_kernel<128,128,2,2>",
-                 "gemm_bf16_pp_kernel"]
-        dom = max(range(4), key=lambda i: prof[i][0])
-        g_ms = sum(p[0] for p in prof)
-        g_fl = sum(p[1] for p in prof)
-        g_n = sum(p[2] for p in prof)
-        covered_cycles = K * E * (g_n / max(1, g_n))  # all launches of the timed region unless the event pool filled
-        dms, dfl, dn = prof[dom]
-        # algorithmic FLOPs of the dominant kernel's launches: its share of the executed GEMM FLOPs scaled to A_min
-        exec_per_cycle = g_fl / (K * E) / 1e12
-        alg_scale = min(1.0, A_MIN_TFLOP_PER_CYCLE / exec_per_cycle) if exec_per_cycle > 0 else 0.0
-        achieved = (dfl * alg_scale / 1e12) / (dms / 1e3) if dms > 0 else 0.0
-        traffic = pmc_traffic(names[dom])
+        value = n_total / elapsed
+        roof = gemm_roofline(n_local, elapsed)
+        roof["path_frac_of_mfma_peak"] = round(value / world * A_MIN_TFLOP_PER_CYCLE / MFMA_PEAK_TFLOPS, 4)
+        att, ln, ft = side_kernels(leg.be, elapsed)
+        steps_mean = leg.be.stats["steps"] / max(leg.be.stats["cycles"], 1)
+        d_in = leg.cfg["text_config"]["ffn_dim"]
         out = {
             "metric": "edit+eval cycles/sec, BLIP-2 FT_VL EVQA", "value": round(value, 3), "unit": "cycles/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BLIP-2-OPT-2.7B + FT_VL, %d synthetic EVQA-shaped edit+eval cycles per GPU "
-                                   "(%d per step), bf16 weights/activations, fp32 master + AdamW state for the edited "
-                                   "fc2 matrix, early stop enabled" % (K * E, E),
-                       "cycles_per_step": E, "cycles_total": total_cycles, "mean_ft_steps": round(steps_mean, 2),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "rccl_ranks": ranks,
+            "config": {"workload": "BLIP-2-OPT-2.7B + FT_VL, %d synthetic EVQA-shaped edit+eval cycles %s (%d per step), bf16 "
+                                   "weights/activations, fp32 master + AdamW state for the edited fc2 matrix, early stop enabled; "
+                                   "FFN recipe: %s" % (n_total if args.scaling == "strong" else K * E,
+                                                       "in total, block-partitioned over the ranks" if args.scaling == "strong" else "per GPU",
+                                                       E, DENSE_RECIPE if head_style == "survey" else SPARSE_RECIPE),
+                       "ffn": "dense" if head_style == "survey" else "sparse", "cycles_per_step": E, "cycles_total": n_total,
+                       "mean_ft_steps": round(steps_mean, 2), "ft_active_columns_mean": ft["npad_mean"], "ft_columns": d_in,
                        "layers": "39/12/32" if layers is None else args.layers, "sharding": "splits block-partitioned, 1 gather"},
-            "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None if traffic is None else traffic["hbm_bytes_per_launch"], "traffic_detail": traffic,
-                         "avg_launch_us": round(1e3 * dms / max(dn, 1), 2), "launches": int(dn),
-                         "executed_tflops": round((dfl / 1e12) / (dms / 1e3), 1) if dms > 0 else 0.0,
-                         "all_gemm_executed_tflops": round((g_fl / 1e12) / (g_ms / 1e3), 1) if g_ms > 0 else 0.0,
-                         "gemm_time_frac_of_step": round((g_ms / 1e3) / elapsed, 3),
-                         "executed_tflop_per_cycle": round(exec_per_cycle, 3), "a_min_tflop_per_cycle": A_MIN_TFLOP_PER_CYCLE,
-                         "path_frac_of_mfma_peak": round(value / world * A_MIN_TFLOP_PER_CYCLE / MFMA_PEAK_TFLOPS, 4)},
-            "phase_s": {k: round(v, 3) for k, v in be.stats.items() if k.startswith("t_")},
-            "build_s": round(build_s, 1),
+            "roofline": roof,
+            "roofline_hbm": {"ft_adamw_step": ft},
+            "kernels": {"attention": att, "layernorm": ln},
+            "phase_s": {k: round(v, 3) for k, v in leg.be.stats.items() if k.startswith("t_")},
+            "build_s": round(leg.build_s, 1),
         }
-        if want_cpu:
+    cycles_for_cpu = leg.sample_cycles(max(1, args.cpu_cycles)) if want_cpu and rank == 0 else None
+    host_arrays, cfg = leg.host_arrays, leg.cfg
+    leg.close()
+    if rank == 0 and not args.no_hbm_micro and layers is None:
+        out["roofline_hbm"].update(hbm_micro(dev))
+    # ---- the dense-FFN leg beside the sparse headline ---------------------------------------------------------------------------
+    if args.ffn == "both":
+        Kd = args.dense_steps or max(2, K // 5)
+        dleg = Leg(args, rank, world, dev, "survey", layers, keep_host_copy=False)
+        d_elapsed, d_local, d_total, _ = timed_leg(dleg, Kd, 1, barrier, use_dist, rank, world, dev)
+        if rank == 0:
+            _, _, dft = side_kernels(dleg.be, d_elapsed)
+            out["dense_ffn"] = {"value": round(d_total / d_elapsed, 3), "unit": "cycles/s", "steps": Kd, "warmup": 1,
+                                "ms_per_step": round(1e3 * d_elapsed / Kd, 2), "recipe": DENSE_RECIPE,
+                                "mean_ft_steps": round(dleg.be.stats["steps"] / max(dleg.be.stats["cycles"], 1), 2),
+                                "ft_active_columns_mean": dft["npad_mean"], "ft_adamw_step": dft,
+                                "phase_s": {k: round(v, 3) for k, v in dleg.be.stats.items() if k.startswith("t_")}}
+        dleg.close()
+    if rank == 0:
+        if want_cpu and cycles_for_cpu is not None:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
-            del model, vllm, editor, be
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(cfg, args.seed, threads, host_arrays)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.seed, threads, host_arrays, cycles_for_cpu, max(1, args.cpu_cycles), head_style)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

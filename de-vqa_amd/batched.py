@@ -347,6 +347,7 @@ class BatchedEditEval:
         post_h = post_argmax.cpu().numpy()
         steps_h = n_steps.cpu().numpy()
         losses_h = losses.cpu().numpy()
+        upd_h = self._adam_t.cpu().numpy()
         torch.cuda.current_stream().synchronize()
         t5 = time.time()
         eva = c["ev"]
@@ -377,6 +378,12 @@ class BatchedEditEval:
             out.append(rd)
         self.stats["cycles"] += E
         self.stats["steps"] += int(steps_h.sum())
+        # algorithmic HBM bytes of the executed AdamW updates (include/devqa.h, devqa_ft_adamw_step): the first update of an edit
+        # reads w0 and writes w, m, v (4 tensors), every later one reads and writes w, m, v (6 tensors), fp32, on [Dout, npad]
+        Dout_, npad_ = self._ft_shape
+        n_upd = int(upd_h.sum())
+        self.stats["updates"] = self.stats.get("updates", 0) + n_upd
+        self.stats["ft_bytes"] = self.stats.get("ft_bytes", 0) + 4 * Dout_ * npad_ * (6 * n_upd - 2 * int((upd_h > 0).sum()))
         self.last_losses = losses_h
         self.last_steps = steps_h
         self.stats["t_host"] += time.time() - t5
@@ -398,17 +405,20 @@ class BatchedEditEval:
         eng = self.eng
         dev = eng.dev
         Dout, Din = w0.shape
+        npad = Din
         if cfg.weight_decay == 0:
             idx, cnt = lib.active_columns(a_ft)
             npad = max(8, (int(cnt.max().item()) + 7) // 8 * 8)   # one small sync per batch: sizes the state
-        else:
+        dense = npad * 10 >= Din * 9      # (nearly) every column is active somewhere: gathering would only copy the matrix E times
+        if dense:
             idx = torch.arange(Din, dtype=torch.int32, device=dev).repeat(E, 1).contiguous()
             cnt = torch.full((E,), Din, dtype=torch.int32, device=dev)
             npad = Din
-        w0c = lib.gather_cols(w0, idx, cnt, npad, per_edit=False)        # [E, Dout, npad] pristine columns
-        a_ft = lib.gather_cols(a_ft, idx, cnt, npad, per_edit=True)      # [E, kmax, npad]
-        w0 = w0c
-        w = w0c.clone()
+            w = torch.empty((E, Dout, Din), dtype=torch.float32, device=dev)   # first update reads the shared w0 (devqa.h)
+        else:
+            w0 = lib.gather_cols(w0, idx, cnt, npad, per_edit=False)        # [E, Dout, npad] pristine columns
+            a_ft = lib.gather_cols(a_ft, idx, cnt, npad, per_edit=True)      # [E, kmax, npad]
+            w = w0.clone()
         mom = torch.empty_like(w)
         var = torch.empty_like(w)
         self.stats["npad_sum"] = self.stats.get("npad_sum", 0) + npad * E
@@ -434,5 +444,11 @@ class BatchedEditEval:
             lib.ft_adamw_step(w, mom, var, w0, a_ft, dy, y, do_update, adam_t, cfg.lr, 0.9, 0.999, 1e-8, cfg.weight_decay,
                               clamp)
         self._adam_t = adam_t
-        lib.delta_op(0, w, w0, mom)  # mom := w - w0 (reuse the buffer): the compacted delta
+        self._ft_shape = (Dout, npad)
+        if dense:   # edits that never updated (first loss already under the floor) have an unwritten w: their delta is zero
+            mom.zero_()
+            for e in torch.nonzero(adam_t > 0).flatten().tolist():
+                lib.delta_op(0, w[e], w0, mom[e])
+        else:
+            lib.delta_op(0, w, w0, mom)  # mom := w - w0 (reuse the buffer): the compacted delta
         return n_steps, losses, mom, idx, cnt, npad

@@ -183,12 +183,8 @@ static int launch_attention(const T* q, int64_t ldq, const T* k, int64_t ldk, co
     const size_t smem = sizeof(float) * (2 * ATT_KC * (dh + 1) + ATT_QT * dh + ATT_QT * ATT_KC);
     const long grid = (long)n_seq * H * q_tiles;
     DEVQA_CHECK_SHAPE(grid < 2147483647L, "attention: grid too large");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * (2 * ATT_KC * (ATT_MAXDH + 1) + ATT_QT * ATT_MAXDH + ATT_QT * ATT_KC)));
-        attr_done = true;
-    }
+    static std::atomic<unsigned> attr_done{0};
+    devqa_set_max_smem(attention_kernel<T>, sizeof(float) * (2 * ATT_KC * (ATT_MAXDH + 1) + ATT_QT * ATT_MAXDH + ATT_QT * ATT_KC), attr_done);
     hipLaunchKernelGGL(attention_kernel<T>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, q, ldq, k, ldk, v,
                        ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles);
     DEVQA_LAUNCH_CHECK("attention");

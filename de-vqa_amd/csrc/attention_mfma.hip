@@ -478,13 +478,13 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
             const long grid = (long)n_seq * H;
             if (dhp == 96) {
                 auto kern = attention_mfma_resident_kernel<96>;
-                static bool attr96 = false;
-                if (!attr96) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr96 = true; }
+                static std::atomic<unsigned> attr96{0};
+                devqa_set_max_smem(kern, 160 * 1024, attr96);
                 hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st0, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, nkp);
             } else {
                 auto kern = attention_mfma_resident_kernel<64>;
-                static bool attr64 = false;
-                if (!attr64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr64 = true; }
+                static std::atomic<unsigned> attr64{0};
+                devqa_set_max_smem(kern, 160 * 1024, attr64);
                 hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st0, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, nkp);
             }
             DEVQA_LAUNCH_CHECK("attention_mfma_resident");
@@ -509,12 +509,15 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
             hipLaunchKernelGGL((attention_mfma_kernel<D, 1>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, \
                                ldo, seq_desc, H, dh, scale, causal, q_tiles);                                          \
     } while (0)
+    // FLOPs as launched (4 Tq Tk dh per head with Tq = Tk = max_q_len: an upper bound for ragged / causal batches, exact for ViT)
+    const int ph = devqa_prof_begin(DEVQA_PROF_ATTENTION, st);
     if (dhp == 32) LAUNCH(32);
     else if (dhp == 64) LAUNCH(64);
     else if (dhp == 96) LAUNCH(96);
     else if (dhp == 128) LAUNCH(128);
     else return devqa_fail(DEVQA_E_SHAPE, "attention: dh=%d unsupported", dh);
 #undef LAUNCH
+    devqa_prof_end(ph, 4.0 * (double)n_seq * H * (double)max_q_len * (double)max_q_len * dh * ((causal & 1) ? 0.5 : 1.0), st);
     DEVQA_LAUNCH_CHECK("attention_mfma");
     return DEVQA_OK;
 }

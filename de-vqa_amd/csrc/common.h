@@ -27,6 +27,29 @@ int devqa_fail(int code, const char* fmt, ...);
         if (e_ != hipSuccess) return devqa_fail(DEVQA_E_HIP, "%s: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+// ---- measurement hook (profile.hip): HIP events around instrumented launches while devqa_profile(1) is in effect ----
+#define DEVQA_PROF_GEMM0 0        /* 0..3: GEMM tile variants 32x128, 64x128, 128x128, 256x256; work = FLOPs */
+#define DEVQA_PROF_ATTENTION 4    /* attention_mfma_kernel; work = FLOPs (4 Tq Tk dh per head, as launched) */
+#define DEVQA_PROF_FT_ADAMW 5     /* ft_adamw_step_kernel; work = bytes if every edit updates (24 E Dout Din) */
+#define DEVQA_PROF_COSINE 6       /* cosine top-k scan; work = corpus bytes */
+#define DEVQA_PROF_LAYERNORM 7    /* layernorm_kernel; work = bytes */
+#define DEVQA_PROF_SLOTS 8
+int devqa_prof_begin(int slot, hipStream_t st);            // -> handle, or -1 when profiling is off / the pool is full
+void devqa_prof_end(int handle, double work, hipStream_t st);
+
+// dynamic-LDS opt-in above 48 KiB: once per (kernel instantiation, device), safe against concurrent host threads.
+// `done` is a function-local static std::atomic<unsigned> bit mask over device ordinals.
+#include <atomic>
+template <typename K>
+static inline void devqa_set_max_smem(K kern, size_t smem, std::atomic<unsigned>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    done.fetch_or(bit, std::memory_order_release);
+}
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // round-to-nearest-even; NaN stays NaN (quiet)
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {

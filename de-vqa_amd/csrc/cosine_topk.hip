@@ -329,6 +329,7 @@ extern "C" int devqa_cosine_topk(const float* corpus, const float* queries, int 
     DEVQA_CHECK_SHAPE(k >= 1 && k <= CT_MAXK, "cosine_topk: k=%d unsupported (1..%d)", k, CT_MAXK);
     DEVQA_CHECK_SHAPE((((uintptr_t)workspace) & 255) == 0, "cosine_topk: workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    const int ph = devqa_prof_begin(DEVQA_PROF_COSINE, st);     // the whole call: norms + score tiles + selection
     char* ws = (char*)workspace;
     float* scores = (float*)ws;
     float* inv_c = (float*)(ws + align256((int64_t)Q * N * 4));
@@ -353,6 +354,7 @@ extern "C" int devqa_cosine_topk(const float* corpus, const float* queries, int 
     else
         hipLaunchKernelGGL(topk_select_kernel, dim3(Q), dim3(256), 0, st, scores, corpus, queries, N, D, k, normalize_corpus,
                            normalize_queries, out_idx, out_score);
+    devqa_prof_end(ph, 4.0 * (double)N * D, st);
     DEVQA_LAUNCH_CHECK("topk_select");
     return DEVQA_OK;
 }

@@ -143,14 +143,18 @@ static int launch_adamw(float* w, float* m, float* v, const float* w0, const flo
                         float beta1, float beta2, float eps, float wd, float clamp_eps, int64_t w0_stride_e, hipStream_t st) {
     if (Din <= 1024) {
         const int row_blocks = (Dout + 4 * ROWS - 1) / (4 * ROWS);
+        const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
         hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS, true>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
                            do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
+        devqa_prof_end(ph, 24.0 * E * (double)Dout * Din, st);
         DEVQA_LAUNCH_CHECK("ft_adamw_step");
         return DEVQA_OK;
     }
     const int row_blocks = (Dout + ROWS - 1) / ROWS;
+    const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
     hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
                        do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
+    devqa_prof_end(ph, 24.0 * E * (double)Dout * Din, st);
     DEVQA_LAUNCH_CHECK("ft_adamw_step");
     return DEVQA_OK;
 }

@@ -158,52 +158,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(
     }
 }
 
-// ---- optional per-launch timing for bench.py's roofline (HIP events on the launch stream) ----------
 #include <mutex>
 #include <vector>
-#define PROF_VARIANTS 4
-#define PROF_MAX_PAIRS 49152
-static bool g_prof_on = false;
-static std::vector<hipEvent_t> g_prof_ev;       // pairs: start, stop
-static std::vector<int> g_prof_variant;
-static std::vector<double> g_prof_flops;
-static size_t g_prof_used = 0;
-
-extern "C" int devqa_profile_gemm(int enable) {
-    if (enable) {
-        if (g_prof_ev.empty()) {
-            g_prof_ev.resize(2 * PROF_MAX_PAIRS);
-            for (auto& e : g_prof_ev)
-                if (hipEventCreate(&e) != hipSuccess) return devqa_fail(DEVQA_E_HIP, "profile: hipEventCreate failed");
-            g_prof_variant.resize(PROF_MAX_PAIRS);
-            g_prof_flops.resize(PROF_MAX_PAIRS);
-        }
-        g_prof_used = 0;
-    }
-    g_prof_on = enable != 0;
-    return DEVQA_OK;
-}
-// Synchronises on the recorded events.  Arrays of PROF_VARIANTS entries: variant 0 = 32x128 tile,
-// 1 = 64x128, 2 = 128x128 (kernel names gemm_bf16_tn_kernel<BM,BN,..>).
-extern "C" int devqa_profile_gemm_read(double* ms, double* flops, int64_t* launches) {
-    for (int i = 0; i < PROF_VARIANTS; ++i) {
-        ms[i] = 0.0;
-        flops[i] = 0.0;
-        launches[i] = 0;
-    }
-    for (size_t i = 0; i < g_prof_used; ++i) {
-        float t = 0.f;
-        if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess) return devqa_fail(DEVQA_E_HIP, "profile: event sync");
-        if (hipEventElapsedTime(&t, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess)
-            return devqa_fail(DEVQA_E_HIP, "profile: elapsed");
-        const int v = g_prof_variant[i];
-        ms[v] += t;
-        flops[v] += g_prof_flops[i];
-        launches[v] += 1;
-    }
-    return DEVQA_OK;
-}
-
 // ---- split-K for skinny problems with a very long K (dH = dlogits . E: M <= 256, N = 2560, K = 50272) ----
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn4, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -261,10 +217,24 @@ extern "C" int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const de
     return DEVQA_OK;
 }
 
-static int g_gemm_mode = -1;
+// Kernel-selection mode for A/B measurements (debugging aid, process-wide by design: it selects among kernels that issue the same
+// MFMA sequence per output element, so a launch that races with a mode change still computes the same result).
+static std::atomic<int> g_gemm_mode_a{-1};
+static int gemm_mode() {
+    int m = g_gemm_mode_a.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("DEVQA_GEMM");
+        int want = e ? atoi(e) : 0;
+        if (want < 0 || (want > 3 && (want < 10 || want > 26))) want = 0;
+        int expect = -1;
+        g_gemm_mode_a.compare_exchange_strong(expect, want);
+        m = g_gemm_mode_a.load(std::memory_order_relaxed);
+    }
+    return m;
+}
 extern "C" int devqa_gemm_set_mode(int mode) {
     if (mode < 0 || (mode > 3 && (mode < 10 || mode > 26))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
-    g_gemm_mode = mode;
+    g_gemm_mode_a.store(mode);
     return DEVQA_OK;
 }
 
@@ -284,21 +254,12 @@ static int launch_gemm(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ld
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t smem = 2 * (BM + BN) * BK * 2;
     auto kern = gemm_bf16_tn_kernel<BM, BN, WM, WN>;
-    static bool attr_done = false;
-    if (!attr_done && smem > 48 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
-    const bool prof = g_prof_on && g_prof_used < PROF_MAX_PAIRS;
-    if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_used], st);
+    static std::atomic<unsigned> attr_done{0};
+    if (smem > 48 * 1024) devqa_set_max_smem(kern, smem, attr_done);
+    const int ph = devqa_prof_begin(BM == 32 ? 0 : (BM == 64 ? 1 : 2), st);
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, st, A, lda, W, ldw, bias, M, N, K, alpha, act,
                        residual, out_bf16, out_f32, ldc, tiles_m, tiles_n, 0);
-    if (prof) {
-        (void)hipEventRecord(g_prof_ev[2 * g_prof_used + 1], st);
-        g_prof_variant[g_prof_used] = BM == 32 ? 0 : (BM == 64 ? 1 : 2);
-        g_prof_flops[g_prof_used] = 2.0 * (double)M * (double)N * (double)K;
-        ++g_prof_used;
-    }
+    devqa_prof_end(ph, 2.0 * (double)M * (double)N * (double)K, st);
     DEVQA_LAUNCH_CHECK("gemm_bf16");
     return DEVQA_OK;
 }
@@ -341,6 +302,7 @@ __global__ void splitk_reduce_epilogue_kernel(const float* __restrict__ part, in
 }
 
 namespace {
+constexpr size_t SPLITK_WS_BYTES = 36u << 20;
 struct SplitKWs { hipStream_t st; int dev; float* p; size_t bytes; };
 SplitKWs g_skws[8] = {};
 std::mutex g_skws_mu;
@@ -355,12 +317,12 @@ float* splitk_workspace(hipStream_t st, size_t bytes) {   // one buffer per (dev
         for (auto& w : g_skws)
             if (!w.p) { slot = &w; break; }
     if (!slot) return nullptr;
-    if (slot->bytes < bytes) {
-        if (slot->p) { (void)hipStreamSynchronize(st); (void)hipFree(slot->p); }
-        slot->p = nullptr; slot->bytes = 0;
-        const size_t want = bytes < (32u << 20) ? (32u << 20) : bytes + (bytes >> 2);
-        if (hipMalloc(reinterpret_cast<void**>(&slot->p), want) != hipSuccess) { (void)hipGetLastError(); slot->p = nullptr; return nullptr; }
-        slot->bytes = want; slot->st = st; slot->dev = dev;
+    // ONE fixed-size buffer per (device, stream), allocated at first use and never freed or regrown: the largest request of the
+    // small-M rule is 512/tiles slabs of <= tiles x (128 x 128) fp32 = 32 MiB, so the launch path never synchronises or frees.
+    if (bytes > SPLITK_WS_BYTES) return nullptr;
+    if (!slot->p) {
+        if (hipMalloc(reinterpret_cast<void**>(&slot->p), SPLITK_WS_BYTES) != hipSuccess) { (void)hipGetLastError(); slot->p = nullptr; return nullptr; }
+        slot->bytes = SPLITK_WS_BYTES; slot->st = st; slot->dev = dev;
     }
     return slot->p;
 }
@@ -388,10 +350,7 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     DEVQA_CHECK_SHAPE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dims too small");
     DEVQA_CHECK_SHAPE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (g_gemm_mode < 0) {
-        const char* e = getenv("DEVQA_GEMM");
-        g_gemm_mode = e ? atoi(e) : 0;
-    }
+    const int g_gemm_mode = gemm_mode();
     // Skinny problems are weight streams: with one 64x128 (128x128) tile per 128 output columns a [64 x 10240 x 2560] product runs
     // on 80 workgroups, and the 257-row GEMMs of a single-image ViT pass on 33-165.  When the tiles cover less than half the chip,
     // split K over enough workgroups to fill it (fp32 partials in the per-stream workspace, one reduce + epilogue pass).
@@ -418,12 +377,8 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
                                        M, N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, ws, (int64_t)N, tiles_m, tiles_n, steps);
                 } else {
                     auto kern = gemm_bf16_tn_kernel<128, 128, 2, 2>;
-                    static bool attr_done = false;
-                    if (!attr_done) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  2 * (128 + 128) * BK * 2);
-                        attr_done = true;
-                    }
+                    static std::atomic<unsigned> attr_done{0};
+                    devqa_set_max_smem(kern, 2 * (128 + 128) * BK * 2, attr_done);
                     hipLaunchKernelGGL(kern, dim3(tiles, used), dim3(256), 2 * (128 + 128) * BK * 2, st, A, lda, W, ldw, (const float*)nullptr,
                                        M, N, K, 1.0f, 0, (const float*)nullptr, (bf16_t*)nullptr, ws, (int64_t)N, tiles_m, tiles_n, steps);
                 }
@@ -440,10 +395,6 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
     // mode 0: LDS-DMA staging when K % 64 == 0, 256x256 tiles for large problems (default); 1: force the
     // register-staged kernels; 2: LDS-DMA staging but no 256x256 tiles; 10..17: experimental ring variants
     // (A/B testing via devqa_gemm_set_mode / DEVQA_GEMM)
-    if (g_gemm_mode < 0) {
-        const char* e = getenv("DEVQA_GEMM");
-        g_gemm_mode = e ? atoi(e) : 0;
-    }
     // the LDS-DMA kernels use 16-byte epilogue accesses: need N, ldc multiples of 4 and 16-byte aligned pointers
     const bool vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && ((((uintptr_t)out_f32) | ((uintptr_t)residual) | ((uintptr_t)bias)) & 15) == 0 &&
                         (((uintptr_t)out_bf16) & 7) == 0;
@@ -463,19 +414,13 @@ extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf1
             return launch_gemm<64, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
         return launch_gemm<128, 128, 2, 2>(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     }
-    const bool prof = g_prof_on && g_prof_used < PROF_MAX_PAIRS;
-    if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_used], st);
+    const int ph = devqa_prof_begin(variant, st);
     int rc;
     if (variant == 1) rc = launch_gemm_glds_64x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     else if (variant == 2) rc = launch_gemm_glds_128x128(A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     else if (g_gemm_mode == 3 || (int64_t)M * lda * 2 >= (1ll << 32) || (int64_t)N * ldw * 2 >= (1ll << 32))  // mode 3: previous default
         rc = launch_gemm_pipe(7, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
     else rc = launch_gemm_pp(2, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
-    if (prof) {
-        (void)hipEventRecord(g_prof_ev[2 * g_prof_used + 1], st);
-        g_prof_variant[g_prof_used] = variant;
-        g_prof_flops[g_prof_used] = 2.0 * (double)M * (double)N * (double)K;
-        ++g_prof_used;
-    }
+    devqa_prof_end(ph, 2.0 * (double)M * (double)N * (double)K, st);
     return rc;
 }

@@ -155,11 +155,8 @@ static int launch_glds(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ld
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t smem = 2 * (BM + BN) * 128;
     auto kern = gemm_bf16_glds_kernel<BM, BN, WM, WN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
+    static std::atomic<unsigned> attr_done{0};
+    devqa_set_max_smem(kern, smem, attr_done);
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), smem, st, A, lda, W, ldw, bias, M, N, K, alpha, act,
                        residual, out_bf16, out_f32, ldc, tiles_m, tiles_n);
     DEVQA_LAUNCH_CHECK("gemm_bf16_glds");

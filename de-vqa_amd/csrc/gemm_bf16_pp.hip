@@ -449,26 +449,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
     }
 }
 
-namespace {
-struct PPWorkspace {
-    float* ws = nullptr;
-    size_t ws_bytes = 0;
-    int* counters = nullptr;
-    int n_counters = 0;
-    int n_cu = 0;
-};
-PPWorkspace g_ppws[16];
-}  // namespace
-
 template <int ACT, bool SK, bool BAL = false>
 static int launch_pp_k(const PPArgs& g, hipStream_t st) {
     const size_t smem = 2 * PP_BUF;
     auto kern = gemm_bf16_pp_kernel<ACT, SK, BAL>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
+    static std::atomic<unsigned> attr_done{0};
+    devqa_set_max_smem(kern, smem, attr_done);
     hipLaunchKernelGGL(kern, dim3(g.dp_tiles + g.sk_wgs), dim3(512), smem, st, g);
     DEVQA_LAUNCH_CHECK("gemm_bf16_pp");
     return DEVQA_OK;
@@ -481,14 +467,16 @@ static int launch_pp(const PPArgs& g, hipStream_t st) {
         h.group_m = -g.group_m;
         return launch_pp_k<ACT, false, true>(h, st);
     }
-    return g.sk_wgs > 0 ? launch_pp_k<ACT, true>(g, st) : launch_pp_k<ACT, false>(g, st);
+    return launch_pp_k<ACT, false>(g, st);
 }
 
 // id 6: group_m 4 with the fp32 LDS transposition for every output kind (A/B of pp_epilogue_bf16).
 // id: 0 group_m 8, 1 group_m 1 (plain column-major tile order), 2 group_m 4 (default), 3 group_m 16,
-//     4 group_m 4 + stream-K tail (experimental: the partial-tile hand-off -- 256 KiB per segment through HBM/L2 plus an
-//       agent-scope acq_rel RMW whose release/acquire writes back / invalidates the XCD's L2 -- costs more than the
-//       partial round it removes on every shape of this path: measured 0.50-0.93x, profiles/r01_summary.md)
+//     4 = 2 (was: group_m 4 + a stream-K tail.  The partial-tile hand-off -- 256 KiB per segment through HBM/L2 plus an
+//       agent-scope acq_rel RMW whose release/acquire writes back / invalidates the XCD's L2 -- cost more than the partial round it
+//       removed on every shape of this path: measured 0.50-0.93x, profiles/r01_summary.md; its launcher, the only code that
+//       allocated and freed device memory inside a launch path, was removed in round 2.  The SK template parameter of the kernel
+//       is kept but no longer instantiated.)
 int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K, float alpha,
                    int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc, hipStream_t st) {
     static const int gms[7] = {8, 1, 4, 16, 4, -4, 4};
@@ -502,57 +490,11 @@ int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_
     g.tiles_m = (M + PP_BM - 1) / PP_BM;
     g.tiles_n = (N + PP_BN - 1) / PP_BN;
     g.group_m = gms[id];
-    const int T = g.tiles_m * g.tiles_n, nk = K / PP_BK;
+    const int T = g.tiles_m * g.tiles_n;
     g.dp_tiles = T; g.sk_wgs = 0; g.sk_per = 1; g.sk_max_seg = 1; g.ws = nullptr; g.counters = nullptr;
     g.bf16_fast = out_bf16 != nullptr && out_f32 == nullptr && residual == nullptr && N % 8 == 0 && ldc % 8 == 0 &&
                   (((uintptr_t)out_bf16) & 15) == 0 && (bias == nullptr || (((uintptr_t)bias) & 15) == 0);
     if (id == 6) g.bf16_fast = 0;       // A/B: the fp32 transposition for every output kind
-    if (id == 4) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        PPWorkspace& wsp = g_ppws[dev & 15];
-        if (wsp.n_cu == 0) {
-            int n = 0;
-            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            wsp.n_cu = n > 0 ? n : 256;
-        }
-        const int P = wsp.n_cu;
-        const int R = T % P;                      // tiles of the last, partial round
-        // worth it when the partial round is neither nearly full nor nearly empty of work to spread
-        if (R > 0 && R * 8 <= P * 7) {
-            const long I = (long)R * nk;
-            int G = (int)(I / 8 < P ? I / 8 : P);  // >= 8 K-tiles per workgroup
-            if (G >= 2 && G > R) {
-                const int per = (int)((I + G - 1) / G);
-                G = (int)((I + per - 1) / per);
-                const int max_seg = (nk + per - 1) / per + 1;
-                const size_t need = (size_t)R * max_seg * 65536 * sizeof(float);
-                bool ok = true;
-                if (need > wsp.ws_bytes) {
-                    (void)hipStreamSynchronize(st);
-                    if (wsp.ws) (void)hipFree(wsp.ws);
-                    wsp.ws = nullptr;
-                    wsp.ws_bytes = 0;
-                    const size_t want = need + (need >> 2);
-                    if (hipMalloc(reinterpret_cast<void**>(&wsp.ws), want) == hipSuccess) wsp.ws_bytes = want; else ok = false;
-                }
-                if (ok && R > wsp.n_counters) {
-                    (void)hipStreamSynchronize(st);
-                    if (wsp.counters) (void)hipFree(wsp.counters);
-                    wsp.counters = nullptr;
-                    wsp.n_counters = 0;
-                    const int nc = R > 1024 ? R : 1024;
-                    if (hipMalloc(reinterpret_cast<void**>(&wsp.counters), nc * sizeof(int)) == hipSuccess &&
-                        hipMemset(wsp.counters, 0, nc * sizeof(int)) == hipSuccess) wsp.n_counters = nc; else ok = false;
-                }
-                if (ok) {
-                    g.dp_tiles = T - R; g.sk_wgs = G; g.sk_per = per; g.sk_max_seg = max_seg; g.ws = wsp.ws; g.counters = wsp.counters;
-                } else {
-                    (void)hipGetLastError();     // out of memory for the workspace: plain data-parallel launch
-                }
-            }
-        }
-    }
     switch (act) {
         case DEVQA_ACT_NONE: return launch_pp<DEVQA_ACT_NONE>(g, st);
         case DEVQA_ACT_RELU: return launch_pp<DEVQA_ACT_RELU>(g, st);

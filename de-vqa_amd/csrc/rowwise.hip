@@ -120,6 +120,7 @@ extern "C" int devqa_layernorm(const float* x, const float* add, const float* ga
     hipStream_t st = (hipStream_t)stream;
 #define LN_ARGS x, add, gamma, beta, M, D, eps, out_bf16, out_f32, st
     const int nvl = (D / 4 + 63) / 64;      // float4 pieces per lane
+    const int ph = devqa_prof_begin(DEVQA_PROF_LAYERNORM, st);
     if (nvl <= 1) launch_layernorm<1, 4>(LN_ARGS);
     else if (nvl <= 2) launch_layernorm<2, 4>(LN_ARGS);
     else if (nvl <= 3) launch_layernorm<3, 2>(LN_ARGS);
@@ -129,6 +130,7 @@ extern "C" int devqa_layernorm(const float* x, const float* add, const float* ga
     else if (nvl <= 10) launch_layernorm<10, 2>(LN_ARGS);
     else launch_layernorm<16, 1>(LN_ARGS);
 #undef LN_ARGS
+    devqa_prof_end(ph, (double)M * D * (4.0 + (add ? 4.0 : 0.0) + (out_bf16 ? 2.0 : 0.0) + (out_f32 ? 4.0 : 0.0)), st);
     DEVQA_LAUNCH_CHECK("layernorm");
     return DEVQA_OK;
 }

@@ -51,6 +51,8 @@ def load():
     _sig(L.devqa_gemm_bf16_splitk, [P, I64, P, I64, I, I, I, I, P, P, P])
     _sig(L.devqa_profile_gemm, [I])
     _sig(L.devqa_profile_gemm_read, [P, P, P])
+    _sig(L.devqa_profile, [I])
+    _sig(L.devqa_profile_read, [I, P, P, P])
     _sig(L.devqa_layernorm, [P, P, P, P, I, I, F, P, P, P])
     _sig(L.devqa_attention_f32, [P, I64, P, I64, P, I64, P, I64, P, I, I, I, I, F, I, P])
     _sig(L.devqa_im2col_patches_f32, [P, I, I, I, I, P, P])
@@ -96,7 +98,7 @@ def load():
     return L
 
 
-EXPORTS = ["devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
+EXPORTS = ["devqa_profile", "devqa_profile_read", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
            "devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
@@ -156,6 +158,20 @@ def profile_gemm_read():
     ln = (ctypes.c_int64 * 4)()
     _chk(load().devqa_profile_gemm_read(ms, fl, ln), "devqa_profile_gemm_read")
     return [(ms[i], fl[i], ln[i]) for i in range(4)]
+
+
+PROF_GEMM0, PROF_ATTENTION, PROF_FT_ADAMW, PROF_COSINE, PROF_LAYERNORM = 0, 4, 5, 6, 7
+
+
+def profile(enable):
+    _chk(load().devqa_profile(int(enable)), "devqa_profile")
+
+
+def profile_read(slot):
+    """-> (ms, work, launches) of one instrumented kernel family since profile(1) (include/devqa.h)."""
+    ms, wk, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    _chk(load().devqa_profile_read(int(slot), ctypes.byref(ms), ctypes.byref(wk), ctypes.byref(ln)), "devqa_profile_read")
+    return ms.value, wk.value, ln.value
 
 
 def _chk(rc, name):

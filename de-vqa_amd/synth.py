@@ -19,12 +19,21 @@ def param_init(name: str, shape, seed: int = 20251121, style: str = "unit") -> n
     positions 0.02 N, and decoder fc1 ~ N(0, 0.15/sqrt(fan_in)) with bias -0.3, which
     makes the ReLU FFN activations sparse (~2% active) like a trained OPT so that the
     FT_VL loop (lr 1e-3, 25 steps) converges over ~20-25 steps with logits of O(1-20)
-    instead of saturating in one step."""
+    instead of saturating in one step.
+    style "survey": SURVEY.md 8(d)'s recipe as written -- every weight N(0, 0.02), LayerNorm weight 1, all biases 0.  The decoder
+    FFN is then DENSE (half of the ReLU units fire on any row), which disables the FT loop's column compaction: bench.py's
+    `--ffn dense` leg."""
     rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
     shape = tuple(int(s) for s in shape)
     z = rng.standard_normal(shape, dtype=np.float32)
     low = name.lower()
     is_ln = ("layer_norm" in low or "layernorm" in low)
+    if style == "survey":   # SURVEY.md 8(d) verbatim: N(0, 0.02) per parameter name, LayerNorm weight = 1, every bias = 0
+        if is_ln:
+            return np.ones(shape, np.float32) if name.endswith("weight") else np.zeros(shape, np.float32)
+        if name.endswith("bias"):
+            return np.zeros(shape, np.float32)
+        return (0.02 * z).astype(np.float32)
     if is_ln and name.endswith("weight"):
         return (1.0 + 0.05 * z).astype(np.float32)
     if style == "llava":  # CLIP ViT + LLaMA naming (de-vqa_amd/llava_spec.py)

@@ -12,8 +12,12 @@
  *   - every function returns 0 on success or a negative DEVQA_E_* code; it never
  *     throws and never synchronises the device; devqa_last_error() returns a
  *     thread-local message for the last failure on the calling thread.
- *   - tensors are raw DEVICE pointers, row-major, caller-owned; the library
- *     allocates nothing.  bf16 is passed as uint16_t bit patterns.
+ *   - tensors are raw DEVICE pointers, row-major, caller-owned.  The op-level
+ *     entry points allocate nothing, with ONE exception: the split-K GEMM rule for
+ *     skinny problems keeps a fixed 36 MiB fp32 partial-sum buffer per (device,
+ *     stream), allocated at first use and never freed or regrown (no hipFree /
+ *     hipMalloc / synchronisation ever happens inside a launch path).
+ *     bf16 is passed as uint16_t bit patterns.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *   - shapes are checked on the host before any launch (a kernel is never
  *     launched with operands its indexing does not cover).
@@ -69,10 +73,19 @@ int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const devqa_bf16* W
  * Every variant issues the same MFMA sequence per output element, so results are bit-identical. */
 int devqa_gemm_set_mode(int mode);
 
-/* Measurement hook for bench.py's roofline: when enabled, every devqa_gemm_bf16 launch is bracketed by
- * HIP events on its own stream (up to 49152 launches).  _read synchronises on them and returns, per tile
- * variant (0: 32x128, 1: 64x128, 2: 128x128; arrays of 4), the summed kernel time (ms), the summed useful
- * FLOPs (2*M*N*K) and the launch count.  Not part of the data path. */
+/* Measurement hook for bench.py's roofline lines (csrc/profile.hip): while enabled, every launch of an instrumented kernel is
+ * bracketed by HIP events on its own stream (up to 98304 launches; thread-safe).  devqa_profile_read synchronises on the events
+ * of one slot and returns its summed kernel time (ms), summed work and launch count.  Slots: 0..3 GEMM tile variants (32x128,
+ * 64x128, 128x128, 256x256 ping-pong; work = 2 M N K FLOPs), 4 attention_mfma (FLOPs as launched), 5 ft_adamw_step (bytes if every
+ * edit updates: 24 E Dout Din), 6 cosine top-k call (corpus bytes 4 N D), 7 layernorm (bytes).  devqa_profile_gemm / _gemm_read are
+ * the round-1 names for slots 0..3 (arrays of 4).  Not part of the data path. */
+#define DEVQA_PROF_SLOT_GEMM0 0
+#define DEVQA_PROF_SLOT_ATTENTION 4
+#define DEVQA_PROF_SLOT_FT_ADAMW 5
+#define DEVQA_PROF_SLOT_COSINE 6
+#define DEVQA_PROF_SLOT_LAYERNORM 7
+int devqa_profile(int enable);
+int devqa_profile_read(int slot, double* ms, double* work, int64_t* launches);
 int devqa_profile_gemm(int enable);
 int devqa_profile_gemm_read(double* ms, double* flops, int64_t* launches);
 

@@ -112,3 +112,39 @@ def test_generic_evaluator_shards_splits_world2(sizes):
         want.append(["r%d" % j for j in range(i, i + sz)])
         i += sz
     assert out == want
+
+
+def _run_bench(extra, env=None):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-cpu"] + extra, env=e, capture_output=True, text=True,
+                       timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_n_spawns_n_ranks_world2():
+    """`python bench.py --gpus 2` with no torchrun environment (the driver's documented form): the parent starts 2 child ranks, they
+    form a process group (gloo here, RCCL on GPUs), shard, meet in the single gather, and rank 0's JSON line comes back with
+    n_gpus = 2.  Weak: K * E cycles per rank; strong: K * E in total, block-partitioned."""
+    rc, j, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--cycles-per-step", "5"])
+    assert rc == 0, err[-1500:]
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["scaling"] == "weak" and j["config"]["cycles_total"] == 30 and j["steps"] == 3
+    rc, j, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "0", "--cycles-per-step", "5", "--scaling", "strong"])
+    assert rc == 0, err[-1500:]
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["cycles_total"] == 15
+    rc, j, err = _run_bench(["--gpus", "1", "--steps", "2", "--cycles-per-step", "4"])
+    assert rc == 0 and j["n_gpus"] == 1 and j["config"]["cycles_total"] == 8
+
+
+def test_bench_launcher_failure_modes():
+    # a rank that exits non-zero makes the parent exit non-zero (and the surviving rank is ended, not left in the collective)
+    rc, j, err = _run_bench(["--gpus", "2", "--steps", "2"], {"DEVQA_BENCH_FAIL_RANK": "1"})
+    assert rc != 0 and "rank exit codes" in err
+    # under a launcher whose WORLD_SIZE disagrees with --gpus the run refuses to print a mislabelled line
+    rc, j, err = _run_bench(["--gpus", "2", "--steps", "2"], {"WORLD_SIZE": "4", "RANK": "0"})
+    assert rc == 2 and j is None and "WORLD_SIZE=4" in err
