@@ -42,6 +42,13 @@ __device__ __forceinline__ void am_swap16(float x, float& a, float& b) {
 __device__ __forceinline__ void am_swap32(float x, float& a, float& b) {
     asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "=&v"(a), "=&v"(b) : "v"(x));
 }
+// max of three without the v_max_f32 x, x canonicalisation clang puts in front of every fmaxf operand that comes out of an MFMA
+// (IEEE sNaN quieting): scores are finite or -inf here.
+__device__ __forceinline__ float am_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ float am_max4(float x) {
     float a, b;
     am_swap16(x, a, b);
@@ -144,8 +151,31 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
         kreg[j] = *reinterpret_cast<const am_u32x4_t*>(k + grow * ldk + st_col[j]);                                         \
         vreg[j] = *reinterpret_cast<const am_u32x4_t*>(v + grow * ldv + st_col[j]);                                         \
     }
+    // Fast form for chunks that lie entirely inside the own key range of a sequence without a visible prefix (every ViT / Q-Former
+    // chunk but the last, OPT sequences that carry their own image tokens): uniform 64-bit base (SGPRs) + a per-thread 32-bit
+    // element offset fixed for the whole loop -> `global_load_dwordx4 v, voff, s[base]` with NO per-chunk vector address arithmetic.
+    // (The general form above spends ~50 VALU instructions per chunk on it, 18 of them quarter-rate 32x32 multiplies -- as many
+    // cycles as the softmax itself.)
+    const bool fast_rows = kp_len == 0 && (int64_t)(AM_KC - 1) * max(ldk, ldv) + h * dh + DHP < (1ll << 31);
+    uint32_t fk_off[LD], fv_off[LD];
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+        fk_off[j] = (uint32_t)(st_row[j] * (int)ldk + st_col[j]);
+        fv_off[j] = (uint32_t)(st_row[j] * (int)ldv + st_col[j]);
+    }
+    const bf16_t* const k_own = k + (int64_t)ko_start * ldk;
+    const bf16_t* const v_own = v + (int64_t)ko_start * ldv;
+#define AM_FETCH_ANY(C0)                                                                                                    \
+    if (fast_rows && (C0) + AM_KC <= n_keys) {                                                                              \
+        const bf16_t* kb = k_own + (int64_t)(C0) * ldk;                                                                     \
+        const bf16_t* vb = v_own + (int64_t)(C0) * ldv;                                                                     \
+        _Pragma("unroll") for (int j = 0; j < LD; ++j) {                                                                    \
+            kreg[j] = *reinterpret_cast<const am_u32x4_t*>(kb + fk_off[j]);                                                 \
+            vreg[j] = *reinterpret_cast<const am_u32x4_t*>(vb + fv_off[j]);                                                 \
+        }                                                                                                                   \
+    } else { AM_FETCH(C0) }
     const bool wave_has_rows = q0 + wave * (16 * QB) < q_len;  // waves without a query still stage K/V and hit the barriers
-    if (n_keys > 0) { AM_FETCH(0) }
+    if (n_keys > 0) { AM_FETCH_ANY(0) }
     for (int c0 = 0; c0 < n_keys; c0 += AM_KC) {
         __syncthreads();  // previous chunk fully consumed
 #pragma unroll
@@ -154,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
             *reinterpret_cast<am_u32x4_t*>(Vs + st_off[j]) = vreg[j];
         }
         __syncthreads();
-        if (c0 + AM_KC < n_keys) { AM_FETCH(c0 + AM_KC) }  // next chunk's loads fly under this chunk's MFMAs
+        if (c0 + AM_KC < n_keys) { AM_FETCH_ANY(c0 + AM_KC) }  // next chunk's loads fly under this chunk's MFMAs
         if (!wave_has_rows) continue;
         // FULL chunks (64 keys, none hidden by the causal rule) take a branch-free instantiation of the body
         auto body = [&](auto full_tag) {
@@ -193,11 +223,14 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                         st[b][t][r] = ok ? st[b][t][r] : -INFINITY;
                     }
             }
-            float mloc = fmaxf(fmaxf(fmaxf(st[b][0][0], st[b][0][1]), fmaxf(st[b][0][2], st[b][0][3])),
-                               fmaxf(fmaxf(st[b][1][0], st[b][1][1]), fmaxf(st[b][1][2], st[b][1][3])));
-            mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(st[b][2][0], st[b][2][1]), fmaxf(st[b][2][2], st[b][2][3])),
-                                     fmaxf(fmaxf(st[b][3][0], st[b][3][1]), fmaxf(st[b][3][2], st[b][3][3]))));
-            mloc = am_max4(mloc);
+            float mloc = am_max3(st[b][0][0], st[b][0][1], st[b][0][2]);
+            mloc = am_max3(mloc, st[b][0][3], st[b][1][0]);
+            mloc = am_max3(mloc, st[b][1][1], st[b][1][2]);
+            mloc = am_max3(mloc, st[b][1][3], st[b][2][0]);
+            mloc = am_max3(mloc, st[b][2][1], st[b][2][2]);
+            mloc = am_max3(mloc, st[b][2][3], st[b][3][0]);
+            mloc = am_max3(mloc, st[b][3][1], st[b][3][2]);
+            mloc = am_max4(fmaxf(mloc, st[b][3][3]));
             float m_new = fmaxf(m_run[b], mloc);                // running max of the UNSCALED scores
             // Lazy rescale: the reference point of the exponentials only has to be CLOSE to the running max.  Unless some query
             // of this wave saw its max grow by more than 2^8 (always true for a query's first visible keys), every lane keeps
@@ -207,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
             const bool rescale = __builtin_amdgcn_ballot_w64(grow) != 0;   // wave-uniform
             if (!rescale) m_new = m_run[b];
             float alpha = 1.f, lloc = 0.f;
-            if (m_new != -INFINITY) {
+            if (FULLC || m_new != -INFINITY) {   // a full chunk shows 64 valid, visible keys to every query: m_new is finite
                 const float mc = m_new * sc2;
                 if (rescale) alpha = __builtin_amdgcn_exp2f(m_run[b] * sc2 - mc);   // m_run[b] = -inf -> 0
 #pragma unroll
