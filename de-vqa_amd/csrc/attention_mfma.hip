@@ -2,18 +2,20 @@
 // softmax statistics and accumulation).  ViT (257x257, dh 88), Q-Former (32x32 / 32x257, dh 64) and
 // OPT (causal + visible prefix, dh 80) all go through this kernel.
 //
-// Workgroup = (sequence, head, 64-query tile); 4 waves x 16 query rows; keys stream through LDS in
-// 64-key chunks (K and V row-major [64][DHP] bf16, row stride 2*DHP+32 bytes = an odd multiple of 32 B,
-// which makes both the ds_read_b128 K-fragment reads and the ds_read_b64_tr_b16 V reads conflict-free).
+// Workgroup = (sequence, head, 64-query tile); 4 waves x 16 query rows; keys stream through a double-buffered LDS image in
+// 64-key chunks (K and V row-major [64][DHP] bf16, rows padded so that both the ds_read_b128 K-fragment reads and the
+// ds_read_b64_tr_b16 V reads are conflict-free), one barrier per chunk.
 //
 // Operand orientation (no LDS round trip for P, no transposed V image):
 //   S^T = K . Q^T   -> a lane's 16x16 accumulator holds, for ONE query (lane&15), the keys
 //                      16t + 4*(lane>>4) + r of key tile t  -> softmax row statistics need only two
 //                      cross-lane steps (xor 16, 32);
-//   O   = P . V     -> the same registers, converted to bf16, ARE the A operand of the PV product if the
-//                      k index of that MFMA enumerates keys in the order (tile 2s, r=0..3, tile 2s+1,
-//                      r=0..3) for lane group lane>>4; the matching B operand is read from the row-major V
-//                      image with ds_read_b64_tr_b16 (4 keys x 16 channels per 16-lane group).
+//   O^T = V^T . P^T -> the same registers, converted to bf16, ARE the B operand (n = query) of that product if the
+//                      k index of the MFMA enumerates keys in the order (tile 2s, r=0..3, tile 2s+1,
+//                      r=0..3) for lane group lane>>4; the matching A operand (m = channel) is read from the row-major V
+//                      image with ds_read_b64_tr_b16 (4 keys x 16 channels per 16-lane group).  The accumulator then holds,
+//                      for the lane's OWN query, 4 consecutive channels per 16-channel tile: the rescale factor and the
+//                      normaliser never cross lanes and the output leaves in 8-byte packed stores.
 // head dims that are not multiples of 32 (88, 80) are zero-padded in LDS to DHP = 96.
 #include <stdlib.h>
 #include "common.h"
@@ -68,18 +70,29 @@ __device__ __forceinline__ float am_sum4(float x) {
 // DEVQA_ATTENTION_QB=2): 128-query tiles -- every K / V fragment read from LDS feeds two MFMAs (half the LDS traffic per query) and
 // long sequences need fewer workgroups that each stream the whole K / V (ViT-g, 257 tokens: 3 instead of 5 per image and head);
 // measured slower, see launch_attention_mfma.
-template <int DHP, int QB>
+template <int DHP, int QB, bool DBUF>
 __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                              const bf16_t* __restrict__ k, int64_t ldk,
                                                              const bf16_t* __restrict__ v, int64_t ldv,
                                                              bf16_t* __restrict__ out, int64_t ldo,
                                                              const int32_t* __restrict__ seq_desc, int H, int dh,
                                                              float scale, int causal, int q_tiles) {
-    constexpr int STRIDE = 2 * DHP + 32;  // bytes per LDS row
+    // bytes per LDS row: the padding makes 8 consecutive rows start in 8 different 4-bank groups (ds_read_b128 K fragments,
+    // ds_write_b128 staging) and 4 consecutive rows in 4 different 8-bank groups (ds_read_b64_tr_b16 V fragments); 16 bytes do
+    // that for 192- and 128-byte rows, 32 for 256- and 64-byte rows.
+    constexpr int STRIDE = 2 * DHP + ((DHP == 96 || DHP == 64) ? 16 : 32);
     constexpr int KS = DHP / 32;          // k-steps of the S^T product
     constexpr int DT = DHP / 16;          // 16-channel output tiles
-    __shared__ __attribute__((aligned(16))) unsigned char Ks[AM_KC * STRIDE];
-    __shared__ __attribute__((aligned(16))) unsigned char Vs[AM_KC * STRIDE];
+    constexpr int BUF = AM_KC * STRIDE;   // one chunk image
+    // K and V chunks are DOUBLE-buffered: chunk i lives in buffer i & 1, so one barrier per chunk orders both hazards (chunk
+    // i + 1 complete before it is read; chunk i - 1 fully consumed before its buffer is refilled) and the LDS writes of the next
+    // chunk overlap the MFMAs of this one.  4 x 64 x 208 B = 52 KiB per workgroup at dh 88 / 80: still 3 workgroups per CU.
+    // DBUF = false (default): ONE image, two barriers per chunk (all reads done -> refill -> visible).  Measured on ViT-g
+    // (tools/attention_bench.py): 184.8 us single-buffered vs 199.3 us double-buffered -- the refill of the next chunk right
+    // behind the barrier competes with the K-fragment reads that open the compute segment; kept as an opt-in
+    // (DEVQA_ATTENTION_DBUF=1) for shapes where the barrier is the longer wait.
+    __shared__ __attribute__((aligned(16))) unsigned char Ks2[(DBUF ? 2 : 1) * BUF];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs2[(DBUF ? 2 : 1) * BUF];
 
     int bid = blockIdx.x;
     {   // workgroups that share an XCD (blockIdx % 8) take a contiguous range of ids: the q tiles of one (sequence, head)
@@ -175,17 +188,32 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
         }                                                                                                                   \
     } else { AM_FETCH(C0) }
     const bool wave_has_rows = q0 + wave * (16 * QB) < q_len;  // waves without a query still stage K/V and hit the barriers
-    if (n_keys > 0) { AM_FETCH_ANY(0) }
-    for (int c0 = 0; c0 < n_keys; c0 += AM_KC) {
-        __syncthreads();  // previous chunk fully consumed
-#pragma unroll
-        for (int j = 0; j < LD; ++j) {
-            *reinterpret_cast<am_u32x4_t*>(Ks + st_off[j]) = kreg[j];
-            *reinterpret_cast<am_u32x4_t*>(Vs + st_off[j]) = vreg[j];
+#define AM_PARK(BUFI)                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < LD; ++j) {                                                                        \
+        *reinterpret_cast<am_u32x4_t*>(Ks2 + (BUFI) * BUF + st_off[j]) = kreg[j];                                           \
+        *reinterpret_cast<am_u32x4_t*>(Vs2 + (BUFI) * BUF + st_off[j]) = vreg[j];                                           \
+    }
+    if (n_keys > 0) {
+        AM_FETCH_ANY(0)
+        AM_PARK(0)
+        if (AM_KC < n_keys) { AM_FETCH_ANY(AM_KC) }
+    }
+    int bi = 0;
+    for (int c0 = 0; c0 < n_keys; c0 += AM_KC, bi ^= (DBUF ? 1 : 0)) {
+        __syncthreads();  // DBUF: chunk c0 complete in buffer bi, all waves done with buffer bi ^ 1; else: previous chunk consumed
+        if (DBUF) {
+            if (c0 + AM_KC < n_keys) {  // the next chunk sits in registers: park it in the other buffer, then fetch the one after
+                AM_PARK(bi ^ 1)
+                if (c0 + 2 * AM_KC < n_keys) { AM_FETCH_ANY(c0 + 2 * AM_KC) }
+            }
+        } else if (c0 > 0) {            // chunk 0 was parked by the prologue
+            AM_PARK(0)
+            __syncthreads();
+            if (c0 + AM_KC < n_keys) { AM_FETCH_ANY(c0 + AM_KC) }  // next chunk's loads fly under this chunk's MFMAs
         }
-        __syncthreads();
-        if (c0 + AM_KC < n_keys) { AM_FETCH_ANY(c0 + AM_KC) }  // next chunk's loads fly under this chunk's MFMAs
         if (!wave_has_rows) continue;
+        const unsigned char* Ks = Ks2 + bi * BUF;
+        const unsigned char* Vs = Vs2 + bi * BUF;
         // FULL chunks (64 keys, none hidden by the causal rule) take a branch-free instantiation of the body
         auto body = [&](auto full_tag) {
             constexpr bool FULLC = decltype(full_tag)::value;
@@ -212,25 +240,36 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
             short8_t pf[QB][2];
 #pragma unroll
             for (int b = 0; b < QB; ++b) {
-            if (need_mask) {
+            float mloc;
+            if (FULLC) {
+                mloc = am_max3(st[b][0][0], st[b][0][1], st[b][0][2]);
+                mloc = am_max3(mloc, st[b][0][3], st[b][1][0]);
+                mloc = am_max3(mloc, st[b][1][1], st[b][1][2]);
+                mloc = am_max3(mloc, st[b][1][3], st[b][2][0]);
+                mloc = am_max3(mloc, st[b][2][1], st[b][2][2]);
+                mloc = am_max3(mloc, st[b][2][3], st[b][3][0]);
+                mloc = am_max3(mloc, st[b][3][1], st[b][3][2]);
+                mloc = fmaxf(mloc, st[b][3][3]);
+            } else {
+                // only the nt (wave-uniform) key tiles that hold a key are touched; the others keep st = 0, which IS their p
+                mloc = -INFINITY;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
+                    if (t >= nt) continue;
+                    if (need_mask) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kidx = c0 + 16 * t + 4 * fq + r;
-                        bool ok = kidx < n_keys;
-                        if (causal && kidx >= kp_len) ok = ok && (kidx - kp_len) <= (qrow0 + 16 * b) + causal_off;
-                        st[b][t][r] = ok ? st[b][t][r] : -INFINITY;
+                        for (int r = 0; r < 4; ++r) {
+                            const int kidx = c0 + 16 * t + 4 * fq + r;
+                            bool ok = kidx < n_keys;
+                            if (causal && kidx >= kp_len) ok = ok && (kidx - kp_len) <= (qrow0 + 16 * b) + causal_off;
+                            st[b][t][r] = ok ? st[b][t][r] : -INFINITY;
+                        }
                     }
+                    mloc = am_max3(mloc, st[b][t][0], st[b][t][1]);
+                    mloc = am_max3(mloc, st[b][t][2], st[b][t][3]);
+                }
             }
-            float mloc = am_max3(st[b][0][0], st[b][0][1], st[b][0][2]);
-            mloc = am_max3(mloc, st[b][0][3], st[b][1][0]);
-            mloc = am_max3(mloc, st[b][1][1], st[b][1][2]);
-            mloc = am_max3(mloc, st[b][1][3], st[b][2][0]);
-            mloc = am_max3(mloc, st[b][2][1], st[b][2][2]);
-            mloc = am_max3(mloc, st[b][2][3], st[b][3][0]);
-            mloc = am_max3(mloc, st[b][3][1], st[b][3][2]);
-            mloc = am_max4(fmaxf(mloc, st[b][3][3]));
+            mloc = am_max4(mloc);
             float m_new = fmaxf(m_run[b], mloc);                // running max of the UNSCALED scores
             // Lazy rescale: the reference point of the exponentials only has to be CLOSE to the running max.  Unless some query
             // of this wave saw its max grow by more than 2^8 (always true for a query's first visible keys), every lane keeps
@@ -244,13 +283,15 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                 const float mc = m_new * sc2;
                 if (rescale) alpha = __builtin_amdgcn_exp2f(m_run[b] * sc2 - mc);   // m_run[b] = -inf -> 0
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
+                    if (!FULLC && t >= nt) continue;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float p = __builtin_amdgcn_exp2f(fmaf(st[b][t][r], sc2, -mc));   // masked (-inf) -> 0
                         st[b][t][r] = p;
                         lloc += p;
                     }
+                }
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) st[b][t] = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -268,18 +309,19 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                 u.w = am_pack2(st[b][2 * s2 + 1][2], st[b][2 * s2 + 1][3]);
                 pf[b][s2] = *reinterpret_cast<short8_t*>(&u);
             }
-            // ---- rescale O: its rows are queries 4fq + r, whose alpha lives in lane (fr' = 4fq + r) ----
+            // ---- rescale O^T: its COLUMN is query fr, the query whose alpha this lane already holds ----
             if (rescale) {
-                float ar[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * fq + r, 64);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[b][dt][r] *= ar[r];
+                    for (int r = 0; r < 4; ++r) o[b][dt][r] *= alpha;
             }
             }
-            // ---- O += P.V with transposed LDS reads of the row-major V image ----
+            // ---- O^T += V^T.P^T: the transposed LDS reads of the row-major V image deliver, for channel fr' and key group fq, the
+            // 8 keys of a k-step -- that is the A operand (m = channel) as well as the B operand (n = channel) layout; with P as
+            // the B operand (n = query fr, same registers as before) the accumulator tile is O^T: row = channel 16dt + 4fq + r,
+            // column = query fr.  Every per-query quantity (alpha, l) then lives in the lane that needs it, and a lane owns 4
+            // CONSECUTIVE channels of its query: 8-byte packed stores instead of 2-byte ones. ----
             const int tq = fr >> 2, tp = fr & 3;  // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -292,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                         (lds_s4_ptr)(Vs + (16 * (2 * s2 + 1) + 4 * fq + tq) * STRIDE + (16 * dt + 4 * tp) * 2));
                     const short8_t vf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
 #pragma unroll
-                    for (int b = 0; b < QB; ++b) o[b][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][s2], vf, o[b][dt], 0, 0, 0);
+                    for (int b = 0; b < QB; ++b) o[b][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b][s2], o[b][dt], 0, 0, 0);
                 }
             }
         };
@@ -301,22 +343,21 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
         if (c0 + AM_KC <= n_keys && all_visible) body(std::true_type{}); else body(std::false_type{});
     }
 
-    // ---- normalise and store: O row = query 4fq + r, column = channel 16dt + fr ----
+    // ---- normalise and store: O^T row = channel 16dt + 4fq + r, column = query fr ----
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        float lr[4];
+        const int qi = q0 + wave * (16 * QB) + 16 * b + fr;
+        if (qi >= q_len) continue;
+        const float inv = l_run[b] > 0.f ? 1.f / l_run[b] : 0.f;
+        bf16_t* orow = out + (int64_t)(q_start + qi) * ldo + h * dh;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run[b], 4 * fq + r, 64);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qi = q0 + wave * (16 * QB) + 16 * b + 4 * fq + r;
-            if (qi >= q_len) continue;
-            const float inv = lr[r] > 0.f ? 1.f / lr[r] : 0.f;
-            bf16_t* orow = out + (int64_t)(q_start + qi) * ldo + h * dh;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int c = 16 * dt + fr;
-                if (c < dh) orow[c] = f32_to_bf16(o[b][dt][r] * inv);
+        for (int dt = 0; dt < DT; ++dt) {
+            const int c = 16 * dt + 4 * fq;
+            if (c < dh) {      // dh % 8 == 0: a lane's 4 channels are all inside or all outside
+                uint2 u;
+                u.x = am_pack2(o[b][dt][0] * inv, o[b][dt][1] * inv);
+                u.y = am_pack2(o[b][dt][2] * inv, o[b][dt][3] * inv);
+                *reinterpret_cast<uint2*>(orow + c) = u;
             }
         }
     }
@@ -529,6 +570,8 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     // lost to 221 VGPRs; the kernel is bound by its ~19 VALU instructions per MFMA (SQ counters, profiles/r01_summary.md H).
     const char* qb_env = getenv("DEVQA_ATTENTION_QB");     // read per launch: the tests flip it
     const int qb = (qb_env && atoi(qb_env) == 2 && max_q_len > 2 * AM_QT && dhp <= 96) ? 2 : 1;
+    const char* db_env = getenv("DEVQA_ATTENTION_DBUF");
+    const bool dbuf = db_env && atoi(db_env) == 1 && qb == 1 && dhp <= 96;
     const int q_tiles = (max_q_len + AM_QT * qb - 1) / (AM_QT * qb);
     const long grid = (long)n_seq * H * q_tiles;
     DEVQA_CHECK_SHAPE(grid < 2147483647L, "attention: grid too large");
@@ -536,11 +579,14 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
 #define LAUNCH(D)                                                                                                      \
     do {                                                                                                               \
         if (qb == 2)                                                                                                   \
-            hipLaunchKernelGGL((attention_mfma_kernel<D, 2>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, \
-                               ldo, seq_desc, H, dh, scale, causal, q_tiles);                                          \
+            hipLaunchKernelGGL((attention_mfma_kernel<D, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                     \
+        else if (dbuf)                                                                                                 \
+            hipLaunchKernelGGL((attention_mfma_kernel<(D <= 96 ? D : 96), 1, true>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, \
+                               k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                     \
         else                                                                                                           \
-            hipLaunchKernelGGL((attention_mfma_kernel<D, 1>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, \
-                               ldo, seq_desc, H, dh, scale, causal, q_tiles);                                          \
+            hipLaunchKernelGGL((attention_mfma_kernel<D, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                     \
     } while (0)
     // FLOPs as launched (4 Tq Tk dh per head with Tq = Tk = max_q_len: an upper bound for ragged / causal batches, exact for ViT)
     const int ph = devqa_prof_begin(DEVQA_PROF_ATTENTION, st);

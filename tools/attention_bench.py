@@ -26,7 +26,10 @@ def t_us(fn, n=20):
 def main():
     lib.load()
     torch.manual_seed(0)
+    only = sys.argv[1] if len(sys.argv) > 1 else None      # "vit" / "opt": one shape (PMC passes)
     for name, n_seq, T, H, dh, causal in (("vit", 127, 257, 16, 88, 0), ("opt", 300, 48, 32, 80, 1)):
+        if only and name != only:
+            continue
         M = n_seq * T
         qkv = (torch.randn(M, 3 * H * dh, device="cuda") * 1.5).to(torch.bfloat16)
         q, k, v = qkv[:, :H * dh], qkv[:, H * dh:2 * H * dh], qkv[:, 2 * H * dh:]
@@ -47,6 +50,17 @@ def main():
         us = t_us(fn)
         flops = 4.0 * n_seq * H * T * T * dh * (0.5 if causal else 1.0)
         print("%-4s %d seq x %d tok x %d heads dh %d causal %d: %7.1f us  %6.1f TFLOP/s  rel err %.2e" % (name, n_seq, T, H, dh, causal, us, flops / us / 1e6, err), flush=True)
+        base = out.clone()
+        for var in ("DEVQA_ATTENTION_DBUF=1", "DEVQA_ATTENTION_QB=2", "DEVQA_ATTENTION_RESIDENT=1"):   # opt-in instantiations
+            kx, vx = var.split("=")
+            os.environ[kx] = vx
+            try:
+                out.zero_()
+                fn()
+                same = bool(torch.equal(out, base))
+                print("     %-28s %7.1f us   bit-identical to the default: %s" % (var, t_us(fn), same), flush=True)
+            finally:
+                del os.environ[kx]
 
 
 if __name__ == "__main__":
