@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                                                              float scale, int causal, int q_tiles) {
     // bytes per LDS row: the padding makes 8 consecutive rows start in 8 different 4-bank groups (ds_read_b128 K fragments,
     // ds_write_b128 staging) and 4 consecutive rows in 4 different 8-bank groups (ds_read_b64_tr_b16 V fragments); 16 bytes do
-    // that for 192- and 128-byte rows, 32 for 256- and 64-byte rows.
-    constexpr int STRIDE = 2 * DHP + ((DHP == 96 || DHP == 64) ? 16 : 32);
+    // that for 192- and 128-byte rows (used by the double-buffered instantiation, which needs the capacity: 52 KiB per workgroup
+    // at dh 88 / 80 = still 3 workgroups per CU), 32 do it for every row size (the default).
+    constexpr int STRIDE = 2 * DHP + ((DBUF && (DHP == 96 || DHP == 64)) ? 16 : 32);
     constexpr int KS = DHP / 32;          // k-steps of the S^T product
     constexpr int DT = DHP / 16;          // 16-channel output tiles
     constexpr int BUF = AM_KC * STRIDE;   // one chunk image
