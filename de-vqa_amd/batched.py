@@ -414,23 +414,29 @@ class BatchedEditEval:
             idx = torch.arange(Din, dtype=torch.int32, device=dev).repeat(E, 1).contiguous()
             cnt = torch.full((E,), Din, dtype=torch.int32, device=dev)
             npad = Din
-            w = torch.empty((E, Dout, Din), dtype=torch.float32, device=dev)   # first update reads the shared w0 (devqa.h)
         else:
             w0 = lib.gather_cols(w0, idx, cnt, npad, per_edit=False)        # [E, Dout, npad] pristine columns
             a_ft = lib.gather_cols(a_ft, idx, cnt, npad, per_edit=True)      # [E, kmax, npad]
-            w = w0.clone()
-        mom = torch.empty_like(w)
-        var = torch.empty_like(w)
         self.stats["npad_sum"] = self.stats.get("npad_sum", 0) + npad * E
         t_lab = torch.from_numpy(labels.reshape(-1)).to(dev)
         t_mask = torch.from_numpy(mask).to(dev)
+        clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else -1.0
+        ctx = eng.path_ctx() if hasattr(eng, "path_ctx") else None
+        if ctx is not None:     # the same loop behind the C ABI (devqa_ft_edit): one call, no Python between the steps
+            delta, losses, n_steps, adam_t = ctx.ft_edit(w0, a_ft, resid_ft, t_lab, t_mask, cfg.num_steps, cfg.lr, cfg.weight_decay, clamp)
+            self._adam_t = adam_t
+            self._ft_shape = (Dout, npad)
+            return n_steps, losses, delta, idx, cnt, npad
         coef = (t_mask / t_mask.sum(1, keepdim=True)).reshape(-1).contiguous()
         active = torch.ones(E, dtype=torch.int32, device=dev)
         do_update = torch.zeros(E, dtype=torch.int32, device=dev)
         n_steps = torch.zeros(E, dtype=torch.int32, device=dev)
         adam_t = torch.zeros(E, dtype=torch.int32, device=dev)
         losses = torch.zeros((E, cfg.num_steps), dtype=torch.float32, device=dev)
-        clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else -1.0
+        # engines without a path-level context (LLaVA / MiniGPT-4 decoders): the same loop, launched from here
+        w = torch.empty((E, Dout, npad), dtype=torch.float32, device=dev) if dense else w0.clone()   # dense: the first update reads w0
+        mom = torch.empty_like(w)
+        var = torch.empty_like(w)
         y = lib.rows_matvec(w0, a_ft)  # step-0 fc2 rows with the pristine matrix (active columns carry all of W.a)
         dl_dtype = eng.adt
         for it in range(cfg.num_steps):

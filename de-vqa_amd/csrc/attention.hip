@@ -173,11 +173,11 @@ static int launch_attention(const T* q, int64_t ldq, const T* k, int64_t ldk, co
                             const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale, int causal,
                             void* stream) {
     DEVQA_CHECK_ARG(q && k && v && out && seq_desc, "attention: null pointer");
+    causal &= 1;      // bit 2 (the caller's self-attention promise, include/devqa.h) is a hint for the MFMA kernels only
     if (n_seq == 0 || max_q_len == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(n_seq > 0 && max_q_len > 0 && H > 0, "attention: bad dims");
     DEVQA_CHECK_SHAPE(dh % 8 == 0 && dh > 0 && dh <= ATT_MAXDH, "attention: dh=%d unsupported", dh);
     DEVQA_CHECK_SHAPE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "attention: row strides must be multiples of 8");
-    DEVQA_CHECK_SHAPE(ldo % 4 == 0 && (((uintptr_t)out) & 7) == 0, "attention: out must be 8-byte aligned with ldo %% 4 == 0 (packed stores)");
     DEVQA_CHECK_SHAPE(ldq >= (int64_t)H * dh && ldk >= (int64_t)H * dh && ldv >= (int64_t)H * dh && ldo >= (int64_t)H * dh,
                       "attention: row strides smaller than H*dh");
     const int q_tiles = (max_q_len + ATT_QT - 1) / ATT_QT;

@@ -165,20 +165,21 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
         kreg[j] = *reinterpret_cast<const am_u32x4_t*>(k + grow * ldk + st_col[j]);                                         \
         vreg[j] = *reinterpret_cast<const am_u32x4_t*>(v + grow * ldv + st_col[j]);                                         \
     }
-    // Fast form for chunks that lie entirely inside the own key range of a sequence without a visible prefix (every ViT / Q-Former
-    // chunk but the last, OPT sequences that carry their own image tokens): uniform 64-bit base (SGPRs) + a per-thread 32-bit
+    // Fast form for chunks that lie entirely inside ONE contiguous key range -- the own range of a sequence without a visible
+    // prefix, or a visible range alone (every ViT / Q-Former chunk but the last): uniform 64-bit base (SGPRs) + a per-thread 32-bit
     // element offset fixed for the whole loop -> `global_load_dwordx4 v, voff, s[base]` with NO per-chunk vector address arithmetic.
     // (The general form above spends ~50 VALU instructions per chunk on it, 18 of them quarter-rate 32x32 multiplies -- as many
     // cycles as the softmax itself.)
-    const bool fast_rows = kp_len == 0 && (int64_t)(AM_KC - 1) * max(ldk, ldv) + h * dh + DHP < (1ll << 31);
+    const bool one_range = kp_len == 0 || own_hi == 0;       // all keys of this tile come from ONE contiguous row range
+    const bool fast_rows = one_range && (int64_t)(AM_KC - 1) * max(ldk, ldv) + h * dh + DHP < (1ll << 31);
     uint32_t fk_off[LD], fv_off[LD];
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
         fk_off[j] = (uint32_t)(st_row[j] * (int)ldk + st_col[j]);
         fv_off[j] = (uint32_t)(st_row[j] * (int)ldv + st_col[j]);
     }
-    const bf16_t* const k_own = k + (int64_t)ko_start * ldk;
-    const bf16_t* const v_own = v + (int64_t)ko_start * ldv;
+    const bf16_t* const k_own = k + (int64_t)(kp_len == 0 ? ko_start : kp_start) * ldk;
+    const bf16_t* const v_own = v + (int64_t)(kp_len == 0 ? ko_start : kp_start) * ldv;
 #define AM_FETCH_ANY(C0)                                                                                                    \
     if (fast_rows && (C0) + AM_KC <= n_keys) {                                                                              \
         const bf16_t* kb = k_own + (int64_t)(C0) * ldk;                                                                     \

@@ -41,11 +41,31 @@ def gather_score_rows(local_rows: np.ndarray, n_total: int, rank: int, world: in
     buf = torch.zeros((mx, local_rows.shape[1] if local_rows.ndim == 2 else 16), dtype=torch.float32, device=device)
     if len(local_rows):
         buf[:len(local_rows)] = torch.from_numpy(local_rows).to(device)
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf)  # RCCL all-gather of <= a few KB per rank: latency-bound, one xGMI hop
+    if torch.device(device).type == "cuda" and os.environ.get("DEVQA_GATHER_ABI", "1") != "0":
+        # the path-level entry point (include/devqa.h, devqa_gather_scores): ONE RCCL all-gather on the library's own communicator
+        allrows = _score_comm(rank, world, torch.device(device)).gather_scores(buf.contiguous())
+        outs = list(allrows.view(world, mx, -1).unbind(0))
+    else:
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf)  # gloo (CPU tests): the same collective through torch.distributed
     if rank != 0:
         return None
     return np.concatenate([o[:s].cpu().numpy() for o, s in zip(outs, sizes)], 0)
+
+
+_SCORE_COMM = {}
+
+
+def _score_comm(rank, world, device):
+    """lib.ScoreComm for this process group: rank 0 draws the RCCL id, the host-side object broadcast hands it to the others."""
+    key = (rank, world, device.index or 0)
+    if key not in _SCORE_COMM:
+        from . import lib
+        uid = [lib.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        _SCORE_COMM[key] = lib.ScoreComm(rank, world, uid[0], device.index or 0)
+    return _SCORE_COMM[key]
 
 
 def gather_results(local_results, local_rows, n_total, rank, world, device):

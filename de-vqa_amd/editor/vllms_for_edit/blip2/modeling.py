@@ -136,7 +136,10 @@ class Blip2Native(nn.Module):
             return
         self.patch_w_gemm.zero_()
         self.patch_w_gemm[:, :self.patch_kreal] = pw.reshape(pw.shape[0], -1).to(self.wdtype)
-        self.embed_T = emb.t().contiguous()
+        if self.embed_T is None:
+            self.embed_T = emb.t().contiguous()
+        else:
+            self.embed_T.copy_(emb.t())      # in place: the path-level context (lib.PathContext) holds this buffer's address
         self._derived_version = (pw._version, emb._version)
 
     @classmethod
@@ -203,6 +206,31 @@ class Blip2Native(nn.Module):
             lib.cast_f32_bf16(master.data, shadow)
             ent[2] = master._version
         return shadow
+
+    @torch.no_grad()
+    def refresh_shadows(self):
+        """Bring the bf16 shadow of every fp32 master up to date (what weight_for_gemm does lazily per name)."""
+        for name in self._fp32_masters:
+            self.weight_for_gemm(name)
+
+    def weight_table(self):
+        """{name: device tensor} for lib.PathContext (include/devqa.h "PATH LEVEL"): every HF parameter under its own name (an
+        fp32 edit target additionally as "<name>#shadow" = the bf16 operand GEMMs read), plus the derived GEMM operands."""
+        self.refresh_derived()
+        t = OrderedDict()
+        for name, p in self.named_parameters():
+            if self._fused_slot(name) is not None:
+                continue          # row blocks of a fused operand: addressed through derived.dec_qkv.*
+            t[name] = p.data
+            ent = self._fp32_masters.get(name)
+            if ent is not None and self.wdtype != torch.float32:
+                t[name + "#shadow"] = ent[1]
+        for layer, w in self.fused_qkv_w.items():
+            t["derived.dec_qkv.%s.weight" % layer] = w
+            t["derived.dec_qkv.%s.bias" % layer] = self.fused_qkv_b[layer]
+        t["derived.patch_w_gemm"] = self.patch_w_gemm
+        t["derived.embed_T"] = self.embed_T
+        return t
 
     def mark_dirty(self, name):
         """Call after writing an fp32 master through a raw pointer (torch's version counter

@@ -9,6 +9,7 @@ Reference call sites replaced (R/ = /root/reference/DE-VQA/):
   tail_logits        <- last-layer fc2 + residual + final LN + lm_head on the label rows only
   ft_edit_batch      <- FTvl.execute_ft hot loop                         (R/editor/vllm_editors/ft_vl/ft_vl.py:111-146)
 """
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -63,6 +64,37 @@ class Blip2Engine:
         self.adt = model.wdtype
         self.want = "bf16" if self.adt == torch.bfloat16 else "f32"
 
+    # ---- path-level context (include/devqa.h "PATH LEVEL"): the schedules below live behind the C ABI ---------------------------
+    def path_ctx(self):
+        """lib.PathContext over this model's weight table, or None when the schedule must stay in Python: a subclass that
+        renames parameters (MiniGPT-4's vision part), editor hooks registered on the engine (MEND_VL module deltas, TP_VL extra
+        neurons), or DEVQA_PATH_ABI=0 (A/B tests of the two drivers of the same kernels)."""
+        if type(self) is not Blip2Engine or not hasattr(self.m, "weight_table") or os.environ.get("DEVQA_PATH_ABI", "1") == "0":
+            return None
+        masters = frozenset(self.m._fp32_masters)
+        if self.__dict__.get("_ctx") is None or self._ctx_masters != masters:      # an editor promoted a new edit target
+            v, q, t = self.v, self.q, self.t
+            d = lib.ModelDesc(family=lib.FAMILY_BLIP2_OPT, compute_dtype=lib.DTYPE_BF16 if self.adt == torch.bfloat16 else lib.DTYPE_F32,
+                              image_size=v["image_size"], patch_size=v["patch_size"], v_hidden=v["hidden_size"], v_layers=v["num_hidden_layers"],
+                              v_heads=v["num_attention_heads"], v_ffn=v["intermediate_size"], q_hidden=q["hidden_size"],
+                              q_layers=q["num_hidden_layers"], q_heads=q["num_attention_heads"], q_ffn=q["intermediate_size"],
+                              q_cross_freq=q["cross_attention_frequency"], num_query_tokens=self.Q, t_hidden=t["hidden_size"],
+                              t_layers=t["num_hidden_layers"], t_heads=t["num_attention_heads"], t_ffn=t["ffn_dim"], t_vocab=t["vocab_size"],
+                              t_max_pos=t["max_position_embeddings"], v_ln_eps=v["layer_norm_eps"], q_ln_eps=q["layer_norm_eps"],
+                              t_ln_eps=LN_EPS_OPT)
+            old = self.__dict__.get("_ctx")
+            if old is not None:
+                torch.cuda.current_stream(self.dev).synchronize()
+                old.close()
+            self._ctx = lib.PathContext(self.dev.index or 0, d, self.m.weight_table())
+            self._ctx_masters = masters
+        self.m.refresh_derived()
+        self.m.refresh_shadows()
+        return self._ctx
+
+    def _hooks_active(self):
+        return bool(getattr(self, "module_deltas", None)) or bool(getattr(self, "extra_neurons", None))
+
     def _act(self, x32):
         """fp32 rows -> GEMM operand dtype"""
         return lib.cast_f32_bf16(x32) if self.adt == torch.bfloat16 else x32
@@ -77,12 +109,15 @@ class Blip2Engine:
     def _p(self, name):
         return self.m.get(name)
 
-    def _full_desc(self, n_seq, q_len, kv_len):
+    def _full_desc(self, n_seq, q_len, kv_len, self_rows=False):
         """n_seq independent sequences: q rows [i*q_len, ...), keys [i*kv_len, ...), all visible."""
-        key = (n_seq, q_len, kv_len)
+        key = (n_seq, q_len, kv_len, self_rows)
         d = self._seq_desc_cache.get(key)
         if d is None:
-            rows = [[i * q_len, q_len, i * kv_len, kv_len, 0, 0] for i in range(n_seq)]
+            # self-attention: the keys are the sequence's OWN rows (fully visible without the causal bit) -- the form the self_full
+            # promise of devqa_attention describes; cross-attention: the keys are a visible range of another row set
+            rows = [[i * q_len, q_len, 0, 0, i * q_len, q_len] if (q_len == kv_len and self_rows) else [i * q_len, q_len, i * kv_len, kv_len, 0, 0]
+                    for i in range(n_seq)]
             d = torch.tensor(rows, dtype=torch.int32, device=self.dev)
             torch.cuda.current_stream(self.dev).synchronize()   # cached across streams (prefetch thread): publish it complete
             self._seq_desc_cache[key] = d
@@ -106,6 +141,9 @@ class Blip2Engine:
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def encode_images(self, pixels):
+        ctx = self.path_ctx()
+        if ctx is not None:
+            return ctx.vision_encode(pixels.contiguous())
         m, v, q = self.m, self.v, self.q
         m.refresh_derived()
         B = pixels.shape[0]
@@ -119,7 +157,7 @@ class Blip2Engine:
         patches = lib.gemm(cols, m.patch_w_gemm, self._p("vision_model.embeddings.patch_embedding.bias"), want="f32")
         x = lib.vit_assemble(patches, self._p("vision_model.embeddings.class_embedding"),
                              self._p("vision_model.embeddings.position_embedding"), B, G * G, D)
-        desc = self._full_desc(B, N, N)
+        desc = self._full_desc(B, N, N, self_rows=True)
         for i in range(v["num_hidden_layers"]):
             p = "vision_model.encoder.layers.%d." % i
             h = self._ln(x, p + "layer_norm1.weight", p + "layer_norm1.bias", eps)
@@ -142,7 +180,7 @@ class Blip2Engine:
         h32 = lib.layernorm(qt.contiguous(), self._p("qformer.layernorm.weight"), self._p("qformer.layernorm.bias"), qeps,
                             want="f32")
         h32 = h32.repeat(B, 1)  # [B*Q, dq] (plumbing: the learned queries are shared by every image)
-        self_desc = self._full_desc(B, Qn, Qn)
+        self_desc = self._full_desc(B, Qn, Qn, self_rows=True)
         cross_desc = self._full_desc(B, Qn, N)
         for i in range(q["num_hidden_layers"]):
             p = "qformer.encoder.layer.%d." % i
@@ -288,6 +326,10 @@ class Blip2Engine:
         x = ps.x
         n_seq = ps.desc.shape[0]
         last = t["num_hidden_layers"] - 1 if upto_layer is None else upto_layer
+        ctx = self.path_ctx() if (save is None and not return_h and not self._hooks_active()) else None
+        if ctx is not None:
+            a = ctx.llm_layers(x, ps.desc, n_seq, ps.max_len, ps.dense, last + 1, stop_before_fc2)
+            return x, a
         deltas = getattr(self, "module_deltas", None) or {}
         for i in range(last + 1):
             p = "language_model.model.decoder.layers.%d." % i
@@ -392,6 +434,9 @@ class Blip2Engine:
     # K8: final LN + tied lm_head on the given rows -> fp32 logits
     @torch.no_grad()
     def lm_head(self, x_rows, add=None):
+        ctx = self.path_ctx()
+        if ctx is not None:
+            return ctx.llm_head(x_rows, add)
         h = self._ln(x_rows, "language_model.model.decoder.final_layer_norm.weight",
                      "language_model.model.decoder.final_layer_norm.bias", LN_EPS_OPT, add=add)
         return lib.gemm(h, self._p("language_model.model.decoder.embed_tokens.weight"), want="f32")

@@ -94,11 +94,38 @@ def load():
     _sig(L.devqa_tp_neuron_bwd, [P, P, I, I, P, I, P, I, P, I, P, P, P, F, F, F, P, P, P, P, P, P])
     _sig(L.devqa_tp_gated_neuron_fwd, [P, I, I, P, P, P, I, P, P, I, P, P, P])
     _sig(L.devqa_tp_gated_neuron_bwd, [P, P, I, I, P, I, P, I, P, I, P, P, P, F, F, F, P, P, P, P, P, P])
+    # ---- path level (include/devqa.h "PATH LEVEL", csrc/path_ctx.hip) ----
+    U64 = ctypes.c_uint64
+    _sig(L.devqa_ctx_create, [I, P, P, I, P])
+    _sig(L.devqa_ctx_destroy, [U64])
+    _sig(L.devqa_ctx_set_weight, [U64, ctypes.c_char_p, P])
+    _sig(L.devqa_vision_encode_workspace, [U64, I], c_int64)
+    _sig(L.devqa_vision_encode, [U64, P, I, P, P, I64, P])
+    _sig(L.devqa_llm_layers_workspace, [U64, I, I], c_int64)
+    _sig(L.devqa_llm_layers, [U64, P, P, I, I, I, I, I, I, P, P, I64, P])
+    _sig(L.devqa_llm_head_workspace, [U64, I], c_int64)
+    _sig(L.devqa_llm_head, [U64, P, P, I, P, P, I64, P])
+    _sig(L.devqa_llm_forward_workspace, [U64, I, I], c_int64)
+    _sig(L.devqa_llm_forward, [U64, P, P, I, I, I, I, P, I, P, P, I64, P])
+    _sig(L.devqa_ft_edit_workspace, [U64, I, I, I], c_int64)
+    _sig(L.devqa_ft_edit, [U64, P, I64, P, P, P, P, I, I, I, P, P, P, P, P, P, I64, P])
+    _sig(L.devqa_ctx_bind_edit_target, [U64, ctypes.c_char_p, P])
+    _sig(L.devqa_apply_delta, [U64, P, P])
+    _sig(L.devqa_restore, [U64, P])
+    _sig(L.devqa_token_acc, [P, I64, I, I, P, P, P, P, P])
+    _sig(L.devqa_comm_unique_id, [P])
+    _sig(L.devqa_comm_create, [I, I, P, I, P])
+    _sig(L.devqa_comm_destroy, [U64])
+    _sig(L.devqa_gather_scores, [U64, P, I, P, P])
     _lib = L
     return L
 
 
-EXPORTS = ["devqa_profile", "devqa_profile_read", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
+EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "devqa_vision_encode_workspace", "devqa_vision_encode",
+           "devqa_llm_layers_workspace", "devqa_llm_layers", "devqa_llm_head_workspace", "devqa_llm_head", "devqa_llm_forward_workspace",
+           "devqa_llm_forward", "devqa_ft_edit_workspace", "devqa_ft_edit", "devqa_ctx_bind_edit_target", "devqa_apply_delta", "devqa_restore",
+           "devqa_token_acc", "devqa_comm_unique_id", "devqa_comm_create", "devqa_comm_destroy", "devqa_gather_scores",
+           "devqa_profile", "devqa_profile_read", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
            "devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
@@ -670,3 +697,190 @@ def swiglu_bwd(gu, da):
     fn = load().devqa_swiglu_bwd_bf16 if gu.dtype == torch.bfloat16 else load().devqa_swiglu_bwd_f32
     _chk(fn(_p(gu), _p(da), R, F2 // 2, _p(out), _stream()), "devqa_swiglu_bwd")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# path level: model context + the launch schedules behind the ABI (include/devqa.h "PATH LEVEL")
+# ---------------------------------------------------------------------------------------------
+DTYPE_BF16, DTYPE_F32, FAMILY_BLIP2_OPT, SCORE_COLS = 1, 2, 1, 16
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("family", "compute_dtype", "image_size", "patch_size", "v_hidden", "v_layers", "v_heads", "v_ffn",
+                                             "q_hidden", "q_layers", "q_heads", "q_ffn", "q_cross_freq", "num_query_tokens",
+                                             "t_hidden", "t_layers", "t_heads", "t_ffn", "t_vocab", "t_max_pos")] + \
+               [(n, ctypes.c_float) for n in ("v_ln_eps", "q_ln_eps", "t_ln_eps")]
+
+
+class WeightEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("ptr", c_void_p), ("dtype", ctypes.c_int32), ("ndim", ctypes.c_int32), ("shape", c_int64 * 4)]
+
+
+class FtCfg(ctypes.Structure):
+    _fields_ = [("num_steps", ctypes.c_int32), ("lr", c_float), ("weight_decay", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("loss_floor", c_float), ("clamp_eps", c_float)]
+
+
+def _ws(nbytes, device):
+    """256-byte aligned scratch of `nbytes` from torch's caching allocator -> (keep-alive tensor, pointer)"""
+    if nbytes < 0:
+        raise DevqaError("workspace query failed (bad context handle or dims)")
+    buf = torch.empty((nbytes + 256,), dtype=torch.uint8, device=device)
+    return buf, c_void_p(buf.data_ptr() + (-buf.data_ptr()) % 256)
+
+
+class PathContext:
+    """Owner of one devqa_ctx_t: the table of named device tensors stays referenced here for the context's lifetime."""
+
+    def __init__(self, device_index, desc: ModelDesc, weights: dict):
+        self._names = [n.encode() for n in weights]
+        self.weights = dict(weights)
+        arr = (WeightEntry * len(weights))()
+        for i, (n, t) in enumerate(weights.items()):
+            if not t.is_cuda or not t.is_contiguous():
+                raise DevqaError("weight %s must be a contiguous device tensor" % n)
+            dt = {torch.bfloat16: DTYPE_BF16, torch.float32: DTYPE_F32}.get(t.dtype)
+            if dt is None or t.dim() < 1 or t.dim() > 4:
+                raise DevqaError("weight %s: unsupported dtype / rank" % n)
+            arr[i].name, arr[i].ptr, arr[i].dtype, arr[i].ndim = self._names[i], t.data_ptr(), dt, t.dim()
+            for k in range(t.dim()):
+                arr[i].shape[k] = t.shape[k]
+        h = ctypes.c_uint64()
+        _chk(load().devqa_ctx_create(int(device_index), ctypes.byref(desc), arr, len(weights), ctypes.byref(h)), "devqa_ctx_create")
+        self.h = h.value
+        self.desc = desc
+        self.device = torch.device("cuda", int(device_index))
+        self.adt = torch.bfloat16 if desc.compute_dtype == DTYPE_BF16 else torch.float32
+
+    def set_weight(self, name, t):
+        self.weights[name] = t
+        _chk(load().devqa_ctx_set_weight(self.h, name.encode(), _p(t)), "devqa_ctx_set_weight")
+
+    def close(self):
+        if getattr(self, "h", None):
+            _chk(load().devqa_ctx_destroy(self.h), "devqa_ctx_destroy")
+            self.h = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and _lib is not None:
+                _lib.devqa_ctx_destroy(self.h)
+        except Exception:
+            pass
+
+    # ---- schedules ----
+    def vision_encode(self, pixels):
+        _need(pixels, torch.float32, "vision_encode pixels")
+        B, d = pixels.shape[0], self.desc
+        out = torch.empty((B, d.num_query_tokens, d.t_hidden), dtype=torch.float32, device=pixels.device)
+        n = load().devqa_vision_encode_workspace(self.h, B)
+        keep, ws = _ws(n, pixels.device)
+        _chk(load().devqa_vision_encode(self.h, _p(pixels), B, _p(out), ws, n, _stream()), "devqa_vision_encode")
+        return out
+
+    def llm_layers(self, x, seq_desc, n_seq, max_len, dense, n_layers=-1, stop_before_fc2=False):
+        """In place on x fp32 [R, d].  -> fc2 input [R, ffn] (compute dtype) when stop_before_fc2, else None"""
+        _need(x, torch.float32, "llm_layers x")
+        R = x.shape[0]
+        a = torch.empty((R, self.desc.t_ffn), dtype=self.adt, device=x.device) if stop_before_fc2 else None
+        n = load().devqa_llm_layers_workspace(self.h, R, int(stop_before_fc2))
+        keep, ws = _ws(n, x.device)
+        _chk(load().devqa_llm_layers(self.h, _p(x), _p(seq_desc), int(n_seq), int(max_len), R, int(bool(dense)), int(n_layers),
+                                     int(bool(stop_before_fc2)), _p(a), ws, n, _stream()), "devqa_llm_layers")
+        return a
+
+    def llm_head(self, rows, add=None):
+        _need(rows, torch.float32, "llm_head rows")
+        if add is not None:
+            _need(add, torch.float32, "llm_head add")
+            assert add.shape == rows.shape
+        R = rows.shape[0]
+        out = torch.empty((R, self.desc.t_vocab), dtype=torch.float32, device=rows.device)
+        n = load().devqa_llm_head_workspace(self.h, R)
+        keep, ws = _ws(n, rows.device)
+        _chk(load().devqa_llm_head(self.h, _p(rows), _p(add), R, _p(out), ws, n, _stream()), "devqa_llm_head")
+        return out
+
+    def llm_forward(self, x, seq_desc, n_seq, max_len, dense, want_rows):
+        _need(x, torch.float32, "llm_forward x")
+        assert want_rows.dtype == torch.int32 and want_rows.is_cuda
+        R, Rw = x.shape[0], want_rows.numel()
+        out = torch.empty((Rw, self.desc.t_vocab), dtype=torch.float32, device=x.device)
+        n = load().devqa_llm_forward_workspace(self.h, R, Rw)
+        keep, ws = _ws(n, x.device)
+        _chk(load().devqa_llm_forward(self.h, _p(x), _p(seq_desc), int(n_seq), int(max_len), R, int(bool(dense)), _p(want_rows), Rw, _p(out),
+                                      ws, n, _stream()), "devqa_llm_forward")
+        return out
+
+    def ft_edit(self, w0, a_rows, resid_rows, labels, mask, num_steps, lr, weight_decay, clamp_eps, beta1=0.9, beta2=0.999, eps=1e-8,
+                loss_floor=1e-2):
+        """-> (delta [E, d, npad], losses [E, num_steps], steps int32 [E], updates int32 [E]); see devqa_ft_edit"""
+        for t, nm in ((w0, "w0"), (a_rows, "a_rows"), (resid_rows, "resid_rows"), (mask, "mask")):
+            _need(t, torch.float32, "ft_edit " + nm)
+        assert labels.dtype == torch.int32 and labels.is_cuda
+        E, kmax, npad = a_rows.shape
+        d = self.desc.t_hidden
+        assert w0.shape in ((d, npad), (E, d, npad)) and tuple(resid_rows.shape) == (E * kmax, d) and tuple(mask.shape) == (E, kmax)
+        dev = a_rows.device
+        delta = torch.empty((E, d, npad), dtype=torch.float32, device=dev)
+        losses = torch.empty((E, num_steps), dtype=torch.float32, device=dev)
+        steps = torch.empty((E,), dtype=torch.int32, device=dev)
+        updates = torch.empty((E,), dtype=torch.int32, device=dev)
+        cfg = FtCfg(int(num_steps), float(lr), float(weight_decay), float(beta1), float(beta2), float(eps), float(loss_floor), float(clamp_eps))
+        n = load().devqa_ft_edit_workspace(self.h, E, kmax, npad)
+        keep, ws = _ws(n, dev)
+        _chk(load().devqa_ft_edit(self.h, _p(w0), d * npad if w0.dim() == 3 else 0, _p(a_rows), _p(resid_rows), _p(labels), _p(mask), E, kmax,
+                                  npad, ctypes.byref(cfg), _p(delta), _p(losses), _p(steps), _p(updates), ws, n, _stream()), "devqa_ft_edit")
+        return delta, losses, steps, updates
+
+    def bind_edit_target(self, name):
+        _chk(load().devqa_ctx_bind_edit_target(self.h, name.encode(), _stream()), "devqa_ctx_bind_edit_target")
+
+    def apply_delta(self, delta):
+        _need(delta, torch.float32, "apply_delta delta")
+        _chk(load().devqa_apply_delta(self.h, _p(delta), _stream()), "devqa_apply_delta")
+
+    def restore(self):
+        _chk(load().devqa_restore(self.h, _stream()), "devqa_restore")
+
+
+def token_acc(logits_rows, labels, mask):
+    """-> (acc fp32 [1], pred int32 [R]) on the device (devqa_token_acc)"""
+    assert logits_rows.dtype == torch.float32 and logits_rows.dim() == 2 and logits_rows.stride(1) == 1
+    R, V = logits_rows.shape
+    assert labels.dtype == torch.int32 and labels.numel() == R
+    _need(mask, torch.float32, "token_acc mask")
+    acc = torch.empty((1,), dtype=torch.float32, device=logits_rows.device)
+    pred = torch.empty((R,), dtype=torch.int32, device=logits_rows.device)
+    _chk(load().devqa_token_acc(_p(logits_rows), logits_rows.stride(0), R, V, _p(labels), _p(mask), _p(acc), _p(pred), _stream()),
+         "devqa_token_acc")
+    return acc, pred
+
+
+def comm_unique_id() -> bytes:
+    buf = ctypes.create_string_buffer(128)
+    _chk(load().devqa_comm_unique_id(buf), "devqa_comm_unique_id")
+    return buf.raw
+
+
+class ScoreComm:
+    """RCCL communicator behind the ABI for the single gather of score rows."""
+
+    def __init__(self, rank, world, uid: bytes, device_index):
+        h = ctypes.c_uint64()
+        _chk(load().devqa_comm_create(int(rank), int(world), ctypes.create_string_buffer(uid, 128), int(device_index), ctypes.byref(h)),
+             "devqa_comm_create")
+        self.h, self.rank, self.world = h.value, rank, world
+
+    def gather_scores(self, local):
+        """local fp32 [n, 16] (same n on every rank) -> fp32 [world * n, 16] on every rank"""
+        _need(local, torch.float32, "gather_scores local")
+        assert local.dim() == 2 and local.shape[1] == SCORE_COLS
+        out = torch.empty((self.world * local.shape[0], SCORE_COLS), dtype=torch.float32, device=local.device)
+        _chk(load().devqa_gather_scores(self.h, _p(local), local.shape[0], _p(out), _stream()), "devqa_gather_scores")
+        return out
+
+    def close(self):
+        if self.h:
+            _chk(load().devqa_comm_destroy(self.h), "devqa_comm_destroy")
+            self.h = None

@@ -34,7 +34,9 @@ extern "C" {
 #define DEVQA_OK 0
 #define DEVQA_E_ARG (-1)   /* null pointer / bad flag */
 #define DEVQA_E_SHAPE (-2) /* dimension outside what the kernel supports */
-#define DEVQA_E_HIP (-3)   /* launch failed */
+#define DEVQA_E_HIP (-3)   /* launch / runtime call failed */
+#define DEVQA_E_OOM (-4)   /* an allocation inside devqa_ctx_create / devqa_ctx_bind_edit_target / devqa_comm_create failed */
+#define DEVQA_E_STATE (-5) /* invalid handle, missing weight-table entry, call out of order */
 
 typedef uint16_t devqa_bf16;
 
@@ -348,6 +350,119 @@ int devqa_ft_step_control(const float* nll, const float* mask, int E, int Lmax, 
 int64_t devqa_cosine_topk_workspace(int N, int Q, int k);
 int devqa_cosine_topk(const float* corpus, const float* queries, int N, int Q, int D, int k, int normalize_corpus,
                       int normalize_queries, int64_t* out_idx, float* out_score, void* workspace, void* stream);
+
+/* =====================================================================================================================
+ * PATH LEVEL (csrc/path_ctx.hip): a model context and the launch schedules of the hot path over the kernels above -- the
+ * surface SURVEY.md 8(b) lists, so that a host in any language drives the edit-then-evaluate path without re-implementing
+ * the schedules.  The Python host (de-vqa_amd/engine.py, batched.py) calls exactly these for BLIP-2.
+ *
+ *   - a context is created once per (process, GPU) from the model dims and a TABLE of named device weights.  The table
+ *     stores POINTERS: the caller keeps ownership and may update weights in place (editors do).  Names are the HF parameter
+ *     names of SURVEY.md Appendix D (R/configs/ft_vl/blip2-opt-2.7b.yaml:8 addresses them), 2-D weights in the compute dtype
+ *     ([out, in], K-contiguous), 1-D parameters / ViT class + position embeddings / query_tokens fp32, plus the derived
+ *     GEMM operands:  "derived.patch_w_gemm" [v_hidden, Kpad] (conv weight flattened, K = 3 P^2 zero-padded to a multiple of
+ *     64), "derived.dec_qkv.<layer>.weight" [3d, d] + ".bias" fp32 [3d] (q, k, v projections of an OPT layer fused),
+ *     "derived.embed_T" [d, V] (transposed tied embedding, dH = dlogits . E).  An fp32 edit target "<name>" may come with its
+ *     compute-dtype shadow "<name>#shadow", which devqa_apply_delta / devqa_restore keep in step.
+ *   - calls on one context are serialised by the caller; every call takes the stream; scratch memory is a caller-provided,
+ *     256-byte aligned `workspace` of at least the bytes the matching *_workspace query returns (-1: bad handle / dims).
+ *     The context itself owns only the pristine copy of the bound edit target.
+ *   - status codes and devqa_last_error() as above; no call synchronises the device.
+ * ===================================================================================================================== */
+typedef uint64_t devqa_ctx_t;
+typedef uint64_t devqa_comm_t;
+#define DEVQA_FAMILY_BLIP2_OPT 1
+#define DEVQA_DTYPE_BF16 1
+#define DEVQA_DTYPE_F32 2
+#define DEVQA_SCORE_COLS 16   /* [sample_id, reliability, text_rephrase, image_rephrase, 9 locality accs, edit_time, steps, final_loss] */
+
+typedef struct devqa_model_desc {
+    int32_t family;        /* DEVQA_FAMILY_* */
+    int32_t compute_dtype; /* DEVQA_DTYPE_BF16 (bf16 operands, fp32 accumulate / residual stream) or DEVQA_DTYPE_F32 ("faithful") */
+    int32_t image_size, patch_size, v_hidden, v_layers, v_heads, v_ffn;             /* ViT (HF Blip2VisionConfig) */
+    int32_t q_hidden, q_layers, q_heads, q_ffn, q_cross_freq, num_query_tokens;     /* Q-Former */
+    int32_t t_hidden, t_layers, t_heads, t_ffn, t_vocab, t_max_pos;                 /* OPT decoder */
+    float v_ln_eps, q_ln_eps, t_ln_eps;
+} devqa_model_desc;
+
+typedef struct devqa_weight {
+    const char* name;   /* HF parameter name or "derived.*" */
+    const void* ptr;    /* device pointer, caller-owned */
+    int32_t dtype;      /* DEVQA_DTYPE_* */
+    int32_t ndim;
+    int64_t shape[4];
+} devqa_weight;
+
+int devqa_ctx_create(int device, const devqa_model_desc* desc, const devqa_weight* table, int n_weights, devqa_ctx_t* out);
+int devqa_ctx_destroy(devqa_ctx_t ctx);
+int devqa_ctx_set_weight(devqa_ctx_t ctx, const char* name, const void* ptr);   /* re-point one table entry */
+
+/* K2-K5 (R/editor/vllms_for_edit/blip2/blip2.py:25-45): pixel_values fp32 [B,3,S,S] -> projected query tokens fp32
+ * [B, num_query_tokens, t_hidden]: im2col + patch GEMM + CLS/positions, v_layers pre-LN ViT layers (fused QKV GEMM, MFMA
+ * attention, GELU FFN), post-LN, the Q-Former over the learned queries (self-attention, cross-attention to the image tokens
+ * every q_cross_freq layers, query FFN; BERT post-LN residuals), language projection. */
+int64_t devqa_vision_encode_workspace(devqa_ctx_t ctx, int B);
+int devqa_vision_encode(devqa_ctx_t ctx, const float* pixel_values, int B, float* out_embeds, void* workspace, int64_t ws_bytes,
+                        void* stream);
+
+/* K7 (blip2.py:68-75, HF OPTDecoder): `n_layers` decoder layers (-1 = all) IN PLACE on the packed fp32 rows x [R, t_hidden]
+ * (token / image-token embeddings + learned positions, devqa_embed_rows), sequences given by the attention descriptors of
+ * devqa_attention (causal own range + optional visible prefix).  dense != 0: every row is a query row of some sequence
+ * (otherwise the attention output is zero-filled first).  With stop_before_fc2 the LAST processed layer stops at its fc2 INPUT:
+ * x then holds the residual stream before that layer's FFN add and out_fc2_in [R, t_ffn] (compute dtype) = relu(fc1(LN(x))) --
+ * the frozen prefix of FT_VL (devqa_llm_prefix in SURVEY.md 8(b)): only fc2.weight of that layer changes during an edit. */
+int64_t devqa_llm_layers_workspace(devqa_ctx_t ctx, int R, int stop_before_fc2);
+int devqa_llm_layers(devqa_ctx_t ctx, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense, int n_layers,
+                     int stop_before_fc2, void* out_fc2_in, void* workspace, int64_t ws_bytes, void* stream);
+/* K8: logits fp32 [R, t_vocab] = lm_head(final LayerNorm(rows [+ add])), rows / add fp32 [R, t_hidden] (tied embedding, no bias) */
+int64_t devqa_llm_head_workspace(devqa_ctx_t ctx, int R);
+int devqa_llm_head(devqa_ctx_t ctx, const float* rows, const float* add, int R, float* out_logits, void* workspace, int64_t ws_bytes,
+                   void* stream);
+/* K7 + K8: all layers on x (in place), then logits of the rows listed in want_rows (int32 [R_want], device) */
+int64_t devqa_llm_forward_workspace(devqa_ctx_t ctx, int R, int R_want);
+int devqa_llm_forward(devqa_ctx_t ctx, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense,
+                      const int32_t* want_rows, int R_want, float* out_logits, void* workspace, int64_t ws_bytes, void* stream);
+
+/* K9-K13 (R/editor/vllm_editors/ft_vl/ft_vl.py:111-158): the FT_VL inner loop for E concurrent edits of the last decoder
+ * layer's fc2 matrix, control flow on the device (no host sync): per step  final LN + lm_head on the loss rows -> masked NLL +
+ * dlogits -> loop control (skip the update under loss_floor, stop after it) -> dH = dlogits . E -> LN backward -> fused
+ * rank-k gradient + AdamW + next fc2 rows (devqa_ft_adamw_step).
+ *   w0        : pristine matrix, shared [t_hidden, npad] (w0_stride_e = 0) or per edit [E, t_hidden, npad] (= t_hidden * npad) --
+ *               npad = t_ffn for the dense loop, or the padded count of ACTIVE columns (devqa_active_columns / devqa_gather_cols_*)
+ *   a_rows    : fp32 [E, kmax, npad] fc2 inputs of the loss rows (padding rows zero);  resid_rows fp32 [E*kmax, t_hidden] residual
+ *               (+ fc2 bias);  labels int32 [E*kmax];  mask fp32 [E, kmax] (1 = loss row)
+ *   out_delta : fp32 [E, t_hidden, npad] = W_e - w0 (0 for an edit that never updated);  out_losses fp32 [E, num_steps];
+ *               out_steps int32 [E] executed steps;  out_updates int32 [E] AdamW updates taken */
+typedef struct devqa_ft_cfg {
+    int32_t num_steps;
+    float lr, weight_decay, beta1, beta2, eps;
+    float loss_floor;   /* 1e-2 in the reference (ft_vl.py:131,145) */
+    float clamp_eps;    /* norm_constraint; < 0 disables */
+} devqa_ft_cfg;
+int64_t devqa_ft_edit_workspace(devqa_ctx_t ctx, int E, int kmax, int npad);
+int devqa_ft_edit(devqa_ctx_t ctx, const float* w0, int64_t w0_stride_e, const float* a_rows, const float* resid_rows,
+                  const int32_t* labels, const float* mask, int E, int kmax, int npad, const devqa_ft_cfg* cfg, float* out_delta,
+                  float* out_losses, int32_t* out_steps, int32_t* out_updates, void* workspace, int64_t ws_bytes, void* stream);
+
+/* K13 on a bound edit target (an fp32 master in the table): bind copies the pristine matrix into the context (the only device
+ * memory a context owns); apply_delta: w += delta (ft_vl.py:56-61); restore: w = pristine (ft_vl.py:44-45); both refresh the
+ * "<name>#shadow" entry when the table has one. */
+int devqa_ctx_bind_edit_target(devqa_ctx_t ctx, const char* name, void* stream);
+int devqa_apply_delta(devqa_ctx_t ctx, const float* delta, void* stream);
+int devqa_restore(devqa_ctx_t ctx, void* stream);
+
+/* K14 (R/evaluation/vllm_editor_eval.py:111,147-150): out_pred[r] = argmax logits_rows[r] (first max wins), out_acc[0] =
+ * sum((pred == labels) * mask) / sum(mask).  logits fp32 [R, V] row stride ldl; labels int32 [R]; mask fp32 [R]. */
+int devqa_token_acc(const float* logits_rows, int64_t ldl, int R, int V, const int32_t* labels, const float* mask, float* out_acc,
+                    int32_t* out_pred, void* stream);
+
+/* The single collective of a sharded run: every rank contributes n_rows x DEVQA_SCORE_COLS fp32 (blocks
+ * padded to the same n_rows), every rank receives world x n_rows x DEVQA_SCORE_COLS in rank order -- one RCCL all-gather
+ * over xGMI.  Rank 0 obtains the 128-byte id (devqa_comm_unique_id) and hands it to the other ranks by any host channel. */
+int devqa_comm_unique_id(void* id128);
+int devqa_comm_create(int rank, int world, const void* id128, int device, devqa_comm_t* out);
+int devqa_comm_destroy(devqa_comm_t comm);
+int devqa_gather_scores(devqa_comm_t comm, const float* local, int n_rows, float* out, void* stream);
 
 #ifdef __cplusplus
 }
