@@ -44,11 +44,26 @@ __device__ __forceinline__ void am_swap16(float x, float& a, float& b) {
 __device__ __forceinline__ void am_swap32(float x, float& a, float& b) {
     asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "=&v"(a), "=&v"(b) : "v"(x));
 }
-// max of three without the v_max_f32 x, x canonicalisation clang puts in front of every fmaxf operand that comes out of an MFMA
-// (IEEE sNaN quieting): scores are finite or -inf here.
-__device__ __forceinline__ float am_max3(float a, float b, float c) {
+// max of the 16 scores a lane holds after the S^T MFMAs, as ONE asm block: 7 v_max3_f32 + 1 v_max_f32 without the v_max_f32 x, x
+// canonicalisation clang puts in front of every fmaxf operand that comes out of an MFMA (IEEE sNaN quieting; scores are finite or
+// -inf here).  The block opens with wait states: on gfx9 a VALU read of an MFMA result is a SOFTWARE-managed hazard, which the
+// compiler resolves for its own instructions but not for inline asm -- an unprotected v_max3 here read stale accumulators now and
+// then (run-to-run differences at rounding level, since softmax is invariant to its reference point; found by
+// tools/debug/att_determinism.py).  12 wait states cover the 4-pass v_mfma_f32_16x16x32_bf16.
+__device__ __forceinline__ float am_max16(const float4_t& a, const float4_t& b, const float4_t& c, const float4_t& d) {
     float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm volatile("s_nop 11\n\t"
+                 "v_max3_f32 %0, %1, %2, %3\n\t"
+                 "v_max3_f32 %0, %0, %4, %5\n\t"
+                 "v_max3_f32 %0, %0, %6, %7\n\t"
+                 "v_max3_f32 %0, %0, %8, %9\n\t"
+                 "v_max3_f32 %0, %0, %10, %11\n\t"
+                 "v_max3_f32 %0, %0, %12, %13\n\t"
+                 "v_max3_f32 %0, %0, %14, %15\n\t"
+                 "v_max_f32 %0, %0, %16"
+                 : "=&v"(r)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]),
+                   "v"(c[3]), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
     return r;
 }
 __device__ __forceinline__ float am_max4(float x) {
@@ -244,14 +259,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
             for (int b = 0; b < QB; ++b) {
             float mloc;
             if (FULLC) {
-                mloc = am_max3(st[b][0][0], st[b][0][1], st[b][0][2]);
-                mloc = am_max3(mloc, st[b][0][3], st[b][1][0]);
-                mloc = am_max3(mloc, st[b][1][1], st[b][1][2]);
-                mloc = am_max3(mloc, st[b][1][3], st[b][2][0]);
-                mloc = am_max3(mloc, st[b][2][1], st[b][2][2]);
-                mloc = am_max3(mloc, st[b][2][3], st[b][3][0]);
-                mloc = am_max3(mloc, st[b][3][1], st[b][3][2]);
-                mloc = fmaxf(mloc, st[b][3][3]);
+                mloc = am_max16(st[b][0], st[b][1], st[b][2], st[b][3]);
             } else {
                 // only the nt (wave-uniform) key tiles that hold a key are touched; the others keep st = 0, which IS their p
                 mloc = -INFINITY;
@@ -267,8 +275,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                             st[b][t][r] = ok ? st[b][t][r] : -INFINITY;
                         }
                     }
-                    mloc = am_max3(mloc, st[b][t][0], st[b][t][1]);
-                    mloc = am_max3(mloc, st[b][t][2], st[b][t][3]);
+                    mloc = fmaxf(fmaxf(mloc, fmaxf(st[b][t][0], st[b][t][1])), fmaxf(st[b][t][2], st[b][t][3]));   // compiler-scheduled
                 }
             }
             mloc = am_max4(mloc);

@@ -125,7 +125,7 @@ int layernorm(const Ctx& c, const float* x, const float* add, const std::string&
 
 int attention(const Ctx& c, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo,
               const int32_t* desc, int n_seq, int max_q, int H, int dh, int causal, hipStream_t st) {
-    const float scale = 1.0f / sqrtf((float)dh);
+    const float scale = (float)pow((double)dh, -0.5);   // dh ** -0.5 evaluated in double, then rounded: what the Python host passes
     if (c.bf16)
         return devqa_attention((const devqa_bf16*)q, ldq, (const devqa_bf16*)k, ldk, (const devqa_bf16*)v, ldv, (devqa_bf16*)out, ldo, desc,
                                n_seq, max_q, H, dh, scale, causal, st);
@@ -240,8 +240,9 @@ int64_t plan_vision(const Ctx& c, int B, Arena& a, VisionPlan& p) {
     p.o32 = (float*)a.take(RQ * dq * 4);
     p.hb = a.take(RQ * dq * e);
     p.qq = a.take(RQ * dq * e);
-    p.kk = a.take(R * dq * e);     // cross-attention keys / values come from the N image tokens
-    p.vv = a.take(R * dq * e);
+    const int64_t RK = R > RQ ? R : RQ;   // keys / values: the Q queries themselves (self-attention) or the N image tokens (cross)
+    p.kk = a.take(RK * dq * e);
+    p.vv = a.take(RK * dq * e);
     p.qatt = a.take(RQ * dq * e);
     p.qf = a.take(RQ * d.q_ffn * e);
     p.d_vit = (int32_t*)a.take((int64_t)B * 24);

@@ -362,3 +362,34 @@ def test_column_compaction(L):
     ref = torch.zeros(Dout, Din)
     ref[:, idx[0, :n0].cpu().long()] = w[:, idx[0, :n0].cpu().long()]
     np.testing.assert_array_equal(dense.cpu().numpy(), ref.numpy())
+
+
+def test_attention_is_deterministic_and_variants_agree(L):
+    """Multi-chunk causal sequences (> 64 keys: the K/V refill path) several times over, and the opt-in instantiations: bit-identical.
+    Guards the software-managed MFMA -> VALU read hazard of the inline-asm max chain (csrc/attention_mfma.hip, am_max16): without its
+    wait states the running max was read stale now and then -- results within tolerance but different from run to run."""
+    import os
+    torch.manual_seed(3)
+    lens = [104, 30, 70, 129, 64, 65, 257]
+    starts = np.cumsum([0] + lens[:-1]).tolist()
+    R = sum(lens)
+    for H, dh, causal in ((5, 8, 1), (32, 80, 1), (16, 88, 0)):
+        d = H * dh
+        qkv = torch.randn(R, 3 * d, device="cuda").to(torch.bfloat16)
+        desc = torch.tensor([[s, n, 0, 0, s, n] for s, n in zip(starts, lens)], dtype=torch.int32, device="cuda")
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+
+        def run():
+            out = torch.full((R, d), 7.0, device="cuda", dtype=torch.bfloat16)
+            L.attention(q, k, v, desc, len(lens), max(lens), H, dh, dh ** -0.5, causal, out=out)
+            torch.cuda.synchronize()
+            return out
+        base = run()
+        for _ in range(5):
+            assert torch.equal(run(), base)
+        for var in ("DEVQA_ATTENTION_DBUF", "DEVQA_ATTENTION_QB"):
+            os.environ[var] = "1" if var.endswith("DBUF") else "2"
+            try:
+                assert torch.equal(run(), base), var
+            finally:
+                del os.environ[var]
