@@ -2,8 +2,8 @@
 (R/editor/vllms_for_edit/base.py:22-233), host logic restated; losses run on the HIP kernels.
 
 Same public names, argument meaning and error behaviour (BaseException on invalid input).
-Not provided on the native path: get_mid_module_inpt/outpt and forward_from_mid_layer (they are
-torch-forward-hook utilities, base.py:138-185, unused by FT_VL) -- they raise NotImplementedError.
+get_mid_module_inpt/outpt and forward_from_mid_layer (torch-forward-hook utilities in the reference, base.py:138-185) are
+provided for decoder layers of the language model, the modules callers address with them; other paths raise NotImplementedError.
 """
 from abc import ABC, abstractmethod
 from typing import List, Optional
@@ -160,11 +160,56 @@ class BaseVLLMForEdit(ABC):
         self.device = device
         self.model.to(device)
 
-    def get_mid_module_inpt(self, *a, **k):
-        raise NotImplementedError("torch-hook utilities are not available on the native HIP path")
+    # base.py:138-185.  The reference implements these three with torch forward hooks (nethook.Trace / TraceDict) on `self.model`;
+    # here the arithmetic is in HIP, so they are provided for what callers address with them -- DECODER LAYERS of the language
+    # model (`llm_layer_tmp.format(i)`, e.g. "language_model.model.decoder.layers.{}"): the hidden states entering / leaving layer
+    # i, and a forward that starts at layer i from given hidden states.  Any other module path raises NotImplementedError.
+    def _mid_layer_index(self, module_path: str) -> int:
+        import re
+        from ...utils import find_module
+        m = re.match(r"^(.*\.layers)\.(\d+)$", module_path)
+        eng = getattr(self, "engine", None)
+        if m is None or eng is None or not hasattr(eng, "decoder_layers"):
+            raise NotImplementedError("native path: mid-module access is provided for decoder layers ('...layers.<i>'), got %r"
+                                      % module_path)
+        find_module(self.model, module_path)          # the path must exist in this model's module tree
+        n = self.engine.t["num_hidden_layers"]
+        i = int(m.group(2))
+        if not 0 <= i < n or not module_path.startswith(self._lm_param_prefix()):
+            raise NotImplementedError("native path: %r is not a decoder layer of the language model" % module_path)
+        return i
 
-    get_mid_module_outpt = get_mid_module_inpt
-    forward_from_mid_layer = get_mid_module_inpt
+    def _pack_for_mid(self, llm_inpt):
+        emb, msk = llm_inpt["inputs_embeds"], llm_inpt["attention_mask"]
+        return self.engine.pack_from_embeds(emb, msk), emb.shape[0], emb.shape[1]
+
+    @torch.no_grad()
+    def get_mid_module_inpt(self, input_embeds, vt_range, mid_module_path, get_first_if_tuple=True):
+        i = self._mid_layer_index(mid_module_path)
+        ps, B, T = self._pack_for_mid(input_embeds)
+        if i > 0:
+            self.engine.decoder_layers(ps, upto_layer=i - 1)
+        return ps.x.view(B, T, -1)
+
+    @torch.no_grad()
+    def get_mid_module_outpt(self, input_embeds, vt_range, mid_module_path, get_first_if_tuple=True):
+        i = self._mid_layer_index(mid_module_path)
+        ps, B, T = self._pack_for_mid(input_embeds)
+        self.engine.decoder_layers(ps, upto_layer=i)
+        return ps.x.view(B, T, -1)
+
+    @torch.no_grad()
+    def forward_from_mid_layer(self, llm_inpt, vt_range, mid_layer_inpt: torch.Tensor, llm_layer_tmp: str, mid_inpt_layer_i: int):
+        """Inference from the LLM's layer `mid_inpt_layer_i` on, fed with `mid_layer_inpt` (same shape as that layer's input for
+        `llm_inpt`); layers before it are skipped.  -> object with .logits [B, T, V]"""
+        from types import SimpleNamespace
+        i = self._mid_layer_index(llm_layer_tmp.format(mid_inpt_layer_i))
+        ps, B, T = self._pack_for_mid(llm_inpt)
+        if tuple(mid_layer_inpt.shape[:2]) != (B, T):
+            raise BaseException("`mid_layer_inpt` must have the shape of the layer input of `llm_inpt`.")
+        ps.x = mid_layer_inpt.reshape(B * T, -1).to(torch.float32).contiguous().clone()
+        x, _ = self.engine.decoder_layers(ps, first_layer=i)
+        return SimpleNamespace(logits=self.engine.lm_head(x).view(B, T, -1))
 
     # base.py:187-196 incl. the dim=1 normalisation quirk (SURVEY Appendix A #15); tiny, host-side torch
     def find_closest_tokens(self, embeddings, embedding_matrix, top_k=1):

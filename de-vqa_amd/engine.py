@@ -316,7 +316,7 @@ class Blip2Engine:
     # stop_before_fc2, the last processed layer stops at the fc2 input: returns (x_mid, a_bf16).
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def decoder_layers(self, ps: PackedSeqs, upto_layer=None, stop_before_fc2=False, save=None, return_h=False):
+    def decoder_layers(self, ps: PackedSeqs, upto_layer=None, stop_before_fc2=False, save=None, return_h=False, first_layer=0):
         """save: None, or {"layers": set of layer ids}; filled with save[i] = activations the backward of layer i needs
         (decoder_backward).  Low-rank module deltas registered in self.module_deltas (MEND_VL's forward_edit_hook,
         mend_vl.py:73-80) are applied to the fc1 / fc2 outputs."""
@@ -326,12 +326,12 @@ class Blip2Engine:
         x = ps.x
         n_seq = ps.desc.shape[0]
         last = t["num_hidden_layers"] - 1 if upto_layer is None else upto_layer
-        ctx = self.path_ctx() if (save is None and not return_h and not self._hooks_active()) else None
+        ctx = self.path_ctx() if (save is None and not return_h and first_layer == 0 and not self._hooks_active()) else None
         if ctx is not None:
             a = ctx.llm_layers(x, ps.desc, n_seq, ps.max_len, ps.dense, last + 1, stop_before_fc2)
             return x, a
         deltas = getattr(self, "module_deltas", None) or {}
-        for i in range(last + 1):
+        for i in range(first_layer, last + 1):
             p = "language_model.model.decoder.layers.%d." % i
             rec = None
             if save is not None and i in save["layers"]:

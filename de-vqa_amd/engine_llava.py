@@ -188,7 +188,7 @@ class LlavaEngine:
 
     # ---- LLaMA decoder layers -----------------------------------------------------------------------------------
     @torch.no_grad()
-    def decoder_layers(self, ps, upto_layer=None, stop_before_fc2=False, save=None, return_h=False):
+    def decoder_layers(self, ps, upto_layer=None, stop_before_fc2=False, save=None, return_h=False, first_layer=0):
         """save: None, or {"layers": set of layer ids}: filled with the activations decoder_backward needs.  Low-rank module
         deltas (set_module_deltas; MEND_VL's forward_edit_hook, mend_vl.py:73-80) are applied to gate / up / down outputs."""
         t, m = self.t, self.m
@@ -198,7 +198,7 @@ class LlavaEngine:
         n_seq = ps.desc.shape[0]
         last = t["num_hidden_layers"] - 1 if upto_layer is None else upto_layer
         deltas = getattr(self, "module_deltas", None) or {}
-        for i in range(last + 1):
+        for i in range(first_layer, last + 1):
             p = self.lm + "model.layers.%d." % i
             rec = None
             if save is not None and i in save["layers"]:

@@ -109,7 +109,8 @@ def _ref_attention(q, k, v, desc, H, dh, scale, causal):
     return out
 
 
-@pytest.mark.parametrize("name", ["vit", "qformer_cross", "opt_causal", "opt_prefix", "tiny_heads"])
+@pytest.mark.parametrize("name", ["vit", "qformer_cross", "opt_causal", "opt_prefix", "tiny_heads", "clip_l_577", "llama_dh128",
+                                  "llama_prefix_576"])
 def test_attention(L, name):
     g = torch.Generator().manual_seed(11)
     if name == "vit":  # 2 images x 257 tokens, fused qkv buffer
@@ -138,6 +139,30 @@ def test_attention(L, name):
             st = np.cumsum([0] + T)
             desc = [(int(st[i]), T[i], 0, 0, int(st[i]), T[i]) for i in range(3)]
             causal, scale = 1, 1.0
+        elif name == "clip_l_577":   # CLIP ViT-L/14-336 of LLaVA-1.5: 576 patches + CLS, 16 heads x 64, own-range descriptors
+            H, dh, n = 16, 64, 577
+            q = bf(torch.randn(2 * n, H * dh, generator=g))
+            k = bf(torch.randn(2 * n, H * dh, generator=g))
+            v = bf(torch.randn(2 * n, H * dh, generator=g))
+            desc = [(0, n, 0, 0, 0, n), (n, n, 0, 0, n, n)]
+            causal, scale = 0, dh ** -0.5
+        elif name == "llama_dh128":  # Vicuna-7B heads (32 x 128), causal, ~600-token sequences (576 image tokens + text)
+            H, dh = 32, 128
+            T = [598, 46, 130]
+            tot = sum(T)
+            q = bf(torch.randn(tot, H * dh, generator=g))
+            k = bf(torch.randn(tot, H * dh, generator=g))
+            v = bf(torch.randn(tot, H * dh, generator=g))
+            st = np.cumsum([0] + T)
+            desc = [(int(st[i]), T[i], 0, 0, int(st[i]), T[i]) for i in range(3)]
+            causal, scale = 1, dh ** -0.5
+        elif name == "llama_prefix_576":  # a shared 576-row image prefix (9 chunks) + two texts attending to it, head dim 128
+            H, dh = 8, 128
+            q = bf(torch.randn(576 + 20 + 70, H * dh, generator=g))
+            k = bf(torch.randn(576 + 20 + 70, H * dh, generator=g))
+            v = bf(torch.randn(576 + 20 + 70, H * dh, generator=g))
+            desc = [(0, 576, 0, 0, 0, 576), (576, 20, 0, 576, 576, 20), (596, 70, 0, 576, 596, 70)]
+            causal, scale = 1, dh ** -0.5
         elif name == "opt_prefix":  # prefix seq (32 rows) + two text seqs attending to it
             H, dh = 32, 80
             q = bf(torch.randn(32 + 16 + 21, H * dh, generator=g))
