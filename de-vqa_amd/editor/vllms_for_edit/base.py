@@ -172,7 +172,10 @@ class BaseVLLMForEdit(ABC):
         if m is None or eng is None or not hasattr(eng, "decoder_layers"):
             raise NotImplementedError("native path: mid-module access is provided for decoder layers ('...layers.<i>'), got %r"
                                       % module_path)
-        find_module(self.model, module_path)          # the path must exist in this model's module tree
+        try:
+            find_module(self.model, module_path)      # the path must exist in this model's module tree
+        except Exception:
+            raise NotImplementedError("native path: %r is not a module of this model" % module_path)
         n = self.engine.t["num_hidden_layers"]
         i = int(m.group(2))
         if not 0 <= i < n or not module_path.startswith(self._lm_param_prefix()):
