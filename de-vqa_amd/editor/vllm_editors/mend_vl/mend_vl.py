@@ -16,8 +16,10 @@ explicit HIP (lm_head rows -> LayerNorm bwd -> per layer: GEMMs on cached transp
 bwd, attention bwd), never an autograd graph over the whole network.
 
 Trained hyper-network state comes from a reference-format `Best` checkpoint (R/editor/vllm_editors/base.py:237-252),
-read with torch.load(weights_only=True).  The training loop (train_init/train/train_a_batch) is not
-built; edited modules must be fc1/fc2 of decoder layers (what R/configs/mend_vl/blip2-opt-2.7b.yaml selects).
+read with torch.load(weights_only=True).  Training runs through the reference's ABC
+(`VLLMBaseEditorWithTraining.train_init` / `train`, editor/vllm_editors/base.py) with `train_a_batch` below; edited
+modules must be FFN projections of decoder layers (fc1/fc2 for OPT, gate/up/down_proj for LLaMA: what the shipped
+R/configs/mend_vl/*.yaml select).
 """
 import os
 import re

@@ -1,5 +1,5 @@
 """Factories and name maps: same functions/arguments as R/utils/__init__.py:29-175 for the
-editors and models built on the HIP path (ft_vl on blip2-opt-2.7b this round)."""
+editors (ft_vl, mend_vl, ike_vl, tp_vl, lte_vl) and models (blip2-opt-2.7b, llava-v1.5-7b, minigpt-4-vicuna-7b) built on the HIP path."""
 import os
 from typing import List, Union
 
