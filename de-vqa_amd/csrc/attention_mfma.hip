@@ -81,12 +81,17 @@ __device__ __forceinline__ float am_sum4(float x) {
     return a + b;
 }
 
+// NW = waves per workgroup (16 * NW * QB queries per tile).  NW = 4 (default): 64-query tiles.  NW = 6 (DHP = 96 only: the chunk image
+// must split evenly over the threads): 96-query tiles for sequences whose length leaves a short tail behind the last 64-query
+// tile -- ViT-g's 257 tokens are 16 full 16-query blocks + 1 query: 5 tiles x 4 waves stage every K / V chunk five times and park
+// 3 idle waves in the fifth workgroup; 3 tiles x 6 waves stage it three times with one idle wave (tools/debug/att_tail_cost.py:
+// T = 256 143 us, T = 257 173 us with NW = 4).
 // QB = query blocks (16 queries each) per wave.  QB = 1 (default): 64-query tiles, 3 workgroups per CU.  QB = 2 (experimental,
 // DEVQA_ATTENTION_QB=2): 128-query tiles -- every K / V fragment read from LDS feeds two MFMAs (half the LDS traffic per query) and
 // long sequences need fewer workgroups that each stream the whole K / V (ViT-g, 257 tokens: 3 instead of 5 per image and head);
 // measured slower, see launch_attention_mfma.
-template <int DHP, int QB, bool DBUF>
-__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+template <int DHP, int QB, bool DBUF, int NW = 4, int EXP = 0>
+__global__ __launch_bounds__(64 * NW, 2) void attention_mfma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                              const bf16_t* __restrict__ k, int64_t ldk,
                                                              const bf16_t* __restrict__ v, int64_t ldv,
                                                              bf16_t* __restrict__ out, int64_t ldo,
@@ -100,6 +105,8 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     constexpr int KS = DHP / 32;          // k-steps of the S^T product
     constexpr int DT = DHP / 16;          // 16-channel output tiles
     constexpr int BUF = AM_KC * STRIDE;   // one chunk image
+    constexpr int NT = 64 * NW;           // threads per workgroup
+    constexpr int QT = 16 * NW * QB;      // queries per workgroup
     // K and V chunks are DOUBLE-buffered: chunk i lives in buffer i & 1, so one barrier per chunk orders both hazards (chunk
     // i + 1 complete before it is read; chunk i - 1 fully consumed before its buffer is refilled) and the LDS writes of the next
     // chunk overlap the MFMAs of this one.  4 x 64 x 208 B = 52 KiB per workgroup at dh 88 / 80: still 3 workgroups per CU.
@@ -121,9 +128,9 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     const int s = bid / (q_tiles * H);
     const int32_t* d = seq_desc + s * 6;
     const int q_start = d[0], q_len = d[1], kp_start = d[2], kp_len = d[3], ko_start = d[4], ko_len = d[5];
-    const int q0 = qt * (AM_QT * QB);
+    const int q0 = qt * QT;
     if (q0 >= q_len) return;  // uniform per workgroup
-    const int nq = min(AM_QT * QB, q_len - q0);
+    const int nq = min(QT, q_len - q0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int causal_off = ko_len - q_len;  // query i sees own keys 0..i+causal_off
@@ -156,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     const float sc2 = scale * 1.44269504088896340736f;
 
     constexpr int CH = DHP / 8;  // 16-byte chunks per row
-    constexpr int LD = AM_KC * CH / 256;  // 16-byte pieces of K (and of V) per thread and chunk
-    static_assert(AM_KC * CH % 256 == 0, "chunk must split evenly over the workgroup");
+    constexpr int LD = AM_KC * CH / NT;  // 16-byte pieces of K (and of V) per thread and chunk
+    static_assert(AM_KC * CH % NT == 0, "chunk must split evenly over the workgroup");
     typedef unsigned am_u32x4_t __attribute__((ext_vector_type(4)));   // (a struct uint4 copied straight from global memory is not
     am_u32x4_t kreg[LD], vreg[LD];                                     //  promoted out of scratch by this compiler)
     // loop-invariant part of this thread's LD staging pieces: LDS offset, channel base pointers, row inside the chunk.  The loads are
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     int st_off[LD], st_row[LD], st_col[LD];
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
-        const int i = tid + j * 256;
+        const int i = tid + j * NT;
         const int r = i / CH, cv = i - r * CH;
         st_row[j] = r;
         st_off[j] = r * STRIDE + cv * 16;
@@ -217,16 +224,16 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     }
     int bi = 0;
     for (int c0 = 0; c0 < n_keys; c0 += AM_KC, bi ^= (DBUF ? 1 : 0)) {
-        __syncthreads();  // DBUF: chunk c0 complete in buffer bi, all waves done with buffer bi ^ 1; else: previous chunk consumed
+        if (EXP != 3) __syncthreads();  // DBUF: chunk c0 complete in buffer bi, all waves done with buffer bi ^ 1; else: previous chunk consumed
         if (DBUF) {
             if (c0 + AM_KC < n_keys) {  // the next chunk sits in registers: park it in the other buffer, then fetch the one after
                 AM_PARK(bi ^ 1)
                 if (c0 + 2 * AM_KC < n_keys) { AM_FETCH_ANY(c0 + 2 * AM_KC) }
             }
         } else if (c0 > 0) {            // chunk 0 was parked by the prologue
-            AM_PARK(0)
-            __syncthreads();
-            if (c0 + AM_KC < n_keys) { AM_FETCH_ANY(c0 + AM_KC) }  // next chunk's loads fly under this chunk's MFMAs
+            if (EXP != 4) { AM_PARK(0) }
+            if (EXP != 3) __syncthreads();
+            if (EXP != 1 && c0 + AM_KC < n_keys) { AM_FETCH_ANY(c0 + AM_KC) }  // next chunk's loads fly under this chunk's MFMAs
         }
         if (!wave_has_rows) continue;
         const unsigned char* Ks = Ks2 + bi * BUF;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                     if (!FULLC && t >= nt) continue;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(st[b][t][r], sc2, -mc));   // masked (-inf) -> 0
+                        const float p = EXP == 2 ? fmaf(st[b][t][r], sc2, -mc) : __builtin_amdgcn_exp2f(fmaf(st[b][t][r], sc2, -mc));   // masked (-inf) -> 0
                         st[b][t][r] = p;
                         lloc += p;
                     }
@@ -368,6 +375,240 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                 u.y = am_pack2(o[b][dt][2] * inv, o[b][dt][3] * inv);
                 *reinterpret_cast<uint2*>(orow + c) = u;
             }
+        }
+    }
+}
+
+// ---- LDS-DMA staged variant (the default) ----------------------------------------------------------------------------------------
+// Same tiling, operand orientation, softmax and results as attention_mfma_kernel<DHP, 1, false>, different K / V staging: the
+// timing-only variants of that kernel (DEVQA_ATTENTION_EXP, tools/debug/att_tail_cost.py) showed that on ViT-g neither the softmax
+// VALU work (no exp: +-0 %) nor the barriers (-3 %) bound it but the global -> register -> ds_write_b128 staging of every chunk
+// (-24 % without the loads, -39 % without loads and LDS stores).  Here every wave moves its share of the next chunk with
+// `global_load_lds_dwordx4` (no staging VGPRs, no LDS store instructions; 64 lanes x 16 B land at consecutive LDS addresses), into the
+// other half of a double-buffered image, one barrier per chunk.  The DMA fixes the image layout to plain row-major pieces
+// (piece p of 16 bytes at byte 16 p, CH = DHP / 8 pieces per key row, no row padding), so bank conflicts are avoided by a
+// source-side permutation instead: LDS position (row R, piece c') holds global piece c' ^ x(R), with x(R) = (R >> 1) & 3 for 4 / 12
+// pieces per row, R & 7 for 8, 2R & 15 for 16 -- found by simulating the guide's bank rules for ds_read_b128 (K fragments, 4 x 16
+// lane groups) and ds_read_b64_tr_b16 (V fragments, 2 x 32): conflict-free for both images (tools/debug/lds_swizzle_search.py).
+typedef __attribute__((address_space(1))) const void* am_gptr_t;
+typedef __attribute__((address_space(3))) void* am_lptr_t;
+template <int CH>
+__device__ __forceinline__ int am_swz(int R) {
+    return CH == 8 ? (R & 7) : CH == 16 ? ((2 * R) & 15) : ((R >> 1) & 3);
+}
+
+template <int DHP, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 && DHP <= 96) ? 4 : 2) void attention_mfma_dma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+                                                                 const bf16_t* __restrict__ k, int64_t ldk,
+                                                                 const bf16_t* __restrict__ v, int64_t ldv,
+                                                                 bf16_t* __restrict__ out, int64_t ldo,
+                                                                 const int32_t* __restrict__ seq_desc, int H, int dh,
+                                                                 float scale, int causal, int q_tiles) {
+    constexpr int ROWB = 2 * DHP;          // bytes per key row in LDS (unpadded)
+    constexpr int KS = DHP / 32;
+    constexpr int DT = DHP / 16;
+    constexpr int CH = DHP / 8;            // 16-byte pieces per row
+    constexpr int IMG = AM_KC * ROWB;      // one chunk image
+    constexpr int NI = AM_KC * CH / 64;    // DMA instructions (64 lanes x 16 B) per image and chunk
+    constexpr int LD = 2 * NI / NW;        // ... per wave and chunk, K and V images together: instruction j * NW + wave of the list K | V
+    constexpr int QT = 16 * NW;            // queries per workgroup
+    static_assert(2 * NI % NW == 0, "chunk must split evenly over the waves");
+    __shared__ __attribute__((aligned(1024))) unsigned char Ks2[2 * IMG];
+    __shared__ __attribute__((aligned(1024))) unsigned char Vs2[2 * IMG];
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int qt = bid % q_tiles;
+    const int h = (bid / q_tiles) % H;
+    const int s = bid / (q_tiles * H);
+    const int32_t* d = seq_desc + s * 6;
+    const int q_start = d[0], q_len = d[1], kp_start = d[2], kp_len = d[3], ko_start = d[4], ko_len = d[5];
+    const int q0 = qt * QT;
+    if (q0 >= q_len) return;  // uniform per workgroup
+    const int nq = min(QT, q_len - q0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int causal_off = ko_len - q_len;
+    const int own_hi = causal ? max(0, min(ko_len, q0 + nq + causal_off)) : ko_len;
+    const int n_keys = kp_len + own_hi;
+
+    const int qrow = q0 + wave * 16 + fr;
+    short8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = ks * 32 + fq * 8;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (qrow < q_len && c < dh) u = *reinterpret_cast<const uint4*>(q + (int64_t)(q_start + qrow) * ldq + h * dh + c);
+        qf[ks] = *reinterpret_cast<short8_t*>(&u);
+    }
+    float4_t o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = scale * 1.44269504088896340736f;
+    // ---- staging: DMA instruction j of this wave fills LDS bytes [(j * 4 + wave) * 1024, + 1024) of an image ----
+    int st_row[LD], st_col[LD];
+    uint32_t f_off[LD];
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+        const int blk = (j * NW + wave) % NI;                 // 1-KiB block of its image (wave-uniform, as is the image)
+        const bool is_v = (j * NW + wave) >= NI;
+        const int p = blk * 64 + lane;
+        const int R = p / CH, cp = p - R * CH;
+        const int c = cp ^ am_swz<CH>(R);
+        st_row[j] = R;
+        st_col[j] = h * dh + min(c * 8, dh - 8);     // channel padding re-reads the last real channels (see the kernel above)
+        f_off[j] = (uint32_t)(R * (int)(is_v ? ldv : ldk) + st_col[j]);
+    }
+    const bool one_range = kp_len == 0 || own_hi == 0;
+    const bool fast_rows = one_range && (int64_t)(AM_KC - 1) * max(ldk, ldv) + h * dh + DHP < (1ll << 31);
+    const bf16_t* const k_own = k + (int64_t)(kp_len == 0 ? ko_start : kp_start) * ldk;
+    const bf16_t* const v_own = v + (int64_t)(kp_len == 0 ? ko_start : kp_start) * ldv;
+#define AMD_STAGE(C0, BUFI)                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < LD; ++j) {                                                                        \
+        const int blk = (j * NW + wave) % NI;                                                                               \
+        const bool is_v = (j * NW + wave) >= NI;                                                                            \
+        if (blk * 64 / CH >= ((n_keys - (C0) + 31) & ~31)) continue;   /* a last, partial chunk: only the 32-key k-steps of P.V that hold a key (their rows must be finite: p = 0 multiplies them) */ \
+        unsigned char* dst = (is_v ? Vs2 : Ks2) + (BUFI) * IMG + blk * 1024;                                                \
+        const int64_t ld = is_v ? ldv : ldk;                                                                                \
+        if (fast_rows && (C0) + AM_KC <= n_keys) {                                                                          \
+            const bf16_t* gb = (is_v ? v_own : k_own) + (int64_t)(C0) * ld;                                                 \
+            __builtin_amdgcn_global_load_lds((am_gptr_t)(gb + f_off[j]), (am_lptr_t)dst, 16, 0, 0);                         \
+        } else {                                                                                                            \
+            const int kidx = min((C0) + st_row[j], n_keys - 1);                                                             \
+            const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);        \
+            __builtin_amdgcn_global_load_lds((am_gptr_t)((is_v ? v : k) + grow * ld + st_col[j]), (am_lptr_t)dst, 16, 0, 0); \
+        }                                                                                                                   \
+    }
+    // ---- fragment addresses inside an image (lane constants; tile / k-step offsets are immediates) ----
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = fr * ROWB + (((4 * ks + fq) ^ am_swz<CH>(fr)) * 16);
+    const int tq = fr >> 2, tp = fr & 3;
+    int voff[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+        voff[dt] = (4 * fq + tq) * ROWB + (((2 * dt + (tp >> 1)) ^ am_swz<CH>(4 * fq + tq)) * 16) + 8 * (tp & 1);
+
+    const bool wave_has_rows = q0 + wave * 16 < q_len;
+    if (n_keys > 0) { AMD_STAGE(0, 0) }
+    int bi = 0;
+    for (int c0 = 0; c0 < n_keys; c0 += AM_KC, bi ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk c0 have landed
+        __syncthreads();                                    // ... everybody's have, and buffer bi ^ 1 (chunk c0 - 64) is consumed
+        if (c0 + AM_KC < n_keys) { AMD_STAGE(c0 + AM_KC, bi ^ 1) }
+        if (!wave_has_rows) continue;
+        const unsigned char* Ks = Ks2 + bi * IMG;
+        const unsigned char* Vs = Vs2 + bi * IMG;
+        auto body = [&](auto full_tag) {
+            constexpr bool FULLC = decltype(full_tag)::value;
+            const int nt = FULLC ? 4 : min(4, (n_keys - c0 + 15) >> 4);
+            float4_t st[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                if (!FULLC && t >= nt) continue;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const short8_t kf = *reinterpret_cast<const short8_t*>(Ks + 16 * t * ROWB + koff[ks]);
+                    st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[t], 0, 0, 0);
+                }
+            }
+            const bool need_mask = !FULLC && ((c0 + AM_KC > n_keys) || (causal && c0 + AM_KC > kp_len));
+            float mloc;
+            if (FULLC) {
+                mloc = am_max16(st[0], st[1], st[2], st[3]);
+            } else {
+                mloc = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t >= nt) continue;
+                    if (need_mask) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int kidx = c0 + 16 * t + 4 * fq + r;
+                            bool ok = kidx < n_keys;
+                            if (causal && kidx >= kp_len) ok = ok && (kidx - kp_len) <= qrow + causal_off;
+                            st[t][r] = ok ? st[t][r] : -INFINITY;
+                        }
+                    }
+                    mloc = fmaxf(fmaxf(mloc, fmaxf(st[t][0], st[t][1])), fmaxf(st[t][2], st[t][3]));
+                }
+            }
+            mloc = am_max4(mloc);
+            float m_new = fmaxf(m_run, mloc);
+            const bool grow = (m_new - m_run) * sc2 > 8.f;
+            const bool rescale = __builtin_amdgcn_ballot_w64(grow) != 0;
+            if (!rescale) m_new = m_run;
+            float alpha = 1.f, lloc = 0.f;
+            if (FULLC || m_new != -INFINITY) {
+                const float mc = m_new * sc2;
+                if (rescale) alpha = __builtin_amdgcn_exp2f(m_run * sc2 - mc);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (!FULLC && t >= nt) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], sc2, -mc));
+                        st[t][r] = p;
+                        lloc += p;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            }
+            lloc = am_sum4(lloc);
+            l_run = l_run * alpha + lloc;
+            m_run = m_new;
+            short8_t pf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint4 u;
+                u.x = am_pack2(st[2 * s2][0], st[2 * s2][1]);
+                u.y = am_pack2(st[2 * s2][2], st[2 * s2][3]);
+                u.z = am_pack2(st[2 * s2 + 1][0], st[2 * s2 + 1][1]);
+                u.w = am_pack2(st[2 * s2 + 1][2], st[2 * s2 + 1][3]);
+                pf[s2] = *reinterpret_cast<short8_t*>(&u);
+            }
+            if (rescale) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (!FULLC && 2 * s2 >= nt) continue;
+                    const short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(Vs + 16 * (2 * s2) * ROWB + voff[dt]));
+                    const short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(Vs + 16 * (2 * s2 + 1) * ROWB + voff[dt]));
+                    const short8_t vf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], o[dt], 0, 0, 0);
+                }
+            }
+        };
+        const bool all_visible = !causal || c0 + AM_KC <= kp_len || (c0 + AM_KC - 1 - kp_len) <= q0 + causal_off;
+        if (c0 + AM_KC <= n_keys && all_visible) body(std::true_type{}); else body(std::false_type{});
+    }
+#undef AMD_STAGE
+    const int qi = q0 + wave * 16 + fr;
+    if (qi >= q_len) return;
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    bf16_t* orow = out + (int64_t)(q_start + qi) * ldo + h * dh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int c = 16 * dt + 4 * fq;
+        if (c < dh) {
+            uint2 u;
+            u.x = am_pack2(o[dt][0] * inv, o[dt][1] * inv);
+            u.y = am_pack2(o[dt][2] * inv, o[dt][3] * inv);
+            *reinterpret_cast<uint2*>(orow + c) = u;
         }
     }
 }
@@ -581,7 +822,26 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     const int qb = (qb_env && atoi(qb_env) == 2 && max_q_len > 2 * AM_QT && dhp <= 96) ? 2 : 1;
     const char* db_env = getenv("DEVQA_ATTENTION_DBUF");
     const bool dbuf = db_env && atoi(db_env) == 1 && qb == 1 && dhp <= 96;
-    const int q_tiles = (max_q_len + AM_QT * qb - 1) / (AM_QT * qb);
+    // 96-query tiles (6 waves) when they need fewer wave slots than 64-query tiles for the longest sequence (257 -> 18 vs 20)
+    const char* nw_env = getenv("DEVQA_ATTENTION_NW");
+    const int slots4 = (max_q_len + 63) / 64 * 4, slots6 = (max_q_len + 95) / 96 * 6;
+    int nw = 4;   // 6 waves measured 40 % SLOWER on ViT-g (6 waves over 4 SIMDs: two SIMDs carry twice the work): opt-in only
+    (void)slots4; (void)slots6;
+    if (nw_env && dhp == 96 && qb == 1 && !dbuf) nw = atoi(nw_env) == 6 ? 6 : 4;
+    const char* exp_env = getenv("DEVQA_ATTENTION_EXP");      // timing experiments (wrong results), tools/debug/att_tail_cost.py
+    const int exp_id = (exp_env && nw == 4 && qb == 1 && !dbuf) ? atoi(exp_env) : 0;
+    const char* dma_env = getenv("DEVQA_ATTENTION_DMA");      // 0: the register-staged kernel (previous default)
+    // default for long sequences only: on the decoder pack of the bench (960 sequences of 32-80 keys, visible prefix + causal own
+    // range, one or two chunks each) the DMA kernel measured 198 us against 135 us for the register-staged one (rocprofv3 trace of
+    // bench.py) -- nothing to overlap the DMA with; DEVQA_ATTENTION_DMA=1 forces it, =0 disables it
+    const bool dma = nw == 4 && qb == 1 && !dbuf && exp_id == 0 &&
+                     (dma_env ? atoi(dma_env) != 0 : max_q_len >= 224);
+    // 128-query tiles (8 waves) halve the K / V staging per query, which is what bounds the kernel on long sequences (ViT-g, T = 256:
+    // 133 -> 116 us); short sequences fill 64-query tiles better (T = 128: 43.6 vs 47.3 us)
+    int dma_nw = max_q_len >= 224 ? 8 : 4;
+    if (nw_env && (atoi(nw_env) == 8 || atoi(nw_env) == 4)) dma_nw = atoi(nw_env);
+    const int qt = dma ? 16 * dma_nw : 16 * nw * qb;
+    const int q_tiles = (max_q_len + qt - 1) / qt;
     const long grid = (long)n_seq * H * q_tiles;
     DEVQA_CHECK_SHAPE(grid < 2147483647L, "attention: grid too large");
     hipStream_t st = (hipStream_t)stream;
@@ -593,6 +853,21 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
         else if (dbuf)                                                                                                 \
             hipLaunchKernelGGL((attention_mfma_kernel<(D <= 96 ? D : 96), 1, true>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, \
                                k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                     \
+        else if (dma) {                                                                                                \
+            if (dma_nw == 8)                                                                                           \
+                hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 8>), dim3((unsigned)grid), dim3(512), 0, st, q, ldq, k, ldk, v, ldv, \
+                                   out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                 \
+            else                                                                                                       \
+                hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
+                                   out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                 \
+        } else if (exp_id >= 1 && exp_id <= 4 && D == 96) {                                                              \
+            if (exp_id == 1) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
+            if (exp_id == 2) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
+            if (exp_id == 3) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
+            if (exp_id == 4) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
+        } else if (nw == 6)                                                                                            \
+            hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 6>), dim3((unsigned)grid), dim3(384), 0, st, q, ldq, k, ldk, v, ldv, \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                     \
         else                                                                                                           \
             hipLaunchKernelGGL((attention_mfma_kernel<D, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
                                out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                     \

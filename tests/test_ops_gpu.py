@@ -182,6 +182,22 @@ def test_attention(L, name):
     d = torch.tensor(desc, dtype=torch.int32, device="cuda")
     out = L.attention(views[0], views[1], views[2], d, len(desc), max(x[1] for x in desc), H, dh, scale, causal)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=2e-2)
+    # both stagings of the chunked kernel on every case, whatever the launcher's default for the shape: register-staged (the default
+    # for short sequences) and LDS-DMA with 64- and 128-query tiles (the default for long ones) -- same arithmetic, bit-identical
+    import os
+    outs = {}
+    for var in ({"DEVQA_ATTENTION_DMA": "0"}, {"DEVQA_ATTENTION_DMA": "1", "DEVQA_ATTENTION_NW": "4"},
+                {"DEVQA_ATTENTION_DMA": "1", "DEVQA_ATTENTION_NW": "8"}):
+        os.environ.update(var)
+        try:
+            o = L.attention(views[0], views[1], views[2], d, len(desc), max(x[1] for x in desc), H, dh, scale, causal)
+        finally:
+            for k_ in var:
+                del os.environ[k_]
+        np.testing.assert_allclose(o.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=2e-2, err_msg=str(var))
+        outs[tuple(sorted(var.items()))] = o
+    vals = list(outs.values())
+    assert torch.equal(vals[0], vals[1]) and torch.equal(vals[0], vals[2]) and torch.equal(vals[0], out)
     if name == "vit":   # the opt-in K/V-resident kernel (self_full promise; enough (sequence, head) pairs to be selected: 8 x 16)
         qkv8 = bf(torch.randn(8 * n, 3 * H * dh, generator=g))
         d8 = [(i * n, n, 0, 0, i * n, n) for i in range(8)]
@@ -418,3 +434,10 @@ def test_attention_is_deterministic_and_variants_agree(L):
                 assert torch.equal(run(), base), var
             finally:
                 del os.environ[var]
+        for dma, nw in (("0", "4"), ("1", "4"), ("1", "8")):      # both stagings, both tile sizes of the LDS-DMA kernel
+            os.environ["DEVQA_ATTENTION_DMA"], os.environ["DEVQA_ATTENTION_NW"] = dma, nw
+            try:
+                for _ in range(3):
+                    assert torch.equal(run(), base), (dma, nw)
+            finally:
+                del os.environ["DEVQA_ATTENTION_DMA"], os.environ["DEVQA_ATTENTION_NW"]
