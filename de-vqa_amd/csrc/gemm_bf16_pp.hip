@@ -145,6 +145,29 @@ __device__ __forceinline__ float pp_act(float x) {
     return x;
 }
 
+// OPT-IN (variant 4, DEVQA_GEMM=24; the default keeps the erf form of pp_act): measured -4 % on the ViT fc1 GEMM (531 -> 505 us) = +0.5-0.8 % of
+// the bench; 1 % of the stored values move by one bf16 step, and that alone moved the real-dim bf16 loss parity from 8.9e-3 to 1.19e-2 of
+// north_star's 1e-2 (tests/test_realdim_batched_gpu.py) -- bf16 noise either way, but the bar is held on the erf form.
+// GELU for outputs that are STORED AS bf16 (fc1 of the ViT / Q-Former): x * Phi(x) with
+// Phi(x) = 0.5 + x Q(x^2) on |x| <= 4.2, Q a degree-8 minimax polynomial (weighted by x: |Phi error| <= 1.3e-5, |GELU error| <=
+// 8.6e-6 |x|: two orders of magnitude below the bf16 rounding of typical outputs, 4e-5 absolute in the negative tail), x clamped
+// beyond (Phi(4.2) = 1 - 1.3e-5).  No reciprocal, no exponential, and two values per instruction on v_pk_fma_f32 / v_pk_mul_f32:
+// ~6.5 VALU instructions per element instead of ~13 + 2 quarter-rate transcendentals.  Outputs kept in fp32 still take pp_act.
+typedef float pp_f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pp_f2_t pp_gelu2_bf16(pp_f2_t x) {
+    const pp_f2_t xc = {__builtin_amdgcn_fmed3f(x[0], -4.2f, 4.2f), __builtin_amdgcn_fmed3f(x[1], -4.2f, 4.2f)};
+    const pp_f2_t s = xc * xc;
+    pp_f2_t q = s * 5.997396590e-11f + -5.632817191e-09f;
+    q = q * s + 2.343521054e-07f;
+    q = q * s + -5.760521982e-06f;
+    q = q * s + 9.457214143e-05f;
+    q = q * s + -1.114136506e-03f;
+    q = q * s + 9.830100464e-03f;
+    q = q * s + -6.636033991e-02f;
+    q = q * s + 3.989074326e-01f;
+    return x * (xc * q + 0.5f);
+}
+
 typedef __bf16 pp_bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float pp_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pp_pack2(float a, float b) {   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
@@ -170,6 +193,7 @@ struct PPArgs {
     float* ws;
     int* counters;
     int bf16_fast;      // bf16-only output that qualifies for pp_epilogue_bf16
+    int gelu_poly;      // bf16-stored GELU on the packed polynomial (variant 4; default 0: the erf form)
 };
 
 // tile id -> (tile_m, tile_n): grouped order (group_m row-tiles of one column-tile, then the next column-tile), so the
@@ -347,8 +371,15 @@ __device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char*
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4_t a = acc[half * 4 + i][j];
-                const float v0 = pp_act<ACT>((a[0] + bj[j].x) * alpha), v1 = pp_act<ACT>((a[1] + bj[j].y) * alpha);
-                const float v2 = pp_act<ACT>((a[2] + bj[j].z) * alpha), v3 = pp_act<ACT>((a[3] + bj[j].w) * alpha);
+                float v0, v1, v2, v3;
+                if (ACT == DEVQA_ACT_GELU && g.gelu_poly) {
+                    const pp_f2_t lo = pp_gelu2_bf16((pp_f2_t){(a[0] + bj[j].x) * alpha, (a[1] + bj[j].y) * alpha});
+                    const pp_f2_t hi = pp_gelu2_bf16((pp_f2_t){(a[2] + bj[j].z) * alpha, (a[3] + bj[j].w) * alpha});
+                    v0 = lo[0]; v1 = lo[1]; v2 = hi[0]; v3 = hi[1];
+                } else {
+                    v0 = pp_act<ACT>((a[0] + bj[j].x) * alpha); v1 = pp_act<ACT>((a[1] + bj[j].y) * alpha);
+                    v2 = pp_act<ACT>((a[2] + bj[j].z) * alpha); v3 = pp_act<ACT>((a[3] + bj[j].w) * alpha);
+                }
                 uint2 p;
                 p.x = pp_pack2(v0, v1);
                 p.y = pp_pack2(v2, v3);
@@ -495,6 +526,7 @@ int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_
     g.bf16_fast = out_bf16 != nullptr && out_f32 == nullptr && residual == nullptr && N % 8 == 0 && ldc % 8 == 0 &&
                   (((uintptr_t)out_bf16) & 15) == 0 && (bias == nullptr || (((uintptr_t)bias) & 15) == 0);
     if (id == 6) g.bf16_fast = 0;       // A/B: the fp32 transposition for every output kind
+    g.gelu_poly = id == 4;              // variant 4 (DEVQA_GEMM=24): bf16-stored GELU on the packed polynomial
     switch (act) {
         case DEVQA_ACT_NONE: return launch_pp<DEVQA_ACT_NONE>(g, st);
         case DEVQA_ACT_RELU: return launch_pp<DEVQA_ACT_RELU>(g, st);
