@@ -8,11 +8,12 @@ sentence embedding of "{prompt} {target_new}" (:143-147); `get_llm_outpt` embeds
 `query_triple`, takes the cosine arg-max over the stored edits (:94-110) and, above `sim_threshold`, runs the decoder on
 prefix ++ probe and drops the prefix rows (:75-92).
 
-PARITY UNPINNED for this composition: the reference's module imports `sentence_transformers` at load (:1), which is not
-installed here, so the reference's own LTEvl could not be run to produce golden vectors, and its tests hold none.  What it
-composes IS pinned: `get_llm_input_embeds` / `get_llm_outpt` of the oracle models by the goldens captured from the
-reference wrappers (tests/test_oracle_golden.py, test_oracle_llava.py), the cosine arg-max by tests/test_ike_cpu.py.  The
-sentence encoder is an argument (`encode(list[str]) -> [n, d]`), as in the product.
+PINNED by the reference itself: tools/make_goldens_lte.py runs the reference's own `LTEvl` on the reference's BLIP-2 wrapper (the
+`sentence_transformers` import, absent here and irrelevant to the arithmetic, is replaced in-process by a stub whose `encode` is the
+bag-of-words function the tests pass as `encode`) and stores prefixes, retrieval pool and decisions, hook logits and results.json for
+edit_n = 1 and 2 in tests/golden/tiny_lte_goldens.*; tests/test_oracle_lte.py::test_lte_oracle_matches_reference_goldens holds this
+file to them (logits 1e-4, 48/48 evaluator entries).  LLaVA / MiniGPT-4 use the same class over their oracle models.  The sentence
+encoder is an argument (`encode(list[str]) -> [n, d]`), as in the product.
 """
 import torch
 import torch.nn.functional as F

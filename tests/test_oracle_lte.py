@@ -1,6 +1,7 @@
 """CPU: the LTE_VL oracle (oracle/lte_oracle.py) on the tiny BLIP-2 -- hook pass-through with an empty pool, prefix
 retrieval on both sides of the threshold, arg-max among several edits, prefix rows dropped, restore, and the oracle
-evaluator driving it.  The composition is PARITY UNPINNED (see the oracle's header); its parts are pinned elsewhere."""
+evaluator driving it; and the same composition against goldens captured from the REFERENCE's own LTEvl
+(tools/make_goldens_lte.py: prefixes, retrieval pool and decisions, hook logits, results.json for edit_n = 1 and 2)."""
 import json
 import os
 from copy import deepcopy
@@ -60,3 +61,57 @@ def test_lte_oracle(gold_dir, in_gold_dir):
     assert ns == [1, 1] and len(res) == 2 and 0.0 <= res[0][0]["reliability"][0]["acc"] <= 1.0
     ed.unhook()
     assert "get_llm_outpt" not in model.__dict__
+
+
+def _flat(results):
+    out = []
+    for split in results:
+        for d in split:
+            out += [(round(x["acc"], 4), x["predict_after_edit"]) for x in d["reliability"]]
+            out += [(round(x["acc"], 4), x["predict_after_edit"]) for g in d["generality"] for x in d["generality"][g]]
+            out += [(round(x["acc"], 4), x["predict_before_edit"] + "|" + x["predict_after_edit"]) for l in d["locality"] for x in d["locality"][l]]
+    return out
+
+
+def test_lte_oracle_matches_reference_goldens(gold_dir, in_gold_dir):
+    """The reference's LTEvl (sentence encoder stubbed by the same bag-of-words function) on the reference's BLIP-2 wrapper."""
+    from oracle import devqa_oracle as O
+    from oracle.lte_oracle import OracleLTEvl
+    j = json.load(open(os.path.join(gold_dir, "tiny_lte_goldens.json")))
+    z = np.load(os.path.join(gold_dir, "tiny_lte_goldens.npz"))
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))["records"]
+    model = _model(gold_dir)
+    ed = OracleLTEvl(model, bow_encode, j["sim_threshold"], DIM)
+    with torch.no_grad():
+        for r in j["inf_requests"]:
+            ed.edit_one_piece(deepcopy(r))
+        np.testing.assert_array_equal(ed.pool.numpy(), z["inf_pool"])
+        for i, pf in enumerate(ed.prefixes):
+            assert pf["attention_mask"].tolist() == z["inf_prefix_mask_%d" % i].tolist()
+            np.testing.assert_allclose(pf["inputs_embeds"].numpy(), z["inf_prefix_embeds_%d" % i], rtol=1e-4, atol=1e-5)
+        kinds = set()
+        for pr in j["inf_probes"]:
+            (x, vt), y, m = model.prompts_imgs_target_to_xym([pr["prompt"]], [pr["image"]], [pr["target"]])
+            x["query_triple"] = (pr["prompt"], pr["image"], pr["target"])
+            got = model.get_llm_outpt(x, vt).numpy()
+            req, pfx, sim = ed.retrieval([pr["prompt"]])
+            assert (None if req is None else [q["prompt"] for q in j["inf_requests"]].index(req["prompt"])) == pr["retrieved"]
+            np.testing.assert_allclose(sim.numpy(), np.asarray(pr["sim"]), atol=1e-6)
+            gold = z["inf_logits_" + pr["name"]]
+            assert list(got.shape) == pr["logits_shape"]
+            assert np.abs(got - gold).max() / np.abs(gold).max() < 1e-4, pr["name"]
+            kinds.add(pr["retrieved"] is None)
+        assert kinds == {True, False}                 # both sides of the threshold are in the fixture
+        ed.restore_to_original_model()
+        pr = j["inf_probes"][0]
+        (x, vt), y, m = model.prompts_imgs_target_to_xym([pr["prompt"]], [pr["image"]], [pr["target"]])
+        x["query_triple"] = (pr["prompt"], pr["image"], pr["target"])
+        gold = z["inf_logits_restored"]
+        assert np.abs(model.get_llm_outpt(x, vt).numpy() - gold).max() / np.abs(gold).max() < 1e-4
+    for sen in (1, 2):
+        res, _ = O.evaluate_sequential_edit(model, ed, rec[:4], sen)
+        want = j["eval"]["sen%d" % sen]
+        a, b = _flat(res), _flat(want)
+        assert len(a) == len(b) == 48
+        assert [x[1] for x in a] == [x[1] for x in b]
+        assert [x[0] for x in a] == [x[0] for x in b]
