@@ -218,6 +218,89 @@ extern "C" int devqa_layernorm_bwd_dx(const float* x, const float* add, const fl
 }
 
 // ------------------------------------------------------------------------------------------
+// LayerNorm backward w.r.t. its parameters (full fine-tuning: LTE_VL training, R/editor/vllm_editors/lte_vl/lte_vl.py:207-233 runs
+// autograd through every nn.LayerNorm of the language model):  dgamma[c] (+)= sum_r dy[r,c] * xhat[r,c],  dbeta[c] (+)= sum_r dy[r,c].
+// Two launches, both deterministic (no atomics): per-row (mean, rstd) by one wave per row into `stats` [M, 2]; then one thread per
+// column and quarter of the rows walks the rows in order (coalesced along the columns), the four partial sums combine in LDS in a
+// fixed order.  Also the column sums of a matrix (bias gradients) as the same second kernel without the xhat factor.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, const float* __restrict__ add, int M, int D, float eps,
+                                                        float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * D;
+    const float* ar = add ? add + (int64_t)row * D : nullptr;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c] + (ar ? ar[c] : 0.f);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float v = xr[c] + (ar ? ar[c] : 0.f) - mean;
+        q += v * v;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+template <bool LN>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                         const float* __restrict__ dy, const float* __restrict__ stats, int M, int D,
+                                                         int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float g = 0.f, b = 0.f;
+    if (c < D) {
+        for (int r = ry; r < M; r += 4) {
+            const float d = dy[(int64_t)r * D + c];
+            b += d;
+            if (LN) {
+                const float v = x[(int64_t)r * D + c] + (add ? add[(int64_t)r * D + c] : 0.f);
+                g += d * (v - stats[2 * r]) * stats[2 * r + 1];
+            }
+        }
+    }
+    red[0][ry][cx] = g;
+    red[1][ry][cx] = b;
+    __syncthreads();
+    if (ry == 0 && c < D) {
+        const float bs = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+        dbeta[c] = (accumulate ? dbeta[c] : 0.f) + bs;
+        if (LN) {
+            const float gs = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+            dgamma[c] = (accumulate ? dgamma[c] : 0.f) + gs;
+        }
+    }
+}
+
+extern "C" int devqa_layernorm_bwd_params(const float* x, const float* add, const float* dy, int M, int D, float eps, int accumulate,
+                                          float* dgamma, float* dbeta, float* stats_ws, void* stream) {
+    DEVQA_CHECK_ARG(x && dy && dgamma && dbeta && stats_ws, "layernorm_bwd_params: null pointer");
+    DEVQA_CHECK_SHAPE(M >= 0 && D > 0, "layernorm_bwd_params: M=%d D=%d", M, D);
+    if (M > 0) {
+        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, M, D, eps, stats_ws);
+        DEVQA_LAUNCH_CHECK("layernorm_bwd_params(stats)");
+    }
+    hipLaunchKernelGGL(col_reduce_kernel<true>, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, add, dy, stats_ws, M, D, accumulate,
+                       dgamma, dbeta);
+    DEVQA_LAUNCH_CHECK("layernorm_bwd_params");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_colsum_f32(const float* x, int M, int D, int accumulate, float* out, void* stream) {
+    DEVQA_CHECK_ARG(x && out, "colsum: null pointer");
+    DEVQA_CHECK_SHAPE(M >= 0 && D > 0, "colsum: M=%d D=%d", M, D);
+    hipLaunchKernelGGL(col_reduce_kernel<false>, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, x, nullptr, M, D,
+                       accumulate, nullptr, out);
+    DEVQA_LAUNCH_CHECK("colsum");
+    return DEVQA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // im2col for the patch-embedding conv: out[b*np + (py*G+px)][(c*P+ky)*P+kx] (bf16), zero pad
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void store_elem(bf16_t* p, float v) { *p = f32_to_bf16(v); }

@@ -15,10 +15,16 @@ Two things differ from the reference in HOW, not WHAT:
   * the sentence encoder (`multi-qa-mpnet-base-dot-v1` through sentence_transformers in the reference, :50; neither is
     available offline) is a constructor argument `encode(list[str]) -> [n, retrieval_embed_dim]`.
 
-Not built: LTE_VL *training* (:152-233) fine-tunes the whole language model with Adam on in-context edit prompts -- a full
-LLM training step, outside SURVEY.md 8's hot path; `train_a_batch` & co. raise NotImplementedError.  The shipped
-reference configs then evaluate with that fine-tuned LLM loaded as the editor checkpoint; here any LLM weights loaded in
-the wrapper are used as they are.
+Training (:152-233): the reference fine-tunes `fine_tune_modules_path` (the shipped configs: the whole
+`language_model`) with Adam at lr 5e-6 on in-context edit prompts -- per step one reliability and two generality label losses on
+prefix ++ probe, and for each of the nine locality probes the mean of two KL terms (plain probe, prefix ++ probe) against logits of a
+frozen copy of the model.  Here that step is ONE packed decoder pass over all 21 sequences with the layer activations saved, the
+row-wise loss kernels (`devqa_vocab_rows`, `devqa_kl_dlogits`), an explicit backward through every decoder layer that also
+accumulates the parameter gradients (`Blip2Engine.decoder_backward(grads=...)`: transposed-operand GEMMs for the weights,
+deterministic column reductions for biases and LayerNorm parameters), the tied embedding's gradient through the lm_head rows, the
+position table's through a one-hot GEMM, and `devqa_adam_step` on every parameter.  Checked against two steps of the reference's own
+loop body (tests/test_lte_gpu.py::test_lte_training_steps, tools/make_goldens_lte.py).  Needs the fp32 ("faithful") wrapper: at lr
+5e-6 an update is below the resolution of bf16 weights, and the reference trains in fp32.  OPT decoders (BLIP-2) only.
 """
 from dataclasses import dataclass
 from types import SimpleNamespace
@@ -29,7 +35,7 @@ import torch
 import yaml
 
 from ...base import BaseConfig
-from ..base import VLLMBaseEditor
+from ..base import VLLMBaseEditor, VLLMBaseEditorWithTraining
 from .... import lib
 
 
@@ -60,13 +66,29 @@ class LTEvlConfig(BaseConfig):
         raise
 
 
-class LTEvl(VLLMBaseEditor):
+class _AdamState(dict):
+    """{'t': step, 'm': {name: tensor}, 'v': {...}} with the two methods the training ABC's checkpoint code calls."""
+
+    def state_dict(self):
+        return {"t": self["t"], "m": dict(self["m"]), "v": dict(self["v"])}
+
+    def load_state_dict(self, sd):
+        self["t"] = int(sd["t"])
+        for k in ("m", "v"):
+            for n, t in sd[k].items():
+                self[k][n].copy_(t.to(self[k][n].device))
+
+
+class LTEvl(VLLMBaseEditorWithTraining):
     reads_query_hook = True     # get_llm_outpt consumes the evaluator's `query_triple`
 
     def __init__(self, vllm, config: LTEvlConfig, device="cuda", vllm_proc_data=None, device_proc_data=None,
                  encode: Callable[[Sequence[str]], np.ndarray] = None):
-        super().__init__(vllm, device)
+        super().__init__(vllm, config, device)
         self.cfg = config
+        if vllm_proc_data is not None:      # the frozen copy that prepares the training batches (lte_vl.py:44-48)
+            self.vllm_proc_data = vllm_proc_data
+            self.device_proc_data = device_proc_data
         if encode is None:
             raise RuntimeError("LTEvl needs `encode`: list[str] -> [n, %d] sentence embeddings (the reference uses "
                                "SentenceTransformer(%r))" % (config.retrieval_embed_dim, config.retriever_path))
@@ -153,13 +175,183 @@ class LTEvl(VLLMBaseEditor):
         t_embd = self._embed([request["prompt"] + " " + request["target_new"]])
         self.text_retr_pool = torch.cat([self.text_retr_pool, t_embd], 0).contiguous()
 
-    # ---- training (lte_vl.py:152-233): full-LLM fine-tuning, not on the hot path -----------------------------------
-    def set_train(self, is_train=False):
+    # ---- training (lte_vl.py:152-233) ------------------------------------------------------------------------------------
+    def set_train(self, is_train=False):  # :152-161 (requires_grad flags have no meaning here: gradients are explicit)
         if is_train:
-            raise NotImplementedError("LTE_VL training fine-tunes the whole language model; not built on the native path")
-        self.is_train = False
+            self._check_trainable()
+        self.is_train = bool(is_train)
 
-    def train_a_batch(self, *a, **k):
-        raise NotImplementedError("LTE_VL training fine-tunes the whole language model; not built on the native path")
+    def _check_trainable(self):
+        eng = self.vllm.engine
+        if type(eng).__name__ != "Blip2Engine":
+            raise NotImplementedError("LTE_VL training is built for OPT decoders (BLIP-2), not %s" % type(eng).__name__)
+        if eng.adt != torch.float32:
+            raise RuntimeError("LTE_VL training needs the fp32 wrapper (dtype='fp32'): at lr %g an Adam update is below the resolution "
+                               "of bf16 weights; the reference trains in fp32" % self.cfg.train_config.lr)
+        if self.cfg.fine_tune_modules_path != "language_model":
+            raise NotImplementedError("LTE_VL training fine-tunes `language_model` (what the shipped configs select), not %r"
+                                      % (self.cfg.fine_tune_modules_path,))
 
-    organize_batch_data = get_a_new_optimizer = preprocess_train_data = train_a_batch
+    def reinit_train_parameters(self):  # :163-164
+        pass
+
+    def preprocess_train_data(self, vllm_edit_data) -> List:  # :166-167
+        return vllm_edit_data.data_with_img
+
+    def organize_batch_data(self, a_batch_of_training_data: List):  # :169-187
+        d = a_batch_of_training_data[0]
+        pd = getattr(self, "vllm_proc_data", None) or self.vllm
+        edit_prefix = self.__get_edit_prefix__(pd, d["requests"][0])
+        rel_xym = pd.prompts_imgs_target_to_xym([d["requests"][0]["prompt"]], [d["requests"][0]["image"]], [d["requests"][0]["target_new"]])
+        gen_xym = {k: pd.prompts_imgs_target_to_xym([v[0]["prompt"]], [v[0]["image"]], [v[0]["target"]]) for k, v in d["generality"].items()}
+        loc_xym = {}
+        for k, v in d["locality"].items():      # the frozen copy's get_llm_outpt carries no retrieval hook (only self.vllm's is wrapped)
+            (input_embeds, vt_range), label_ids, label_masks = pd.prompts_imgs_target_to_xym([v[0]["prompt"]], [v[0]["image"]], [v[0]["target"]])
+            pre_logits = pd.get_llm_outpt(input_embeds, vt_range).logits
+            loc_xym[k] = ((input_embeds, vt_range), pre_logits, label_masks)
+        return edit_prefix, rel_xym, gen_xym, loc_xym
+
+    def get_modules_for_training(self) -> Dict[str, object]:  # :189-193
+        from ....utils import find_module
+        if isinstance(self.cfg.fine_tune_modules_path, str):
+            return {"llm": find_module(self.vllm.model, self.cfg.fine_tune_modules_path)}
+        return {n: find_module(self.vllm.model, n) for n in self.cfg.fine_tune_modules_path}
+
+    def _train_params(self):
+        """{full HF name: parameter} of the fine-tuned module, the q/k/v projections replaced by the fused operand they are row
+        blocks of (one Adam state per storage; elementwise the same update)."""
+        self._check_trainable()
+        m = self.vllm.model
+        out = {}
+        for n, p_ in m.language_model.named_parameters():
+            name = "language_model." + n
+            if m._fused_slot(name) is None:
+                out[name] = p_.data
+        for layer, w in m.fused_qkv_w.items():
+            out["derived.dec_qkv.%s.weight" % layer] = w
+            out["derived.dec_qkv.%s.bias" % layer] = m.fused_qkv_b[layer]
+        return out
+
+    def get_a_new_optimizer(self):  # :195-198: Adam(lr), torch defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay)
+        ps = self._train_params()
+        return _AdamState(t=0, m={n: torch.zeros_like(p_) for n, p_ in ps.items()}, v={n: torch.zeros_like(p_) for n, p_ in ps.items()})
+
+    def other_train_init_final(self):  # :200-201
+        self.restore_to_original_model()
+
+    @torch.no_grad()
+    def train_a_batch(self, a_batch_of_training_data):
+        """-> (loss, log_dict) with the reference's keys (:203-233)."""
+        self._check_trainable()
+        if getattr(self, "opt", None) is None:
+            self.opt = self.get_a_new_optimizer()
+        eng, dev, tc = self.vllm.engine, self.device, self.cfg.train_config
+        edit_prefix, rel_xym, gen_xym, loc_xym = a_batch_of_training_data
+        pe = edit_prefix["inputs_embeds"][0].to(dev, torch.float32)
+        assert int(edit_prefix["attention_mask"].sum()) == pe.shape[0]
+
+        def seq(x, with_prefix):
+            e, am = x["inputs_embeds"], x["attention_mask"]
+            assert e.shape[0] == 1 and int(am.sum()) == e.shape[1], "LTE_VL trains on one record at a time (lte_vl.py:170)"
+            e = e[0].to(dev, torch.float32)
+            return torch.cat([pe, e], 0) if with_prefix else e
+        # ---- the 21 sequences of a step: label-loss rows first, KL rows after (row layout of the loss kernels) ----
+        items, groups = [], []          # items: (embeds [T, d], L);  groups: (kind, name, lambda, mask [L], item indices, labels | pre_logits)
+        (x, _vt), y, m = rel_xym
+        groups.append(("rel", None, tc.relia_lambda, m[0], [len(items)], y[0]))
+        items.append((seq(x, True), y.shape[1]))
+        for k, ((x, _vt), y, m) in gen_xym.items():
+            groups.append(("gen", k, tc.gen_lambda, m[0], [len(items)], y[0]))
+            items.append((seq(x, True), y.shape[1]))
+        n_label_groups = len(groups)
+        for k, ((x, _vt), pre_logits, m) in loc_xym.items():
+            L = m.shape[1]
+            groups.append(("loc", k, tc.loc_lambda, m[0], [len(items), len(items) + 1], pre_logits[0, -L:].to(dev, torch.float32)))
+            items.append((seq(x, False), L))
+            items.append((seq(x, True), L))
+        tmax = (max(e.shape[0] for e, _ in items) + 3) // 4 * 4
+        B, d = len(items), pe.shape[1]
+        emb = torch.zeros((B, tmax, d), dtype=torch.float32, device=dev)
+        msk = torch.zeros((B, tmax), dtype=torch.int32, device=dev)
+        row0 = []                                             # first label row of every item in the packed buffer
+        for b, (e, L) in enumerate(items):
+            emb[b, :e.shape[0]] = e
+            msk[b, :e.shape[0]] = 1
+            row0.append(b * tmax + e.shape[0] - L)
+        ps = eng.pack_from_embeds(emb, msk, lens=[e.shape[0] for e, _ in items])
+        n_layers = eng.t["num_hidden_layers"]
+        save = {"layers": set(range(n_layers))}
+        x_fin, _ = eng.decoder_layers(ps, save=save)
+        rows, coef, coef_log, labels, pre_rows, spans = [], [], [], [], [], []
+        for gi, (kind, name, lam, mask, its, aux) in enumerate(groups):
+            mk = mask.to(torch.float32).cpu()
+            tot = float(mk.sum())
+            a = len(rows)
+            for it in its:
+                L = items[it][1]
+                rows += list(range(row0[it], row0[it] + L))
+                w = mk / tot / len(its)                        # label_loss / logit_KL_loss average over the mask; the two KL terms are averaged
+                coef_log.append(w)
+                coef.append(w * lam)
+                if kind == "loc":
+                    pre_rows.append(aux)
+                else:
+                    labels.append(aux.to(torch.int32).cpu())
+            spans.append((a, len(rows)))
+        ridx = torch.tensor(rows, dtype=torch.int32, device=dev)
+        coef_t = torch.cat(coef).to(dev).contiguous()
+        pre_ln = lib.gather_rows(x_fin, ridx)
+        hn = eng._ln(pre_ln, "language_model.model.decoder.final_layer_norm.weight", "language_model.model.decoder.final_layer_norm.bias", 1e-5)
+        emb_w = eng._p("language_model.model.decoder.embed_tokens.weight")
+        logits = lib.gemm(hn, emb_w, want="f32")
+        n_lab = spans[n_label_groups - 1][1]
+        _, nll, dlog = lib.vocab_rows(logits[:n_lab], torch.cat(labels).to(dev).contiguous(), coef_t[:n_lab].contiguous(), want_argmax=False,
+                                      want_nll=True, want_dlogits=True, dlogits_dtype=torch.float32)
+        row_loss = [nll]
+        if len(groups) > n_label_groups:
+            kl, dkl = lib.kl_dlogits(torch.cat(pre_rows, 0).contiguous(), logits[n_lab:], coef_t[n_lab:].contiguous(), torch.float32)
+            dlog = torch.cat([dlog, dkl], 0)
+            row_loss.append(kl)
+        per_row = (torch.cat(row_loss) * torch.cat(coef_log).to(dev)).cpu()      # unweighted, as the reference logs them
+        log = {"Reliability loss": 0.0, "Generality loss": {}, "Locality loss": {}}
+        loss = 0.0
+        for (kind, name, lam, _m, _its, _aux), (a, b) in zip(groups, spans):
+            v = float(per_row[a:b].sum())
+            loss += v * lam
+            if kind == "rel":
+                log["Reliability loss"] = v
+            else:
+                log["Generality loss" if kind == "gen" else "Locality loss"][name] = v
+        # ---- backward ----
+        st = self.opt
+        P = self._train_params()
+        G = st.get("_grads")
+        if G is None:
+            G = st["_grads"] = {n: torch.zeros_like(p_) for n, p_ in P.items()}
+        else:
+            for g in G.values():
+                g.zero_()
+        dlog = dlog.contiguous()
+        # tied embedding: the lm_head's weight gradient dlogits^T . LN(h) (the inputs arrive as embeddings from the frozen copy)
+        eng.acc_linear_grads(G, "language_model.model.decoder.embed_tokens.weight", None, hn, dlog)
+        dH = lib.gemm(dlog, self.vllm.model.embed_T, want="f32")
+        lib.layernorm_bwd_params(pre_ln, dH, 1e-5, G["language_model.model.decoder.final_layer_norm.weight"],
+                                 G["language_model.model.decoder.final_layer_norm.bias"])
+        dxr = eng.final_norm_bwd(pre_ln, dH)
+        dx = torch.zeros_like(x_fin)
+        dx.index_copy_(0, ridx.long(), dxr)
+        _, dx0 = eng.decoder_backward(ps, save, dx, set(), grads=G)
+        # learned positions (OPT: row position + 2): one-hot^T . dx as a GEMM, deterministic
+        pos = (torch.cumsum(msk, 1) * msk - 1).reshape(-1).long() + 2
+        n_pos = P["language_model.model.decoder.embed_positions.weight"].shape[0]
+        onehot = torch.zeros((dx0.shape[0], n_pos), dtype=torch.float32, device=dev)
+        onehot[torch.arange(dx0.shape[0], device=dev), pos.clamp_(0, n_pos - 1)] = msk.reshape(-1).to(torch.float32)
+        eng.acc_linear_grads(G, "language_model.model.decoder.embed_positions.weight", None, dx0, onehot)
+        # ---- Adam ----
+        st["t"] += 1
+        for n, p_ in P.items():
+            lib.adam_step_(p_.reshape(-1), G[n].reshape(-1), st["m"][n].reshape(-1), st["v"][n].reshape(-1), tc.lr, st["t"], None)
+        self.last_grads = G
+        eng.__dict__.pop("_wt_cache", None)                   # transposed operands of the backward are stale now
+        self.vllm.model.refresh_derived(force=True)           # embed_T
+        return loss, log

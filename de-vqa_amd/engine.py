@@ -389,12 +389,32 @@ class Blip2Engine:
             c[key] = getter().t().contiguous()
         return c[key]
 
+    @staticmethod
+    def _padk(t):
+        """[r, k] -> contiguous, zero-padded to k % 4 == 0 (K of the exact-fp32 GEMM)"""
+        pad = (-t.shape[1]) % 4
+        return t.contiguous() if pad == 0 else torch.cat([t, torch.zeros((t.shape[0], pad), dtype=t.dtype, device=t.device)], 1).contiguous()
+
     @torch.no_grad()
-    def decoder_backward(self, ps: PackedSeqs, save, dx, capture):
+    def acc_linear_grads(self, grads, wname, bname, x_rows, d_rows):
+        """grads[wname] += d_rows^T x_rows, grads[bname] += column sums of d_rows (fp32; the autograd of F.linear over the packed
+        rows): one TN GEMM on the transposed operands (K = number of rows) and one deterministic column reduction."""
+        x32 = x_rows.to(torch.float32)
+        d32 = d_rows.to(torch.float32).contiguous()
+        g = grads[wname]
+        lib.gemm(self._padk(d32.t()), self._padk(x32.t()), residual=g, out_f32=g)
+        if bname is not None:
+            lib.colsum_(d32, grads[bname], True)
+
+    @torch.no_grad()
+    def decoder_backward(self, ps: PackedSeqs, save, dx, capture, grads=None):
         """Backward through the saved decoder layers (highest first).  dx: fp32 [R, d] gradient w.r.t. the decoder
         output (input of the final LayerNorm).  Returns {module name: (input rows, output-gradient rows)} for the
         fc1 / fc2 modules named in `capture` -- what MEND_VL's forward/backward hooks record (mend_vl.py:62-71) --
-        and the gradient w.r.t. the input of the lowest saved layer."""
+        and the gradient w.r.t. the input of the lowest saved layer.
+        grads (full fine-tuning, LTE_VL training): {parameter name: fp32 accumulator}; every decoder-layer parameter found in it
+        receives its gradient -- fc1 / fc2 / out_proj weights and biases, the fused q|k|v operand under
+        "derived.dec_qkv.<i>.weight" / ".bias" (the HF q/k/v parameters are row blocks of it), both LayerNorms."""
         t = self.t
         d, H = t["hidden_size"], t["num_attention_heads"]
         dh = d // H
@@ -408,6 +428,8 @@ class Blip2Engine:
             dz = self._act(dx)
             if p + "fc2" in capture:
                 out[p + "fc2"] = (rec["a"], dx.clone())
+            if grads is not None:
+                self.acc_linear_grads(grads, p + "fc2.weight", p + "fc2.bias", rec["a"], dx)
             da = lib.gemm(dz, self._wt(p + "fc2", lambda: self._w(p + "fc2.weight")), want="f32")
             d2 = deltas.get(p + "fc2")
             if d2 is not None:   # the delta branch a @ dW also carries gradient to a
@@ -416,17 +438,30 @@ class Blip2Engine:
             if p + "fc1" in capture:
                 out[p + "fc1"] = (rec["h2"], dpre)
             dpre_op = self._act(dpre)
+            if grads is not None:
+                self.acc_linear_grads(grads, p + "fc1.weight", p + "fc1.bias", rec["h2"], dpre)
             dh2 = lib.gemm(dpre_op, self._wt(p + "fc1", lambda: self._w(p + "fc1.weight")), want="f32")
             d1 = deltas.get(p + "fc1")
             if d1 is not None:
                 lib.gemm(lib.gemm(dpre_op, d1["dt"]), d1["xtT"], residual=dh2, out_f32=dh2)
             dy = lib.layernorm_bwd_dx(rec["x_mid"], self._p(p + "final_layer_norm.weight"), dh2, LN_EPS_OPT)
+            if grads is not None:
+                lib.layernorm_bwd_params(rec["x_mid"], dh2, LN_EPS_OPT, grads[p + "final_layer_norm.weight"], grads[p + "final_layer_norm.bias"])
             lib.delta_op(1, dy, None, dx)      # dy += dx (residual branch)
+            if grads is not None:
+                self.acc_linear_grads(grads, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", rec["att"], dy)
             datt = lib.gemm(self._act(dy), self._wt(p + "out_proj", lambda: self._w(p + "self_attn.out_proj.weight")))
             qkv = rec["qkv"]
             dq, dk, dv = lib.attention_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], rec["att"], datt, ps.desc, n_seq,
                                            ps.max_len, H, dh, dh ** -0.5, 1)
-            dh1 = lib.gemm(torch.cat([dq, dk, dv], 1), self._wt(p + "qkv", lambda: self.m.fused_qkv_w[str(i)]), want="f32")
+            dqkv = torch.cat([dq, dk, dv], 1)
+            if grads is not None:
+                h1 = self._ln(rec["x_in"], p + "self_attn_layer_norm.weight", p + "self_attn_layer_norm.bias", LN_EPS_OPT)
+                self.acc_linear_grads(grads, "derived.dec_qkv.%d.weight" % i, "derived.dec_qkv.%d.bias" % i, h1, dqkv)
+            dh1 = lib.gemm(dqkv, self._wt(p + "qkv", lambda: self.m.fused_qkv_w[str(i)]), want="f32")
+            if grads is not None:
+                lib.layernorm_bwd_params(rec["x_in"], dh1, LN_EPS_OPT, grads[p + "self_attn_layer_norm.weight"],
+                                         grads[p + "self_attn_layer_norm.bias"])
             dx = lib.layernorm_bwd_dx(rec["x_in"], self._p(p + "self_attn_layer_norm.weight"), dh1, LN_EPS_OPT)
             lib.delta_op(1, dx, None, dy)
         return out, dx

@@ -66,6 +66,8 @@ def load():
     _sig(L.devqa_cast_f32_bf16, [P, P, I64, P])
     _sig(L.devqa_vocab_rows, [P, I64, I, I, P, P, P, P, P, I64, P])
     _sig(L.devqa_layernorm_bwd_dx, [P, P, P, P, I, I, F, P, P])
+    _sig(L.devqa_layernorm_bwd_params, [P, P, P, I, I, F, I, P, P, P, P])
+    _sig(L.devqa_colsum_f32, [P, I, I, I, P, P])
     _sig(L.devqa_ft_adamw_step, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I64, P])
     _sig(L.devqa_active_columns, [P, I, I, I, P, P, P])
     _sig(L.devqa_gather_cols_f32, [P, I64, I64, I, P, I64, P, I, I, P, P])
@@ -130,7 +132,7 @@ EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "dev
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
            "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
-           "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
+           "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_layernorm_bwd_params", "devqa_colsum_f32", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk", "devqa_attention_bwd",
            "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_mend_normalize_concat",
            "devqa_mend_lrlinear_epilogue", "devqa_logit_kl_rows", "devqa_kl_dlogits", "devqa_welford_rows",
@@ -369,6 +371,24 @@ def layernorm_bwd_dx(x, gamma, dy, eps, add=None):
     _chk(load().devqa_layernorm_bwd_dx(_p(x), _p(add), _p(gamma), _p(dy), M, D, float(eps), _p(dx), _stream()),
          "devqa_layernorm_bwd_dx")
     return dx
+
+
+def layernorm_bwd_params(x, dy, eps, dgamma, dbeta, add=None, accumulate=True):
+    """dgamma (+)= sum_r dy * xhat(x [+ add]), dbeta (+)= sum_r dy over the rows of fp32 [M, D] (in place)."""
+    M, D = x.shape
+    _need(x, torch.float32, "x"); _need(dy, torch.float32, "dy"); _need(dgamma, torch.float32, "dgamma"); _need(dbeta, torch.float32, "dbeta")
+    assert dy.shape == x.shape and dgamma.numel() == D and dbeta.numel() == D
+    ws = torch.empty((max(M, 1), 2), dtype=torch.float32, device=x.device)
+    _chk(load().devqa_layernorm_bwd_params(_p(x), _p(add), _p(dy), M, D, float(eps), int(bool(accumulate)), _p(dgamma), _p(dbeta), _p(ws),
+                                           _stream()), "devqa_layernorm_bwd_params")
+
+
+def colsum_(x, out, accumulate=True):
+    """out (+)= column sums of fp32 [M, D] (bias gradients)."""
+    M, D = x.shape
+    _need(x, torch.float32, "x"); _need(out, torch.float32, "out")
+    assert out.numel() == D
+    _chk(load().devqa_colsum_f32(_p(x), M, D, int(bool(accumulate)), _p(out), _stream()), "devqa_colsum_f32")
 
 
 def attention(q, k, v, seq_desc, n_seq, max_q_len, H, dh, scale, causal, out=None, self_full=False):

@@ -90,5 +90,11 @@ def load_vllm_editor(editor_name: str, edit_model_name: str, device, extra_devic
         return TPvl(vllm, TPvlConfig.from_yaml(config_path), device, **editor_kwargs)
     if editor_name == "lte_vl":  # needs encode=callable (the reference loads sentence_transformers' multi-qa-mpnet-base-dot-v1)
         from ..editor.vllm_editors.lte_vl.lte_vl import LTEvl, LTEvlConfig
-        return LTEvl(vllm, LTEvlConfig.from_yaml(config_path), device, **editor_kwargs)
+        # for_train (:159-162): a second, frozen copy of the model prepares the training batches (the reference puts it on
+        # extra_devices[0]; one MI355X holds both, so it lives on the same device); a trained checkpoint is loaded below
+        vllm_data_proc = load_vllm_for_edit(edit_model_name, device, dtype) if for_train else None
+        ed = LTEvl(vllm, LTEvlConfig.from_yaml(config_path), device, vllm_data_proc, device if for_train else None, **editor_kwargs)
+        if editor_ckpt_path is not None:      # :173-174
+            ed.load_ckpt(editor_ckpt_path, True, False)
+        return ed
     raise RuntimeError("No such editor %s" % editor_name)

@@ -276,6 +276,13 @@ int devqa_vocab_rows_f32(const float* logits, int64_t ldl, int R, int V, const i
 int devqa_layernorm_bwd_dx(const float* x, const float* add, const float* gamma, const float* dy, int M, int D, float eps,
                            float* dx, void* stream);
 
+/* LayerNorm backward w.r.t. gamma / beta over M rows (autograd through nn.LayerNorm in full fine-tuning: LTE_VL training,
+ * R/editor/vllm_editors/lte_vl/lte_vl.py:207-233): dgamma[c] (+)= sum_r dy[r,c] * xhat[r,c], dbeta[c] (+)= sum_r dy[r,c], xhat from
+ * x (+ add).  stats_ws: 2 * M floats of scratch.  Deterministic.  devqa_colsum_f32: out[c] (+)= sum_r x[r,c] (bias gradients). */
+int devqa_layernorm_bwd_params(const float* x, const float* add, const float* dy, int M, int D, float eps, int accumulate,
+                               float* dgamma, float* dbeta, float* stats_ws, void* stream);
+int devqa_colsum_f32(const float* x, int M, int D, int accumulate, float* out, void* stream);
+
 /* ---- K10/K11/K12: fused FT_VL inner step on the edited matrix ---------------------------------
  * One launch per optimiser step, batched over E concurrent edits that each own a private
  * fp32 copy of the edited matrix W_e [Dout,Din] and AdamW moments m_e, v_e:

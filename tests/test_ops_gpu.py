@@ -441,3 +441,31 @@ def test_attention_is_deterministic_and_variants_agree(L):
                     assert torch.equal(run(), base), (dma, nw)
             finally:
                 del os.environ["DEVQA_ATTENTION_DMA"], os.environ["DEVQA_ATTENTION_NW"]
+
+
+def test_layernorm_param_grads_and_colsum(L):
+    """dgamma / dbeta of LayerNorm over packed rows (+ accumulate) and column sums, vs float64 autograd; deterministic."""
+    g = torch.Generator().manual_seed(9)
+    for M, D in ((1, 40), (37, 40), (300, 2560), (129, 1408)):
+        x = torch.randn(M, D, generator=g) * 2 + 0.3
+        add = torch.randn(M, D, generator=g)
+        dy = torch.randn(M, D, generator=g)
+        xd = (x + add).double().requires_grad_(False)
+        gam = torch.ones(D, dtype=torch.float64, requires_grad=True)
+        bet = torch.zeros(D, dtype=torch.float64, requires_grad=True)
+        y = torch.nn.functional.layer_norm(xd, (D,), gam, bet, 1e-5)
+        (y * dy.double()).sum().backward()
+        dg = torch.full((D,), 0.5, device="cuda")
+        db = torch.full((D,), -0.25, device="cuda")
+        L.layernorm_bwd_params(dev(x), dev(dy), 1e-5, dg, db, add=dev(add), accumulate=True)
+        np.testing.assert_allclose(dg.cpu().numpy() - 0.5, gam.grad.float().numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
+        np.testing.assert_allclose(db.cpu().numpy() + 0.25, bet.grad.float().numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
+        dg2, db2 = torch.empty(D, device="cuda"), torch.empty(D, device="cuda")
+        L.layernorm_bwd_params(dev(x), dev(dy), 1e-5, dg2, db2, add=dev(add), accumulate=False)
+        dg3, db3 = torch.empty(D, device="cuda"), torch.empty(D, device="cuda")
+        L.layernorm_bwd_params(dev(x), dev(dy), 1e-5, dg3, db3, add=dev(add), accumulate=False)
+        assert torch.equal(dg2, dg3) and torch.equal(db2, db3)
+        cs = torch.zeros(D, device="cuda")
+        L.colsum_(dev(dy), cs, True)
+        L.colsum_(dev(dy), cs, True)
+        np.testing.assert_allclose(cs.cpu().numpy(), 2 * dy.double().sum(0).float().numpy(), rtol=1e-5, atol=1e-5 * M ** 0.5)
