@@ -44,9 +44,10 @@ DENSE_RECIPE = "SURVEY 8(d) recipe verbatim: every weight N(0, 0.02), LayerNorm 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cycles-per-step", type=int, default=60)
+    ap.add_argument("--cycles-per-step", type=int, default=127,
+                    help="cycles per batch; 127 -> 508 images = four ViT chunks of 127 images (32639 rows = 127.5 row tiles of 256: every GEMM round full)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--ffn", choices=["sparse", "dense", "both"], default="both")
     ap.add_argument("--dense-steps", type=int, default=0, help="steps of the dense leg under --ffn both (default max(2, steps // 5))")

@@ -11,6 +11,7 @@
 // edit; threads stride over Din in float4 units, so each wave-instruction touches 1 KiB of
 // contiguous HBM.  The a-rows (L x Din fp32, <= 320 KB) are re-read by every workgroup and stay
 // L2/MALL resident.  Per-row dot products are reduced with wavefront shuffles + one LDS hop.
+#include <stdlib.h>
 #include "common.h"
 
 // NARROW (column-compacted matrices, Din of a few hundred): every WAVE owns its own ROWS rows (the workgroup 4 x ROWS) and
@@ -137,10 +138,130 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
     }
 }
 
+// GROUPED (column-compacted matrices whose row is not a multiple of 64 float4: npad = 272 -> 68 float4 left the wave-per-row
+// form above a second pass with 4 of 64 lanes active, 53 % of the issued memory instructions doing work -- the 4.4 of 8 TB/s the
+// bench line reported): G lanes own a row (G = 16 or 8: 256- or 128-byte contiguous pieces per row and step), a wave 64 / G rows,
+// a workgroup 4 x 64 / G; ceil(nv / G) steps cover a row with at most G - 1 idle lane-steps (68 float4: 9 steps of 8, 94 %).
+// The per-row dot products for the next forward reduce inside the G-lane group.  Same per-element arithmetic as above.
+template <int L, int G>
+__global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __restrict__ w, float* __restrict__ m,
+                                                                    float* __restrict__ v, const float* __restrict__ w0,
+                                                                    const float* __restrict__ a, const float* __restrict__ dy,
+                                                                    float* __restrict__ y, const int32_t* __restrict__ do_update,
+                                                                    const int32_t* __restrict__ adam_t, int Lmax, int Dout, int Din,
+                                                                    float lr, float beta1, float beta2, float eps, float wd,
+                                                                    float clamp_eps, int row_blocks, int64_t w0_stride_e) {
+    constexpr int RW = 64 / G;      // rows per wave
+    const int e = blockIdx.x / row_blocks;
+    const int rb = blockIdx.x % row_blocks;
+    if (!do_update[e]) return;  // uniform
+    w0 += (int64_t)e * w0_stride_e;
+    const int t = adam_t[e];
+    const bool first = (t <= 1);
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)t));
+    const float bc2 = (float)(1.0 - pow((double)beta2, (double)t));
+    const float step_size = lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    const float decay = 1.f - lr * wd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % G;
+    const int i = (rb * 4 + wave) * RW + lane / G;        // this lane group's row
+    const bool row_ok = i < Dout;
+    const int ic = row_ok ? i : Dout - 1;                  // idle groups shadow the last row (loads only)
+    const int64_t mat = (int64_t)Dout * Din;
+    float* we = w + (int64_t)e * mat;
+    float* me = m + (int64_t)e * mat;
+    float* ve = v + (int64_t)e * mat;
+    const float* ae = a + (int64_t)e * Lmax * Din;
+    const float* dye = dy + (int64_t)e * Lmax * Dout;
+    float dyv[L], ysum[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        dyv[l] = (l < Lmax) ? dye[(int64_t)l * Dout + ic] : 0.f;
+        ysum[l] = 0.f;
+    }
+    const int nv = Din >> 2;
+#pragma unroll 2
+    for (int c = sub; c < nv; c += G) {
+        float4 av[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            av[l] = (l < Lmax) ? reinterpret_cast<const float4*>(ae + (int64_t)l * Din)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t off = (int64_t)ic * nv + c;
+        float4 wv, mv, vv, w0v;
+        if (first) {
+            w0v = reinterpret_cast<const float4*>(w0)[off];
+            wv = w0v;
+            mv = make_float4(0.f, 0.f, 0.f, 0.f);
+            vv = mv;
+        } else {
+            wv = reinterpret_cast<const float4*>(we)[off];
+            mv = reinterpret_cast<const float4*>(me)[off];
+            vv = reinterpret_cast<const float4*>(ve)[off];
+            if (clamp_eps >= 0.f) w0v = reinterpret_cast<const float4*>(w0)[off];
+        }
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            g[0] += dyv[l] * av[l].x;
+            g[1] += dyv[l] * av[l].y;
+            g[2] += dyv[l] * av[l].z;
+            g[3] += dyv[l] * av[l].w;
+        }
+        float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+        float mq[4] = {mv.x, mv.y, mv.z, mv.w};
+        float vq[4] = {vv.x, vv.y, vv.z, vv.w};
+        const float w0q[4] = {w0v.x, w0v.y, w0v.z, w0v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wq[k] *= decay;
+            mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
+            vq[k] = vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
+            const float denom = sqrtf(vq[k]) / bc2_sqrt + eps;
+            wq[k] -= step_size * (mq[k] / denom);
+            if (clamp_eps >= 0.f) wq[k] = fminf(fmaxf(wq[k], w0q[k] - clamp_eps), w0q[k] + clamp_eps);
+        }
+        if (row_ok) {
+            reinterpret_cast<float4*>(we)[off] = make_float4(wq[0], wq[1], wq[2], wq[3]);
+            reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
+            reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            ysum[l] += (wq[0] * av[l].x + wq[1] * av[l].y) + (wq[2] * av[l].z + wq[3] * av[l].w);
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        float s = ysum[l];
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (sub == 0 && row_ok && l < Lmax) y[((int64_t)e * Lmax + l) * Dout + i] = s;
+    }
+}
+
 template <int L, int ROWS>
 static int launch_adamw(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
                         const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din, float lr,
                         float beta1, float beta2, float eps, float wd, float clamp_eps, int64_t w0_stride_e, hipStream_t st) {
+    // column-compacted matrices: lanes per row by issue efficiency nv / (ceil(nv / G) * G); the wave-per-row form when it is >= 0.9 there
+    const int nv4 = Din >> 2;
+    auto eff = [&](int G) { return (double)nv4 / (double)((nv4 + G - 1) / G * G); };
+    static const int grouped_env = getenv("DEVQA_FT_GROUPED") ? atoi(getenv("DEVQA_FT_GROUPED")) : -1;     // 0: off, 8 / 16: forced
+    if (Din <= 1024 && grouped_env != 0 && (grouped_env > 0 || eff(64) < 0.9)) {
+        const int G = grouped_env > 0 ? grouped_env : (eff(16) >= 0.83 ? 16 : 8);   // measured (tools/debug/ft_sweep_bench.py): 256-byte pieces win unless they idle > 1/6 of the steps
+        const int rows_wg = 4 * (64 / G);
+        const int row_blocks = (Dout + rows_wg - 1) / rows_wg;
+        const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
+        if (G == 16)
+            hipLaunchKernelGGL((ft_adamw_step_grouped_kernel<L, 16>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update,
+                               adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
+        else
+            hipLaunchKernelGGL((ft_adamw_step_grouped_kernel<L, 8>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update,
+                               adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
+        devqa_prof_end(ph, 24.0 * E * (double)Dout * Din, st);
+        DEVQA_LAUNCH_CHECK("ft_adamw_step(grouped)");
+        return DEVQA_OK;
+    }
     if (Din <= 1024) {
         const int row_blocks = (Dout + 4 * ROWS - 1) / (4 * ROWS);
         const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
