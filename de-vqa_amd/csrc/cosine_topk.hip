@@ -9,7 +9,9 @@
 //
 // Exactness: the fp32 scan only has to place the true top-k inside the top-(k+8); the final order
 // and the reported scores come from the fp64 re-score, so indices match a float64 brute force.
+#include <stdlib.h>
 #include "common.h"
+#include <rocprim/warp/warp_reduce.hpp>
 
 #define CT_MARGIN 8
 #define CT_MAXK 32
@@ -313,12 +315,284 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const float* __res
     }
 }
 
+// ---- few queries (IKE_VL / LTE_VL retrieval: Q = 1 per probe) ------------------------------------------------------------------
+// The tiled path above is four launches and a selection by ONE workgroup whose k + 8 rounds each cross two barriers: 91 us at k = 5
+// and 205 us at k = 32 over a 15000 x 384 corpus that streams in 3 us -- launch latency and a serial selection, not bytes.  For Q <= 4,
+// two launches:
+//   score_select : a wave owns 64 corpus rows: each row is read once for its norm and its <= 4 dot products, lane r keeps row r's
+//                  scores; then k + 8 arg-max rounds over the 64 lanes (shuffles only) leave a SORTED candidate list per wave and query
+//   merge_final  : one workgroup per query: a 64-way merge of sorted lists per wave (lane = list, one head each; the winner advances
+//                  its pointer), the four waves' results merged once more, then the fp64 re-score and (score desc, id asc) order of
+//                  the kernels above.
+// The query's norm scales all of its scores alike and is left to the fp64 re-score.
+// arg-max of (score desc, id asc) over a wave, id 0x7fffffff = nothing.  Two DPP all-reductions (rocPRIM warp_reduce: max of the
+// scores, then min of the ids that hold it) instead of a 6-step butterfly of ds_bpermute pairs: the selection rounds are dependent
+// chains, and 12 LDS-crossbar round trips per round were what the first version of this path spent its time on.
+typedef rocprim::warp_reduce<float, 64, true> ct_wr_f;
+typedef rocprim::warp_reduce<int, 64, true> ct_wr_i;
+struct ct_wr_storage {
+    ct_wr_f::storage_type f;
+    ct_wr_i::storage_type i;
+};
+__device__ __forceinline__ void ct_wave_argmax(float& bs, int& bi, ct_wr_storage& st) {
+    float m;
+    ct_wr_f().reduce(bi == 0x7fffffff ? -INFINITY : bs, m, st.f, rocprim::maximum<float>());
+    int mi;
+    ct_wr_i().reduce((bi != 0x7fffffff && bs == m) ? bi : 0x7fffffff, mi, st.i, rocprim::minimum<int>());
+    bs = m;
+    bi = mi;
+}
+
+template <int QMAX>
+__global__ __launch_bounds__(256) void score_select_kernel(const float* __restrict__ corpus, const float* __restrict__ queries, int N, int Q,
+                                                           int D, int norm_c, int nc, int n_lists, float* __restrict__ list_s,
+                                                           int* __restrict__ list_i) {
+    __shared__ ct_wr_storage wr_st[4];
+    ct_wr_storage& wst = wr_st[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_lists) return;
+    const int row0 = w * 64;
+    float mine[QMAX];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) mine[q] = -INFINITY;
+    const int nrows = min(64, N - row0);
+    // rows in groups of RG with all of a group's loads issued before the first use: one row at a time the loop was a chain of 64
+    // global-memory round trips (59 us for 64 rows)
+    constexpr int RG = 8;
+    const int nv = D >> 2;
+    for (int r0 = 0; r0 < nrows; r0 += RG) {
+        float nrm[RG], acc[RG][QMAX];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            nrm[g] = 0.f;
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) acc[g][q] = 0.f;
+        }
+        for (int c = lane; c < nv; c += 64) {
+            float4 v[RG];
+#pragma unroll
+            for (int g = 0; g < RG; ++g)
+                v[g] = reinterpret_cast<const float4*>(corpus + (int64_t)(row0 + min(r0 + g, nrows - 1)) * D)[c];
+            float4 u[QMAX];
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q)
+                u[q] = q < Q ? reinterpret_cast<const float4*>(queries + (int64_t)q * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                nrm[g] += (v[g].x * v[g].x + v[g].y * v[g].y) + (v[g].z * v[g].z + v[g].w * v[g].w);
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q)
+                    acc[g][q] += (v[g].x * u[q].x + v[g].y * u[q].y) + (v[g].z * u[q].z + v[g].w * u[q].w);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            const int r = r0 + g;
+            float n2;
+            ct_wr_f().reduce(nrm[g], n2, wst.f, rocprim::plus<float>());       // DPP all-reduce
+            const float ic = norm_c ? (n2 > 0.f ? 1.f / sqrtf(n2) : 0.f) : 1.f;
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q)
+                if (q < Q) {
+                    float sc;
+                    ct_wr_f().reduce(acc[g][q], sc, wst.f, rocprim::plus<float>());
+                    if (lane == r && r < nrows) mine[q] = sc * ic;
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        if (q >= Q) continue;
+        float v = mine[q];
+        int id = lane < nrows ? row0 + lane : 0x7fffffff;
+        float os = -INFINITY;
+        int oi = -1;
+        for (int p = 0; p < nc; ++p) {
+            float bs = id == 0x7fffffff ? -INFINITY : v;
+            int bi = id;
+            ct_wave_argmax(bs, bi, wst);
+            if (lane == p) {
+                os = bs;
+                oi = bi == 0x7fffffff ? -1 : bi;
+            }
+            if (bi != 0x7fffffff && id == bi) id = 0x7fffffff;      // the owner retires
+        }
+        if (lane < nc) {
+            list_s[((int64_t)q * n_lists + w) * 64 + lane] = os;
+            list_i[((int64_t)q * n_lists + w) * 64 + lane] = oi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void merge_final_kernel(const float* __restrict__ list_s, const int* __restrict__ list_i, int n_lists,
+                                                          const float* __restrict__ corpus, const float* __restrict__ queries, int N, int D,
+                                                          int k, int nc, int norm_c, int norm_q, int64_t* __restrict__ out_idx,
+                                                          float* __restrict__ out_score) {
+    __shared__ float run_s[4][2][64];      // per wave: running merged list (ping-pong)
+    __shared__ int run_i[4][2][64];
+    __shared__ float fin_s[64];
+    __shared__ int cand_i[CT_MAXK + CT_MARGIN];
+    __shared__ double cand_s[CT_MAXK + CT_MARGIN];
+    __shared__ ct_wr_storage wr_st[4];
+    const int qi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ct_wr_storage& wst = wr_st[wave];
+    const float* ls = list_s + (int64_t)qi * n_lists * 64;
+    const int* li = list_i + (int64_t)qi * n_lists * 64;
+    // wave w merges lists w, w + 4, ... in batches of 31 + its running list, each batch staged in LDS first (a winner advancing its
+    // pointer then costs an LDS read, not a global-memory round trip inside the dependent chain of rounds)
+    __shared__ float st_s[4][32][CT_MAXK + CT_MARGIN];
+    __shared__ int st_i[4][32][CT_MAXK + CT_MARGIN];
+    int cur = 0;
+    bool have = false;
+    for (int j0 = wave; j0 < n_lists; j0 += 4 * 31) {
+        const int nb = min(31, (n_lists - j0 + 3) / 4);
+        for (int e = lane; e < nb * nc; e += 64) {          // list e / nc, entry e % nc
+            const int l = e / nc, p = e - l * nc;
+            st_s[wave][l][p] = ls[(int64_t)(j0 + 4 * l) * 64 + p];
+            st_i[wave][l][p] = li[(int64_t)(j0 + 4 * l) * 64 + p];
+        }
+        if (have)
+            for (int p = lane; p < nc; p += 64) {
+                st_s[wave][31][p] = run_s[wave][cur][p];
+                st_i[wave][31][p] = run_i[wave][cur][p];
+            }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS stores are visible to its lanes
+        int ptr = 0;
+        float hv = -INFINITY;
+        int hi = 0x7fffffff;
+        const int my = lane < nb ? lane : (lane == 31 && have ? 31 : -1);
+        if (my >= 0) {
+            hv = st_s[wave][my][0];
+            hi = st_i[wave][my][0];
+            if (hi < 0) hi = 0x7fffffff;
+        }
+        float* ds = run_s[wave][cur ^ 1];
+        int* di = run_i[wave][cur ^ 1];
+        for (int p = 0; p < nc; ++p) {
+            float bs = hi == 0x7fffffff ? -INFINITY : hv;
+            int bi = hi;
+            ct_wave_argmax(bs, bi, wst);
+            if (lane == 0) {
+                ds[p] = bs;
+                di[p] = bi == 0x7fffffff ? -1 : bi;
+            }
+            if (bi != 0x7fffffff && hi == bi) {
+                ++ptr;
+                if (ptr < nc) {
+                    hv = st_s[wave][my][ptr];
+                    hi = st_i[wave][my][ptr];
+                    if (hi < 0) hi = 0x7fffffff;
+                } else {
+                    hi = 0x7fffffff;
+                }
+            }
+        }
+        cur ^= 1;
+        have = true;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!have && lane < nc) {       // a wave without lists
+        run_s[wave][cur][lane] = -INFINITY;
+        run_i[wave][cur][lane] = -1;
+    }
+    __shared__ int cur_of[4];
+    if (lane == 0) cur_of[wave] = cur;
+    __syncthreads();
+    if (wave == 0) {
+        // the four waves' lists -> the final candidates
+        int ptr = 0;
+        float hv = -INFINITY;
+        int hi = 0x7fffffff;
+        const float* ps = nullptr;
+        const int* pi = nullptr;
+        if (lane < 4) {
+            ps = run_s[lane][cur_of[lane]];
+            pi = run_i[lane][cur_of[lane]];
+            hv = ps[0];
+            hi = pi[0];
+            if (hi < 0) hi = 0x7fffffff;
+        }
+        for (int p = 0; p < nc; ++p) {
+            float bs = hi == 0x7fffffff ? -INFINITY : hv;
+            int bi = hi;
+            ct_wave_argmax(bs, bi, wst);
+            if (lane == 0) {
+                fin_s[p] = bs;
+                cand_i[p] = bi == 0x7fffffff ? -1 : bi;
+            }
+            if (bi != 0x7fffffff && hi == bi) {
+                ++ptr;
+                if (ptr < nc) {
+                    hv = ps[ptr];
+                    hi = pi[ptr];
+                    if (hi < 0) hi = 0x7fffffff;
+                } else {
+                    hi = 0x7fffffff;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float* qv = queries + (int64_t)qi * D;
+    double qn = 0.0;
+    if (norm_q) {
+        for (int c = lane; c < D; c += 64) qn += (double)qv[c] * (double)qv[c];
+        qn = wave_sum_d(qn);
+    }
+    for (int p = wave; p < nc; p += 4) {
+        const int ci = cand_i[p];
+        double dot = 0.0, cn = 0.0;
+        if (ci >= 0 && ci < N) {
+            const float* cv = corpus + (int64_t)ci * D;
+            for (int c = lane; c < D; c += 64) {
+                const double x = (double)cv[c];
+                dot += x * (double)qv[c];
+                cn += x * x;
+            }
+        }
+        dot = wave_sum_d(dot);
+        cn = wave_sum_d(cn);
+        if (lane == 0) {
+            double s = dot;
+            if (norm_c) s = cn > 0.0 ? s / sqrt(cn) : 0.0;
+            if (norm_q) s = qn > 0.0 ? s / sqrt(qn) : 0.0;
+            cand_s[p] = (ci >= 0 && ci < N) ? s : -INFINITY;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n_ok = 0;
+        for (int a = 0; a < nc; ++a) n_ok += cand_i[a] >= 0;
+        for (int a = 1; a < nc; ++a) {
+            const double s = cand_s[a];
+            const int id = cand_i[a];
+            int b = a - 1;
+            while (b >= 0 && (cand_s[b] < s || (cand_s[b] == s && (unsigned)cand_i[b] > (unsigned)id))) {
+                cand_s[b + 1] = cand_s[b];
+                cand_i[b + 1] = cand_i[b];
+                --b;
+            }
+            cand_s[b + 1] = s;
+            cand_i[b + 1] = id;
+        }
+        for (int a = 0; a < k; ++a) {
+            out_idx[(int64_t)qi * k + a] = a < n_ok ? (int64_t)cand_i[a] : (int64_t)-1;
+            out_score[(int64_t)qi * k + a] = a < n_ok ? (float)cand_s[a] : -INFINITY;
+        }
+    }
+}
+
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 extern "C" int64_t devqa_cosine_topk_workspace(int N, int Q, int k) {
     (void)k;
     if (N <= 0 || Q <= 0) return 256;
-    return align256((int64_t)Q * N * 4) + align256((int64_t)N * 4) + align256((int64_t)Q * 4);
+    // few-query path: [Q][ceil(N / 64)][64] candidate scores live in the score region (<= Q * (N + 63) floats), the ids behind it
+    const int64_t ids = Q <= 4 ? align256((int64_t)Q * ((N + 63) / 64) * 64 * 4) : 0;
+    return align256((int64_t)Q * (N + 64) * 4) + align256((int64_t)N * 4) + align256((int64_t)Q * 4) + ids;
 }
 
 extern "C" int devqa_cosine_topk(const float* corpus, const float* queries, int N, int Q, int D, int k, int normalize_corpus,
@@ -334,6 +608,23 @@ extern "C" int devqa_cosine_topk(const float* corpus, const float* queries, int 
     float* scores = (float*)ws;
     float* inv_c = (float*)(ws + align256((int64_t)Q * N * 4));
     float* inv_q = (float*)((char*)inv_c + align256((int64_t)N * 4));
+    {   // few queries: two launches (score + per-wave selection, merge + fp64 re-score); DEVQA_COSINE_FEWQ=0 keeps the tiled path
+        static const int fewq = getenv("DEVQA_COSINE_FEWQ") ? atoi(getenv("DEVQA_COSINE_FEWQ")) : 1;
+        const int nc = min(k + CT_MARGIN, N);
+        const int n_lists = (N + 63) / 64;                                  // one sorted candidate list of <= 64 entries per wave
+        if (fewq && Q <= 4) {
+            float* ls = scores;                                             // [Q][n_lists][64] scores, then ids: inside the Q * N floats
+            int* li = (int*)(ws + align256((int64_t)Q * (N + 64) * 4));     // ids: behind the (padded) score region
+            hipLaunchKernelGGL(score_select_kernel<4>, dim3((n_lists + 3) / 4), dim3(256), 0, st, corpus, queries, N, Q, D, normalize_corpus,
+                               nc, n_lists, ls, li);
+            DEVQA_LAUNCH_CHECK("score_select");
+            hipLaunchKernelGGL(merge_final_kernel, dim3(Q), dim3(256), 0, st, ls, li, n_lists, corpus, queries, N, D, k, nc,
+                               normalize_corpus, normalize_queries, out_idx, out_score);
+            devqa_prof_end(ph, 4.0 * (double)N * D, st);
+            DEVQA_LAUNCH_CHECK("merge_final");
+            return DEVQA_OK;
+        }
+    }
     if (normalize_corpus) {
         hipLaunchKernelGGL(row_inv_norm_kernel, dim3((N + 3) / 4), dim3(256), 0, st, corpus, N, D, inv_c);
         DEVQA_LAUNCH_CHECK("row_inv_norm(corpus)");

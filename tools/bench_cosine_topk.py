@@ -19,7 +19,7 @@ def main():
     N, D = 15000, 384
     corpus = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32)).cuda()
     out = []
-    for Q, k in ((1000, 32), (1000, 5), (1, 5), (64, 32)):
+    for Q, k in ((1000, 32), (1000, 5), (1, 5), (1, 32), (4, 32), (64, 32)):
         q = torch.from_numpy(rng.standard_normal((Q, D)).astype(np.float32)).cuda()
         for _ in range(3):
             lib.cosine_topk(corpus, q, k)
