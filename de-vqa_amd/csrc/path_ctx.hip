@@ -429,6 +429,13 @@ extern "C" int devqa_llm_layers(devqa_ctx_t h, float* x, const int32_t* seq_desc
     return llm_layers(c, x, seq_desc, n_seq, max_len, R, dense, n_layers, stop_before_fc2, out_fc2_in, w, (hipStream_t)stream);
 }
 
+// SURVEY.md 8(b)'s name for the frozen prefix of FT_VL: all layers, the last one stopping at its fc2 input
+extern "C" int64_t devqa_llm_prefix_workspace(devqa_ctx_t h, int R) { return devqa_llm_layers_workspace(h, R, 1); }
+extern "C" int devqa_llm_prefix(devqa_ctx_t h, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense, void* out_fc2_in,
+                                void* workspace, int64_t ws_bytes, void* stream) {
+    return devqa_llm_layers(h, x, seq_desc, n_seq, max_len, R, dense, -1, 1, out_fc2_in, workspace, ws_bytes, stream);
+}
+
 extern "C" int64_t devqa_llm_head_workspace(devqa_ctx_t h, int R) {
     Ctx* c = ctx_of(h);
     if (!c || R <= 0) return -1;
@@ -749,4 +756,81 @@ extern "C" int devqa_gather_scores(devqa_comm_t h, const float* local, int n_row
     DEVQA_CHECK_ARG(cm && local && out && n_rows > 0, "gather_scores: bad argument");
     const int rc = g_rccl.AllGather(local, out, (size_t)n_rows * DEVQA_SCORE_COLS, /*ncclFloat32*/ 7, cm->nccl, (hipStream_t)stream);
     return rc == 0 ? DEVQA_OK : rccl_fail("ncclAllGather", rc);
+}
+
+
+// ---- K16 / K17: MEND_VL's hyper-network transform and low-rank delta application as two calls ------------------------------------
+// K16 (R/editor/vllm_editors/mend_vl/auxiliary_networks.py:112-151, 62-83, inference mode): rows idx[0..n) of (x [R, du], delta [R, dv])
+// -> normalise with the stored statistics and concatenate [n, D = du + dv] -> n_layers low-rank residual layers
+// out = x + relu((x v^T) u^T + bias) * mode_scale + mode_shift (exact-fp32 GEMMs) -> split into (x~ [n, du], delta~ [n, dv]).
+extern "C" int64_t devqa_mend_transform_workspace(int n, int du, int dv, int rank) {
+    if (n <= 0 || du <= 0 || dv <= 0 || rank <= 0) return 256;
+    const int64_t D = (int64_t)du + dv;
+    return 3 * al256((int64_t)n * D * 4) + al256((int64_t)n * rank * 4);
+}
+
+extern "C" int devqa_mend_transform(const float* x, const float* delta, const int32_t* idx, int n, int du, int dv,
+                                    const devqa_mend_net* net, float* out_x, float* out_d, void* workspace, int64_t ws_bytes, void* stream) {
+    DEVQA_CHECK_ARG(x && delta && net && out_x && out_d && workspace, "mend_transform: null pointer");
+    if (n == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(n > 0 && du > 0 && dv > 0 && net->rank > 0 && net->n_layers >= 1 && net->n_layers <= DEVQA_MEND_MAX_LAYERS,
+                      "mend_transform: bad dims n=%d du=%d dv=%d rank=%d layers=%d", n, du, dv, net->rank, net->n_layers);
+    DEVQA_CHECK_SHAPE((du + dv) % 4 == 0 && net->rank % 4 == 0, "mend_transform: D=%d and rank=%d must be multiples of 4 (exact-fp32 GEMM)", du + dv, net->rank);
+    DEVQA_CHECK_ARG((((uintptr_t)workspace) & 255) == 0, "mend_transform: workspace must be 256-byte aligned");
+    DEVQA_CHECK_SHAPE(ws_bytes >= devqa_mend_transform_workspace(n, du, dv, net->rank), "mend_transform: workspace too small");
+    const int D = du + dv;
+    char* ws = (char*)workspace;
+    float* a = (float*)ws;
+    float* b = (float*)(ws + al256((int64_t)n * D * 4));
+    float* pre = (float*)(ws + 2 * al256((int64_t)n * D * 4));
+    float* low = (float*)(ws + 3 * al256((int64_t)n * D * 4));
+    int rc = devqa_mend_normalize_concat(x, delta, idx, net->u_mean, net->u_std, net->v_mean, net->v_std, 1e-7f, n, du, dv, a, stream);
+    if (rc != DEVQA_OK) return rc;
+    float* cur = a;
+    float* nxt = b;
+    for (int l = 0; l < net->n_layers; ++l) {
+        const devqa_mend_layer& L = net->layers[l];
+        DEVQA_CHECK_ARG(L.u && L.v && L.bias && L.mode_scale && L.mode_shift, "mend_transform: layer %d has a null pointer", l);
+        rc = devqa_gemm_f32(cur, D, L.v, D, nullptr, n, net->rank, D, 1.f, DEVQA_ACT_NONE, nullptr, low, net->rank, stream);      // x v^T
+        if (rc != DEVQA_OK) return rc;
+        rc = devqa_gemm_f32(low, net->rank, L.u, net->rank, nullptr, n, D, net->rank, 1.f, DEVQA_ACT_NONE, nullptr, pre, D, stream);  // . u^T
+        if (rc != DEVQA_OK) return rc;
+        rc = devqa_mend_lrlinear_epilogue(pre, L.bias, L.mode_scale, L.mode_shift, cur, nxt, n, D, stream);
+        if (rc != DEVQA_OK) return rc;
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    // split [n, D] -> [n, du], [n, dv]
+    hipError_t e = hipMemcpy2DAsync(out_x, (size_t)du * 4, cur, (size_t)D * 4, (size_t)du * 4, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(out_d, (size_t)dv * 4, cur + du, (size_t)D * 4, (size_t)dv * 4, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return devqa_fail(DEVQA_E_HIP, "mend_transform: split copy: %s", hipGetErrorString(e));
+    return DEVQA_OK;
+}
+
+// K17 (mend_vl.py:73-80, the forward hook `output + input @ delta_W` with delta_W = x~^T delta~ * lr / n kept in FACTORS):
+// y [R, dout] fp32 += (h [R, din] . xt^T [din, npad]) . dt [npad, dout], operands in the compute dtype (bf16 or fp32), npad % 64 == 0;
+// dtT = dt transposed [dout, npad] (the TN GEMM operand).
+extern "C" int64_t devqa_mend_apply_workspace(int R, int npad, int compute_dtype) {
+    if (R <= 0 || npad <= 0) return 256;
+    return al256((int64_t)R * npad * (compute_dtype == DEVQA_DTYPE_F32 ? 4 : 2));
+}
+
+extern "C" int devqa_mend_apply(const void* h, const void* xt, const void* dtT, float* y, int R, int din, int dout, int npad, int compute_dtype,
+                                void* workspace, int64_t ws_bytes, void* stream) {
+    DEVQA_CHECK_ARG(h && xt && dtT && y && workspace, "mend_apply: null pointer");
+    if (R == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE(R > 0 && din > 0 && dout > 0 && npad > 0 && npad % 64 == 0, "mend_apply: bad dims R=%d din=%d dout=%d npad=%d", R, din, dout, npad);
+    DEVQA_CHECK_ARG(compute_dtype == DEVQA_DTYPE_BF16 || compute_dtype == DEVQA_DTYPE_F32, "mend_apply: unknown dtype %d", compute_dtype);
+    DEVQA_CHECK_SHAPE(ws_bytes >= devqa_mend_apply_workspace(R, npad, compute_dtype), "mend_apply: workspace too small");
+    if (compute_dtype == DEVQA_DTYPE_F32) {
+        float* coef = (float*)workspace;
+        int rc = devqa_gemm_f32((const float*)h, din, (const float*)xt, din, nullptr, R, npad, din, 1.f, DEVQA_ACT_NONE, nullptr, coef, npad, stream);
+        if (rc != DEVQA_OK) return rc;
+        return devqa_gemm_f32(coef, npad, (const float*)dtT, npad, nullptr, R, dout, npad, 1.f, DEVQA_ACT_NONE, y, y, dout, stream);
+    }
+    devqa_bf16* coef = (devqa_bf16*)workspace;
+    int rc = devqa_gemm_bf16((const devqa_bf16*)h, din, (const devqa_bf16*)xt, din, nullptr, R, npad, din, 1.f, DEVQA_ACT_NONE, nullptr, coef, nullptr,
+                             npad, stream);
+    if (rc != DEVQA_OK) return rc;
+    return devqa_gemm_bf16(coef, npad, (const devqa_bf16*)dtT, npad, nullptr, R, dout, npad, 1.f, DEVQA_ACT_NONE, y, nullptr, y, dout, stream);
 }

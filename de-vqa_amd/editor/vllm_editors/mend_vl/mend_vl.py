@@ -262,6 +262,15 @@ class MENDvl(VLLMBaseEditorWithTraining):
             lib.welford_rows(d32, nz, reset, A[pre + "v_mean"], A[pre + "v_s"], A[pre + "v_std"], k_old)
             A[pre + "k"] = k_new
             self.norm_init[m["shape"]] = True
+        if not self.training:       # inference: the whole transform is one path-level call (K16, devqa_mend_transform)
+            layers = [{"u": A[pre + "mlp.layers.%d.u" % l], "v": A[pre + "mlp.layers.%d.v" % l], "bias": A[pre + "mlp.layers.%d.bias" % l],
+                       "mode_scale": A[pre + "mlp.layers.%d.mode_scale.weight" % l][m["idx"]].contiguous(),
+                       "mode_shift": A[pre + "mlp.layers.%d.mode_shift.weight" % l][m["idx"]].contiguous()} for l in range(self.n_layers)]
+            D_, rank_ = xin32.shape[1] + d32.shape[1], layers[0]["v"].shape[0]
+            if self.n_layers <= lib.MEND_MAX_LAYERS and D_ % 4 == 0 and rank_ % 4 == 0:
+                stats = (A[pre + "u_mean"], A[pre + "u_std"], A[pre + "v_mean"], A[pre + "v_std"]) if norm else None
+                xt, dt = lib.mend_transform(xin32, d32, nz, layers, stats)
+                return xt, dt, None
         inp = lib.mend_normalize_concat(xin32, d32, nz, A[pre + "u_mean"] if norm else None, A[pre + "u_std"] if norm else None,
                                         A[pre + "v_mean"] if norm else None, A[pre + "v_std"] if norm else None, 1e-7)
         din = xin32.shape[1]

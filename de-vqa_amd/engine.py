@@ -358,7 +358,7 @@ class Blip2Engine:
             lib.gemm(a, self._w(p + "fc2.weight"), self._p(p + "fc2.bias"), residual=x, out_f32=x)
             d2 = deltas.get(p + "fc2")
             if d2 is not None:
-                lib.gemm(lib.gemm(a, d2["xt"]), d2["dtT"], residual=x, out_f32=x)
+                lib.mend_apply_(a, d2["xt"], d2["dtT"], x)       # K17: x += (a . xt^T) . dt
             self.add_extra_neurons(i, h, x)
         return x, None
 

@@ -224,7 +224,7 @@ class LlavaEngine:
             lib.gemm(a, self._w(p + "mlp.down_proj.weight"), residual=x, out_f32=x)
             dd = deltas.get(p + "mlp.down_proj")
             if dd is not None:
-                lib.gemm(lib.gemm(a, dd["xt"]), dd["dtT"], residual=x, out_f32=x)
+                lib.mend_apply_(a, dd["xt"], dd["dtT"], x)       # K17: x += (a . xt^T) . dt
             self.add_extra_neurons(i, h, x)
         return x, None
 

@@ -105,6 +105,12 @@ def load():
     _sig(L.devqa_vision_encode, [U64, P, I, P, P, I64, P])
     _sig(L.devqa_llm_layers_workspace, [U64, I, I], c_int64)
     _sig(L.devqa_llm_layers, [U64, P, P, I, I, I, I, I, I, P, P, I64, P])
+    _sig(L.devqa_llm_prefix_workspace, [U64, I], c_int64)
+    _sig(L.devqa_llm_prefix, [U64, P, P, I, I, I, I, P, P, I64, P])
+    _sig(L.devqa_mend_transform_workspace, [I, I, I, I], c_int64)
+    _sig(L.devqa_mend_transform, [P, P, P, I, I, I, P, P, P, P, I64, P])
+    _sig(L.devqa_mend_apply_workspace, [I, I, I], c_int64)
+    _sig(L.devqa_mend_apply, [P, P, P, P, I, I, I, I, I, P, I64, P])
     _sig(L.devqa_llm_head_workspace, [U64, I], c_int64)
     _sig(L.devqa_llm_head, [U64, P, P, I, P, P, I64, P])
     _sig(L.devqa_llm_forward_workspace, [U64, I, I], c_int64)
@@ -124,7 +130,8 @@ def load():
 
 
 EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "devqa_vision_encode_workspace", "devqa_vision_encode",
-           "devqa_llm_layers_workspace", "devqa_llm_layers", "devqa_llm_head_workspace", "devqa_llm_head", "devqa_llm_forward_workspace",
+           "devqa_llm_layers_workspace", "devqa_llm_layers", "devqa_llm_prefix_workspace", "devqa_llm_prefix", "devqa_mend_transform_workspace",
+           "devqa_mend_transform", "devqa_mend_apply_workspace", "devqa_mend_apply", "devqa_llm_head_workspace", "devqa_llm_head", "devqa_llm_forward_workspace",
            "devqa_llm_forward", "devqa_ft_edit_workspace", "devqa_ft_edit", "devqa_ctx_bind_edit_target", "devqa_apply_delta", "devqa_restore",
            "devqa_token_acc", "devqa_comm_unique_id", "devqa_comm_create", "devqa_comm_destroy", "devqa_gather_scores",
            "devqa_profile", "devqa_profile_read", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
@@ -736,6 +743,66 @@ class WeightEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char_p), ("ptr", c_void_p), ("dtype", ctypes.c_int32), ("ndim", ctypes.c_int32), ("shape", c_int64 * 4)]
 
 
+MEND_MAX_LAYERS = 4
+
+
+class MendLayer(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("u", "v", "bias", "mode_scale", "mode_shift")]
+
+
+class MendNet(ctypes.Structure):
+    _fields_ = [("n_layers", ctypes.c_int32), ("rank", ctypes.c_int32), ("u_mean", c_void_p), ("u_std", c_void_p), ("v_mean", c_void_p),
+                ("v_std", c_void_p), ("layers", MendLayer * MEND_MAX_LAYERS)]
+
+
+def mend_transform(x, delta, idx, layers, stats=None):
+    """K16 (devqa_mend_transform): rows `idx` (int32, or None = all) of fp32 x [R, du] / delta [R, dv] through the hyper-network in
+    inference mode.  layers: list of dicts {u [D, rank], v [rank, D], bias, mode_scale, mode_shift [D]} (fp32, contiguous; the mode row
+    of the edited module already selected); stats: (u_mean, u_std, v_mean, v_std) or None.  -> (x~ [n, du], delta~ [n, dv])"""
+    _need(x, torch.float32, "mend_transform x"); _need(delta, torch.float32, "mend_transform delta")
+    du, dv = x.shape[1], delta.shape[1]
+    n = x.shape[0] if idx is None else int(idx.numel())
+    out_x = torch.empty((n, du), dtype=torch.float32, device=x.device)
+    out_d = torch.empty((n, dv), dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out_x, out_d
+    net = MendNet()
+    net.n_layers, net.rank = len(layers), int(layers[0]["v"].shape[0])
+    keep = []
+    if stats is not None:
+        for name, t in zip(("u_mean", "u_std", "v_mean", "v_std"), stats):
+            _need(t, torch.float32, "mend_transform " + name)
+            setattr(net, name, t.data_ptr())
+    for i, L in enumerate(layers):
+        for name in ("u", "v", "bias", "mode_scale", "mode_shift"):
+            t = L[name]
+            _need(t, torch.float32, "mend_transform layer %d %s" % (i, name))
+            keep.append(t)
+            setattr(net.layers[i], name, t.data_ptr())
+    nb = load().devqa_mend_transform_workspace(n, du, dv, net.rank)
+    kws, ws = _ws(nb, x.device)
+    _chk(load().devqa_mend_transform(_p(x), _p(delta), _p(idx), n, du, dv, ctypes.byref(net), _p(out_x), _p(out_d), ws, nb, _stream()),
+         "devqa_mend_transform")
+    return out_x, out_d
+
+
+def mend_apply_(h, xt, dtT, y):
+    """K17 (devqa_mend_apply): y [R, dout] fp32 += (h [R, din] . xt^T) . dt for the low-rank factors xt [npad, din], dtT [dout, npad]
+    (operands in h's dtype: bf16 or fp32; npad % 64 == 0)."""
+    assert h.dtype == xt.dtype == dtT.dtype and h.dtype in (torch.bfloat16, torch.float32)
+    for t in (h, xt, dtT):
+        assert t.is_cuda and t.is_contiguous()
+    _need(y, torch.float32, "mend_apply y")
+    R, din = h.shape
+    npad, dout = xt.shape[0], dtT.shape[0]
+    assert xt.shape[1] == din and dtT.shape[1] == npad and y.shape == (R, dout)
+    cd = 2 if h.dtype == torch.float32 else 1
+    nb = load().devqa_mend_apply_workspace(R, npad, cd)
+    kws, ws = _ws(nb, h.device)
+    _chk(load().devqa_mend_apply(_p(h), _p(xt), _p(dtT), _p(y), R, din, dout, npad, cd, ws, nb, _stream()), "devqa_mend_apply")
+    return y
+
+
 class FtCfg(ctypes.Structure):
     _fields_ = [("num_steps", ctypes.c_int32), ("lr", c_float), ("weight_decay", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
                 ("loss_floor", c_float), ("clamp_eps", c_float)]
@@ -807,6 +874,17 @@ class PathContext:
         keep, ws = _ws(n, x.device)
         _chk(load().devqa_llm_layers(self.h, _p(x), _p(seq_desc), int(n_seq), int(max_len), R, int(bool(dense)), int(n_layers),
                                      int(bool(stop_before_fc2)), _p(a), ws, n, _stream()), "devqa_llm_layers")
+        return a
+
+    def llm_prefix(self, x, seq_desc, n_seq, max_len, dense):
+        """SURVEY 8(b)'s devqa_llm_prefix: all layers in place on x, the last one stopping at its fc2 input -> [R, ffn]"""
+        _need(x, torch.float32, "llm_prefix x")
+        R = x.shape[0]
+        a = torch.empty((R, self.desc.t_ffn), dtype=self.adt, device=x.device)
+        n = load().devqa_llm_prefix_workspace(self.h, R)
+        keep, ws = _ws(n, x.device)
+        _chk(load().devqa_llm_prefix(self.h, _p(x), _p(seq_desc), int(n_seq), int(max_len), R, int(bool(dense)), _p(a), ws, n, _stream()),
+             "devqa_llm_prefix")
         return a
 
     def llm_head(self, rows, add=None):

@@ -421,6 +421,10 @@ int devqa_vision_encode(devqa_ctx_t ctx, const float* pixel_values, int B, float
 int64_t devqa_llm_layers_workspace(devqa_ctx_t ctx, int R, int stop_before_fc2);
 int devqa_llm_layers(devqa_ctx_t ctx, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense, int n_layers,
                      int stop_before_fc2, void* out_fc2_in, void* workspace, int64_t ws_bytes, void* stream);
+/* devqa_llm_prefix (SURVEY.md 8(b)'s name): devqa_llm_layers over ALL layers with stop_before_fc2 = 1 */
+int64_t devqa_llm_prefix_workspace(devqa_ctx_t ctx, int R);
+int devqa_llm_prefix(devqa_ctx_t ctx, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense, void* out_fc2_in,
+                     void* workspace, int64_t ws_bytes, void* stream);
 /* K8: logits fp32 [R, t_vocab] = lm_head(final LayerNorm(rows [+ add])), rows / add fp32 [R, t_hidden] (tied embedding, no bias) */
 int64_t devqa_llm_head_workspace(devqa_ctx_t ctx, int R);
 int devqa_llm_head(devqa_ctx_t ctx, const float* rows, const float* add, int R, float* out_logits, void* workspace, int64_t ws_bytes,
@@ -470,6 +474,31 @@ int devqa_comm_unique_id(void* id128);
 int devqa_comm_create(int rank, int world, const void* id128, int device, devqa_comm_t* out);
 int devqa_comm_destroy(devqa_comm_t comm);
 int devqa_gather_scores(devqa_comm_t comm, const float* local, int n_rows, float* out, void* stream);
+
+/* ---- K16 / K17: MEND_VL's GradientTransform and the application of its low-rank deltas (devqa_mend_transform /
+ * devqa_mend_apply).  R/editor/vllm_editors/mend_vl/auxiliary_networks.py:112-151 (GradientTransform.forward, inference mode), :62-83
+ * (LRLinear), :20-24 (IDMLP); R/editor/vllm_editors/mend_vl/mend_vl.py:73-80 (forward_edit_hook).
+ *   transform: rows idx[0..n) (nullptr: rows 0..n) of x [R, du] and delta [R, dv] (fp32) -> (x - u_mean) / (u_std + 1e-7) | same for
+ *     delta (statistics nullptr: no normalisation) -> n_layers times  out = in + relu((in v^T) u^T + bias) * mode_scale + mode_shift
+ *     with v [rank, D], u [D, rank], bias / mode_scale / mode_shift [D] (the mode row of the edited module already selected; D = du +
+ *     dv) on the exact-fp32 GEMM -> out_x [n, du], out_d [n, dv].  D % 4 == 0, rank % 4 == 0.
+ *   apply: y [R, dout] fp32 += (h [R, din] . xt^T) . dt with the factors xt [npad, din] and dtT [dout, npad] in the compute dtype
+ *     (delta_W = xt^T dt is never materialised), npad % 64 == 0 (zero rows). */
+#define DEVQA_MEND_MAX_LAYERS 4
+typedef struct devqa_mend_layer {
+    const float *u, *v, *bias, *mode_scale, *mode_shift;
+} devqa_mend_layer;
+typedef struct devqa_mend_net {
+    int32_t n_layers, rank;
+    const float *u_mean, *u_std, *v_mean, *v_std;   /* nullptr: aux_model.norm = False */
+    devqa_mend_layer layers[DEVQA_MEND_MAX_LAYERS];
+} devqa_mend_net;
+int64_t devqa_mend_transform_workspace(int n, int du, int dv, int rank);
+int devqa_mend_transform(const float* x, const float* delta, const int32_t* idx, int n, int du, int dv, const devqa_mend_net* net,
+                         float* out_x, float* out_d, void* workspace, int64_t ws_bytes, void* stream);
+int64_t devqa_mend_apply_workspace(int R, int npad, int compute_dtype);
+int devqa_mend_apply(const void* h, const void* xt, const void* dtT, float* y, int R, int din, int dout, int npad, int compute_dtype,
+                     void* workspace, int64_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """GPU: the PATH-LEVEL C ABI (include/devqa.h "PATH LEVEL", csrc/path_ctx.hip).
 
 1. One complete tiny edit+eval cycle driven through the path-level entry points ONLY -- devqa_ctx_create, devqa_vision_encode,
-   devqa_llm_layers (the frozen prefix), devqa_llm_forward, devqa_llm_head, devqa_ft_edit, devqa_ctx_bind_edit_target,
+   devqa_llm_prefix / devqa_llm_layers (the frozen prefix), devqa_llm_forward, devqa_llm_head, devqa_ft_edit, devqa_ctx_bind_edit_target,
    devqa_apply_delta, devqa_restore, devqa_token_acc -- plus op-level packing helpers (embed_rows / gather_rows / gemm), with NO use of
    engine.py / batched.py / the evaluator: what a non-Python host would write.  Checked against the REFERENCE goldens: G4 (per-step
    losses, step count, weight delta of `FTvl.execute_ft`) and G5 (`results.json` of `evaluate_sequential_edit`).
@@ -111,7 +111,10 @@ def test_one_cycle_through_path_level_calls_only(tiny, in_gold_dir):
     req = d0["requests"][0]
     e = H.probe(req["prompt"], req["image"], " " + req["target_new"])          # the leading space FT_VL forces (ft_vl.py:73-75)
     x, desc, max_len, spans = H.pack([e])
-    a = ctx.llm_layers(x, desc, 1, max_len, True, -1, stop_before_fc2=True)      # x: residual before the edited layer's FFN add
+    x_chk = x.clone()
+    a = ctx.llm_prefix(x, desc, 1, max_len, True)                                # devqa_llm_prefix; x: residual before the edited layer's FFN add
+    a_chk = ctx.llm_layers(x_chk, desc, 1, max_len, True, -1, stop_before_fc2=True)     # the same call under its general name
+    assert torch.equal(a, a_chk) and torch.equal(x, x_chk)
     L = e["y"].numel()
     rows = [spans[0][1] - L + i for i in range(L) if int(e["m"][i]) != 0]
     ridx = torch.tensor(rows, dtype=torch.int32, device=dev)
@@ -237,3 +240,45 @@ def test_gather_scores_single_rank():
     torch.cuda.synchronize()
     assert torch.equal(out, rows)
     comm.close()
+
+
+def test_mend_transform_and_apply_entry_points():
+    """devqa_mend_transform (K16) against the op-level composition it sequences and a float64 restatement of
+    GradientTransform / LRLinear (auxiliary_networks.py:112-151, 62-83); devqa_mend_apply (K17) against h @ (xt^T dt)."""
+    import devqa_amd  # noqa: F401
+    from devqa_amd import lib
+    g = torch.Generator().manual_seed(5)
+    R, du, dv, rank, nl = 9, 40, 24, 16, 2
+    D = du + dv
+    x, dl = torch.randn(R, du, generator=g), torch.randn(R, dv, generator=g)
+    idx = torch.tensor([0, 2, 3, 7], dtype=torch.int32)
+    stats = [torch.randn(du, generator=g), torch.rand(du, generator=g) + 0.5, torch.randn(dv, generator=g), torch.rand(dv, generator=g) + 0.5]
+    layers = [{"u": torch.randn(D, rank, generator=g) * 0.2, "v": torch.randn(rank, D, generator=g) * 0.2, "bias": torch.randn(D, generator=g) * 0.1,
+               "mode_scale": torch.rand(D, generator=g) + 0.5, "mode_shift": torch.randn(D, generator=g) * 0.1} for _ in range(nl)]
+    cu = lambda t: t.cuda().contiguous()  # noqa: E731
+    ox, od = lib.mend_transform(cu(x), cu(dl), cu(idx), [{k: cu(v) for k, v in L_.items()} for L_ in layers], [cu(t) for t in stats])
+    # float64 restatement
+    sel = idx.long()
+    inp = torch.cat([(x[sel].double() - stats[0].double()) / (stats[1].double() + 1e-7),
+                     (dl[sel].double() - stats[2].double()) / (stats[3].double() + 1e-7)], 1)
+    for L_ in layers:
+        pre = inp @ L_["v"].double().T @ L_["u"].double().T + L_["bias"].double()
+        inp = inp + torch.relu(pre) * L_["mode_scale"].double() + L_["mode_shift"].double()
+    # the epilogue's exact formula is the op-level kernel's (tests/test_mend_gpu.py pins it to the reference); here: same composition
+    inp32 = lib.mend_normalize_concat(cu(x), cu(dl), cu(idx), *[cu(t) for t in stats], 1e-7)
+    for L_ in layers:
+        prea = lib.gemm(lib.gemm(inp32, cu(L_["v"])), cu(L_["u"]))
+        inp32 = lib.mend_lrlinear_epilogue(prea, cu(L_["bias"]), cu(L_["mode_scale"]), cu(L_["mode_shift"]), inp32)
+    assert torch.equal(ox, inp32[:, :du].contiguous()) and torch.equal(od, inp32[:, du:].contiguous())
+    for mode in (torch.float32, torch.bfloat16):
+        npad, din, dout, Rr = 64, 48, 40, 13
+        h = torch.randn(Rr, din, generator=g).to(mode).cuda()
+        xt = torch.zeros(npad, din)
+        dt = torch.zeros(npad, dout)
+        xt[:5], dt[:5] = torch.randn(5, din, generator=g), torch.randn(5, dout, generator=g)
+        y0 = torch.randn(Rr, dout, generator=g).cuda()
+        y = y0.clone()
+        lib.mend_apply_(h, xt.to(mode).cuda(), dt.t().contiguous().to(mode).cuda(), y)
+        ref = y0.double().cpu() + (h.double().cpu() @ xt.to(mode).double().T) @ dt.to(mode).double()
+        tol = 1e-5 if mode == torch.float32 else 3e-2
+        assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < tol
