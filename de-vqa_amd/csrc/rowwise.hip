@@ -225,15 +225,16 @@ extern "C" int devqa_layernorm_bwd_dx(const float* x, const float* add, const fl
 // fixed order.  Also the column sums of a matrix (bias gradients) as the same second kernel without the xhat factor.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, const float* __restrict__ add, int M, int D, float eps,
-                                                        float* __restrict__ stats) {
+                                                        int rms, float* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* xr = x + (int64_t)row * D;
     const float* ar = add ? add + (int64_t)row * D : nullptr;
     float s = 0.f;
-    for (int c = lane; c < D; c += 64) s += xr[c] + (ar ? ar[c] : 0.f);
-    const float mean = wave_sum(s) / (float)D;
+    if (!rms)
+        for (int c = lane; c < D; c += 64) s += xr[c] + (ar ? ar[c] : 0.f);
+    const float mean = rms ? 0.f : wave_sum(s) / (float)D;      // RMSNorm: xhat = x * rsqrt(mean(x^2) + eps)
     float q = 0.f;
     for (int c = lane; c < D; c += 64) {
         const float v = xr[c] + (ar ? ar[c] : 0.f) - mean;
@@ -277,12 +278,13 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     }
 }
 
-extern "C" int devqa_layernorm_bwd_params(const float* x, const float* add, const float* dy, int M, int D, float eps, int accumulate,
+extern "C" int devqa_layernorm_bwd_params(const float* x, const float* add, const float* dy, int M, int D, float eps, int rms, int accumulate,
                                           float* dgamma, float* dbeta, float* stats_ws, void* stream) {
-    DEVQA_CHECK_ARG(x && dy && dgamma && dbeta && stats_ws, "layernorm_bwd_params: null pointer");
+    DEVQA_CHECK_ARG(x && dy && dgamma && stats_ws && (dbeta || rms), "layernorm_bwd_params: null pointer");
     DEVQA_CHECK_SHAPE(M >= 0 && D > 0, "layernorm_bwd_params: M=%d D=%d", M, D);
+    if (!dbeta) dbeta = stats_ws + 2 * (int64_t)(M > 0 ? M : 1);      // RMSNorm has no shift: the column sums go to scratch
     if (M > 0) {
-        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, M, D, eps, stats_ws);
+        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, M, D, eps, rms, stats_ws);
         DEVQA_LAUNCH_CHECK("layernorm_bwd_params(stats)");
     }
     hipLaunchKernelGGL(col_reduce_kernel<true>, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, add, dy, stats_ws, M, D, accumulate,

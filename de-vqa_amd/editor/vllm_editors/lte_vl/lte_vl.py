@@ -24,7 +24,9 @@ accumulates the parameter gradients (`Blip2Engine.decoder_backward(grads=...)`: 
 deterministic column reductions for biases and LayerNorm parameters), the tied embedding's gradient through the lm_head rows, the
 position table's through a one-hot GEMM, and `devqa_adam_step` on every parameter.  Checked against two steps of the reference's own
 loop body (tests/test_lte_gpu.py::test_lte_training_steps, tools/make_goldens_lte.py).  Needs the fp32 ("faithful") wrapper: at lr
-5e-6 an update is below the resolution of bf16 weights, and the reference trains in fp32.  OPT decoders (BLIP-2) only.
+5e-6 an update is below the resolution of bf16 weights, and the reference trains in fp32.  BLIP-2 (OPT) is pinned by the reference's
+own steps; LLaVA / MiniGPT-4 (LLaMA: RMSNorm, RoPE, SwiGLU, untied lm_head) run the same schedule through `LlavaEngine`'s backward and are
+checked against an autograd restatement over the oracle models (oracle/lte_oracle.py::train_a_batch, itself pinned on BLIP-2).
 """
 from dataclasses import dataclass
 from types import SimpleNamespace
@@ -183,14 +185,14 @@ class LTEvl(VLLMBaseEditorWithTraining):
 
     def _check_trainable(self):
         eng = self.vllm.engine
-        if type(eng).__name__ != "Blip2Engine":
-            raise NotImplementedError("LTE_VL training is built for OPT decoders (BLIP-2), not %s" % type(eng).__name__)
+        if not hasattr(eng, "train_params"):
+            raise NotImplementedError("LTE_VL training: %s has no all-parameter backward" % type(eng).__name__)
         if eng.adt != torch.float32:
             raise RuntimeError("LTE_VL training needs the fp32 wrapper (dtype='fp32'): at lr %g an Adam update is below the resolution "
                                "of bf16 weights; the reference trains in fp32" % self.cfg.train_config.lr)
-        if self.cfg.fine_tune_modules_path != "language_model":
-            raise NotImplementedError("LTE_VL training fine-tunes `language_model` (what the shipped configs select), not %r"
-                                      % (self.cfg.fine_tune_modules_path,))
+        if self.cfg.fine_tune_modules_path != eng.LM_MODULE:
+            raise NotImplementedError("LTE_VL training fine-tunes `%s` (what the shipped configs select), not %r"
+                                      % (eng.LM_MODULE, self.cfg.fine_tune_modules_path))
 
     def reinit_train_parameters(self):  # :163-164
         pass
@@ -218,19 +220,8 @@ class LTEvl(VLLMBaseEditorWithTraining):
         return {n: find_module(self.vllm.model, n) for n in self.cfg.fine_tune_modules_path}
 
     def _train_params(self):
-        """{full HF name: parameter} of the fine-tuned module, the q/k/v projections replaced by the fused operand they are row
-        blocks of (one Adam state per storage; elementwise the same update)."""
         self._check_trainable()
-        m = self.vllm.model
-        out = {}
-        for n, p_ in m.language_model.named_parameters():
-            name = "language_model." + n
-            if m._fused_slot(name) is None:
-                out[name] = p_.data
-        for layer, w in m.fused_qkv_w.items():
-            out["derived.dec_qkv.%s.weight" % layer] = w
-            out["derived.dec_qkv.%s.bias" % layer] = m.fused_qkv_b[layer]
-        return out
+        return self.vllm.engine.train_params()
 
     def get_a_new_optimizer(self):  # :195-198: Adam(lr), torch defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay)
         ps = self._train_params()
@@ -301,9 +292,7 @@ class LTEvl(VLLMBaseEditorWithTraining):
         ridx = torch.tensor(rows, dtype=torch.int32, device=dev)
         coef_t = torch.cat(coef).to(dev).contiguous()
         pre_ln = lib.gather_rows(x_fin, ridx)
-        hn = eng._ln(pre_ln, "language_model.model.decoder.final_layer_norm.weight", "language_model.model.decoder.final_layer_norm.bias", 1e-5)
-        emb_w = eng._p("language_model.model.decoder.embed_tokens.weight")
-        logits = lib.gemm(hn, emb_w, want="f32")
+        hn, logits = eng.head_fwd(pre_ln)
         n_lab = spans[n_label_groups - 1][1]
         _, nll, dlog = lib.vocab_rows(logits[:n_lab], torch.cat(labels).to(dev).contiguous(), coef_t[:n_lab].contiguous(), want_argmax=False,
                                       want_nll=True, want_dlogits=True, dlogits_dtype=torch.float32)
@@ -332,26 +321,15 @@ class LTEvl(VLLMBaseEditorWithTraining):
             for g in G.values():
                 g.zero_()
         dlog = dlog.contiguous()
-        # tied embedding: the lm_head's weight gradient dlogits^T . LN(h) (the inputs arrive as embeddings from the frozen copy)
-        eng.acc_linear_grads(G, "language_model.model.decoder.embed_tokens.weight", None, hn, dlog)
-        dH = lib.gemm(dlog, self.vllm.model.embed_T, want="f32")
-        lib.layernorm_bwd_params(pre_ln, dH, 1e-5, G["language_model.model.decoder.final_layer_norm.weight"],
-                                 G["language_model.model.decoder.final_layer_norm.bias"])
-        dxr = eng.final_norm_bwd(pre_ln, dH)
+        dxr = eng.head_bwd(pre_ln, hn, dlog, G)               # lm_head / tied embedding + final norm
         dx = torch.zeros_like(x_fin)
         dx.index_copy_(0, ridx.long(), dxr)
         _, dx0 = eng.decoder_backward(ps, save, dx, set(), grads=G)
-        # learned positions (OPT: row position + 2): one-hot^T . dx as a GEMM, deterministic
-        pos = (torch.cumsum(msk, 1) * msk - 1).reshape(-1).long() + 2
-        n_pos = P["language_model.model.decoder.embed_positions.weight"].shape[0]
-        onehot = torch.zeros((dx0.shape[0], n_pos), dtype=torch.float32, device=dev)
-        onehot[torch.arange(dx0.shape[0], device=dev), pos.clamp_(0, n_pos - 1)] = msk.reshape(-1).to(torch.float32)
-        eng.acc_linear_grads(G, "language_model.model.decoder.embed_positions.weight", None, dx0, onehot)
+        eng.embed_bwd(msk, dx0, G)                            # learned positions (OPT)
         # ---- Adam ----
         st["t"] += 1
         for n, p_ in P.items():
             lib.adam_step_(p_.reshape(-1), G[n].reshape(-1), st["m"][n].reshape(-1), st["v"][n].reshape(-1), tc.lr, st["t"], None)
         self.last_grads = G
-        eng.__dict__.pop("_wt_cache", None)                   # transposed operands of the backward are stale now
-        self.vllm.model.refresh_derived(force=True)           # embed_T
+        eng.after_param_update()
         return loss, log

@@ -406,6 +406,54 @@ class Blip2Engine:
         if bname is not None:
             lib.colsum_(d32, grads[bname], True)
 
+    # ---- full fine-tuning of the language model (LTE_VL training): what an editor needs beyond decoder_backward(grads=...) ----
+    LM_MODULE = "language_model"
+
+    def train_params(self):
+        """{name: fp32 storage} of every trainable parameter of the language model; the q / k / v projections appear as the fused
+        operand they are row blocks of ("derived.dec_qkv.<i>.weight" / ".bias": one optimizer state per storage)."""
+        m, out = self.m, {}
+        for n, p_ in getattr(m, self.LM_MODULE).named_parameters():
+            name = self.LM_MODULE + "." + n
+            if m._fused_slot(name) is None:
+                out[name] = p_.data
+        for layer, w in m.fused_qkv_w.items():
+            out["derived.dec_qkv.%s.weight" % layer] = w
+            out["derived.dec_qkv.%s.bias" % layer] = m.fused_qkv_b[layer]
+        return out
+
+    @torch.no_grad()
+    def head_fwd(self, pre_ln):
+        """rows before the final LayerNorm -> (normalised rows, fp32 logits)"""
+        hn = self._ln(pre_ln, "language_model.model.decoder.final_layer_norm.weight", "language_model.model.decoder.final_layer_norm.bias",
+                      LN_EPS_OPT)
+        return hn, lib.gemm(hn, self._p("language_model.model.decoder.embed_tokens.weight"), want="f32")
+
+    @torch.no_grad()
+    def head_bwd(self, pre_ln, hn, dlog, grads):
+        """dlogits [R, V] fp32 -> gradient rows w.r.t. pre_ln; accumulates the tied embedding (the lm_head's weight gradient
+        dlogits^T . LN(h): training inputs arrive as embeddings, so the input side contributes nothing) and the final LayerNorm."""
+        self.acc_linear_grads(grads, "language_model.model.decoder.embed_tokens.weight", None, hn, dlog)
+        dH = lib.gemm(dlog, self.m.embed_T, want="f32")
+        lib.layernorm_bwd_params(pre_ln, dH, LN_EPS_OPT, grads["language_model.model.decoder.final_layer_norm.weight"],
+                                 grads["language_model.model.decoder.final_layer_norm.bias"])
+        return self.final_norm_bwd(pre_ln, dH)
+
+    @torch.no_grad()
+    def embed_bwd(self, mask, dx0, grads):
+        """gradient w.r.t. the decoder input rows -> learned positions (OPT: position of a row + 2) as one-hot^T . dx on the GEMM"""
+        name = "language_model.model.decoder.embed_positions.weight"
+        n_pos = grads[name].shape[0]
+        msk = mask.to(torch.int64)
+        pos = ((torch.cumsum(msk, 1) * msk - 1).reshape(-1) + 2).clamp_(0, n_pos - 1)
+        onehot = torch.zeros((dx0.shape[0], n_pos), dtype=torch.float32, device=dx0.device)
+        onehot[torch.arange(dx0.shape[0], device=dx0.device), pos] = msk.reshape(-1).to(torch.float32)
+        self.acc_linear_grads(grads, name, None, dx0, onehot)
+
+    def after_param_update(self):
+        self.__dict__.pop("_wt_cache", None)        # transposed operands of the backward
+        self.m.refresh_derived(force=True)          # embed_T
+
     @torch.no_grad()
     def decoder_backward(self, ps: PackedSeqs, save, dx, capture, grads=None):
         """Backward through the saved decoder layers (highest first).  dx: fp32 [R, d] gradient w.r.t. the decoder

@@ -7,7 +7,7 @@ CLS -> multi_modal_projector -> splice at the `<image>` token) and :63-68 (langu
 import torch
 
 from . import lib
-from .engine import PackedSeqs, plan_image_chunks
+from .engine import Blip2Engine, PackedSeqs, plan_image_chunks
 
 
 class LlavaEngine:
@@ -262,10 +262,52 @@ class LlavaEngine:
             c[key] = getter().t().contiguous()
         return c[key]
 
+    # ---- full fine-tuning of the language model (LTE_VL training); see Blip2Engine ----
+    _padk = staticmethod(Blip2Engine._padk)
+    acc_linear_grads = Blip2Engine.acc_linear_grads
+
+    @property
+    def LM_MODULE(self):
+        return self.lm.rstrip(".")
+
+    def train_params(self):
+        """As Blip2Engine.train_params: fused q|k|v ("derived.llama_qkv.<i>") and gate|up ("derived.llama_gu.<i>") operands stand for
+        the projections that are their row blocks.  embed_tokens is listed and never receives a gradient (training inputs arrive as
+        embeddings; lm_head is not tied), exactly as in the reference, where Adam skips parameters without a gradient."""
+        m, out = self.m, {}
+        for n, p_ in getattr(m, self.LM_MODULE).named_parameters():
+            name = self.LM_MODULE + "." + n
+            if m._fused_slot(name) is None:
+                out[name] = p_.data
+        for key, w in m.fused_w.items():
+            if key.startswith("llama_"):
+                out["derived." + key] = w
+        return out
+
     @torch.no_grad()
-    def decoder_backward(self, ps, save, dx, capture):
+    def head_fwd(self, pre_ln):
+        hn = lib.rmsnorm(pre_ln, self._p(self.lm + "model.norm.weight"), self.eps, want=self.want)
+        return hn, lib.gemm(hn, self._w(self.lm + "lm_head.weight"), want="f32")
+
+    @torch.no_grad()
+    def head_bwd(self, pre_ln, hn, dlog, grads):
+        self.acc_linear_grads(grads, self.lm + "lm_head.weight", None, hn, dlog)
+        dH = lib.gemm(dlog, self.m.embed_T, want="f32")
+        lib.layernorm_bwd_params(pre_ln, dH, self.eps, grads[self.lm + "model.norm.weight"], None, rms=True)
+        return self.final_norm_bwd(pre_ln, dH)
+
+    def embed_bwd(self, mask, dx0, grads):
+        pass            # rotary positions: nothing learned on the input side
+
+    def after_param_update(self):
+        self.__dict__.pop("_wt_cache", None)
+        self.m.refresh_derived(force=True)
+
+    @torch.no_grad()
+    def decoder_backward(self, ps, save, dx, capture, grads=None):
         """Backward through the saved LLaMA layers (highest first); see Blip2Engine.decoder_backward.  Captures (input rows,
-        output-gradient rows) of the gate / up / down projections named in `capture`."""
+        output-gradient rows) of the gate / up / down projections named in `capture`; with `grads` every decoder-layer parameter
+        receives its gradient (fused q|k|v and gate|up operands under "derived.llama_qkv.<i>" / "derived.llama_gu.<i>")."""
         t, m = self.t, self.m
         d, H, F = t["hidden_size"], t["num_attention_heads"], t["intermediate_size"]
         dh = d // H
@@ -279,6 +321,8 @@ class LlavaEngine:
             dz = self._act(dx)
             if p + "mlp.down_proj" in capture:
                 out[p + "mlp.down_proj"] = (rec["a"], dx.clone())
+            if grads is not None:
+                self.acc_linear_grads(grads, p + "mlp.down_proj.weight", None, rec["a"], dx)
             da = lib.gemm(dz, self._wt(p + "down", lambda: self._w(p + "mlp.down_proj.weight")), want="f32")
             dd = deltas.get(p + "mlp.down_proj")
             if dd is not None:
@@ -289,19 +333,31 @@ class LlavaEngine:
                 out[p + "mlp.gate_proj"] = (rec["h2"], dgate)
             if p + "mlp.up_proj" in capture:
                 out[p + "mlp.up_proj"] = (rec["h2"], dup)
+            if grads is not None:
+                self.acc_linear_grads(grads, "derived.llama_gu.%d" % i, None, rec["h2"], dgu)
             dh2 = lib.gemm(self._act(dgu), self._wt(p + "gu", lambda: m.fused_w["llama_gu.%d" % i]), want="f32")
             for e, g in ((deltas.get(p + "mlp.gate_proj"), dgate), (deltas.get(p + "mlp.up_proj"), dup)):
                 if e is not None:
                     lib.gemm(lib.gemm(self._act(g), e["dt"]), e["xtT"], residual=dh2, out_f32=dh2)
             dy = lib.rmsnorm_bwd_dx(rec["x_mid"], self._p(p + "post_attention_layernorm.weight"), dh2, self.eps)
+            if grads is not None:
+                lib.layernorm_bwd_params(rec["x_mid"], dh2, self.eps, grads[p + "post_attention_layernorm.weight"], None, rms=True)
             lib.delta_op(1, dy, None, dx)
+            if grads is not None:
+                self.acc_linear_grads(grads, p + "self_attn.o_proj.weight", None, rec["att"], dy)
             datt = lib.gemm(self._act(dy), self._wt(p + "o", lambda: self._w(p + "self_attn.o_proj.weight")))
             qkv = rec["qkv"]
             dq, dk, dv = lib.attention_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], rec["att"], datt, ps.desc, n_seq,
                                            ps.max_len, H, dh, dh ** -0.5, 1)
             dqk = torch.cat([dq, dk], 1).contiguous()
             lib.rope_(dqk, neg_pos, 2 * H, dh, self.theta)            # the rotation's transpose = rotation by -pos
-            dh1 = lib.gemm(torch.cat([dqk, dv], 1), self._wt(p + "qkv", lambda: m.fused_w["llama_qkv.%d" % i]), want="f32")
+            dqkv = torch.cat([dqk, dv], 1)
+            if grads is not None:
+                h1 = lib.rmsnorm(rec["x_in"], self._p(p + "input_layernorm.weight"), self.eps, want=self.want)
+                self.acc_linear_grads(grads, "derived.llama_qkv.%d" % i, None, h1, dqkv)
+            dh1 = lib.gemm(dqkv, self._wt(p + "qkv", lambda: m.fused_w["llama_qkv.%d" % i]), want="f32")
+            if grads is not None:
+                lib.layernorm_bwd_params(rec["x_in"], dh1, self.eps, grads[p + "input_layernorm.weight"], None, rms=True)
             dx = lib.rmsnorm_bwd_dx(rec["x_in"], self._p(p + "input_layernorm.weight"), dh1, self.eps)
             lib.delta_op(1, dx, None, dy)
         return out, dx

@@ -66,7 +66,7 @@ def load():
     _sig(L.devqa_cast_f32_bf16, [P, P, I64, P])
     _sig(L.devqa_vocab_rows, [P, I64, I, I, P, P, P, P, P, I64, P])
     _sig(L.devqa_layernorm_bwd_dx, [P, P, P, P, I, I, F, P, P])
-    _sig(L.devqa_layernorm_bwd_params, [P, P, P, I, I, F, I, P, P, P, P])
+    _sig(L.devqa_layernorm_bwd_params, [P, P, P, I, I, F, I, I, P, P, P, P])
     _sig(L.devqa_colsum_f32, [P, I, I, I, P, P])
     _sig(L.devqa_ft_adamw_step, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I64, P])
     _sig(L.devqa_active_columns, [P, I, I, I, P, P, P])
@@ -380,14 +380,17 @@ def layernorm_bwd_dx(x, gamma, dy, eps, add=None):
     return dx
 
 
-def layernorm_bwd_params(x, dy, eps, dgamma, dbeta, add=None, accumulate=True):
-    """dgamma (+)= sum_r dy * xhat(x [+ add]), dbeta (+)= sum_r dy over the rows of fp32 [M, D] (in place)."""
+def layernorm_bwd_params(x, dy, eps, dgamma, dbeta, add=None, accumulate=True, rms=False):
+    """dgamma (+)= sum_r dy * xhat(x [+ add]), dbeta (+)= sum_r dy over the rows of fp32 [M, D] (in place).  rms: LlamaRMSNorm's xhat
+    (no mean subtraction), dbeta may be None."""
     M, D = x.shape
-    _need(x, torch.float32, "x"); _need(dy, torch.float32, "dy"); _need(dgamma, torch.float32, "dgamma"); _need(dbeta, torch.float32, "dbeta")
-    assert dy.shape == x.shape and dgamma.numel() == D and dbeta.numel() == D
-    ws = torch.empty((max(M, 1), 2), dtype=torch.float32, device=x.device)
-    _chk(load().devqa_layernorm_bwd_params(_p(x), _p(add), _p(dy), M, D, float(eps), int(bool(accumulate)), _p(dgamma), _p(dbeta), _p(ws),
-                                           _stream()), "devqa_layernorm_bwd_params")
+    _need(x, torch.float32, "x"); _need(dy, torch.float32, "dy"); _need(dgamma, torch.float32, "dgamma")
+    assert dy.shape == x.shape and dgamma.numel() == D and (dbeta is None or dbeta.numel() == D) and (rms or dbeta is not None)
+    if dbeta is not None:
+        _need(dbeta, torch.float32, "dbeta")
+    ws = torch.empty((2 * max(M, 1) + D,), dtype=torch.float32, device=x.device)
+    _chk(load().devqa_layernorm_bwd_params(_p(x), _p(add), _p(dy), M, D, float(eps), int(bool(rms)), int(bool(accumulate)), _p(dgamma),
+                                           _p(dbeta), _p(ws), _stream()), "devqa_layernorm_bwd_params")
 
 
 def colsum_(x, out, accumulate=True):

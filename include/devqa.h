@@ -278,8 +278,9 @@ int devqa_layernorm_bwd_dx(const float* x, const float* add, const float* gamma,
 
 /* LayerNorm backward w.r.t. gamma / beta over M rows (autograd through nn.LayerNorm in full fine-tuning: LTE_VL training,
  * R/editor/vllm_editors/lte_vl/lte_vl.py:207-233): dgamma[c] (+)= sum_r dy[r,c] * xhat[r,c], dbeta[c] (+)= sum_r dy[r,c], xhat from
- * x (+ add).  stats_ws: 2 * M floats of scratch.  Deterministic.  devqa_colsum_f32: out[c] (+)= sum_r x[r,c] (bias gradients). */
-int devqa_layernorm_bwd_params(const float* x, const float* add, const float* dy, int M, int D, float eps, int accumulate,
+ * x (+ add).  rms != 0: LlamaRMSNorm (xhat = x * rsqrt(mean(x^2) + eps); dbeta may be nullptr).  stats_ws: 2 * M + D floats of scratch.
+ * Deterministic.  devqa_colsum_f32: out[c] (+)= sum_r x[r,c] (bias gradients). */
+int devqa_layernorm_bwd_params(const float* x, const float* add, const float* dy, int M, int D, float eps, int rms, int accumulate,
                                float* dgamma, float* dbeta, float* stats_ws, void* stream);
 int devqa_colsum_f32(const float* x, int M, int D, int accumulate, float* out, void* stream);
 

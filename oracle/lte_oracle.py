@@ -70,3 +70,75 @@ class OracleLTEvl:
         cat = {"attention_mask": torch.cat([prefix["attention_mask"], x["attention_mask"]], 1),
                "inputs_embeds": torch.cat([prefix["inputs_embeds"], x["inputs_embeds"]], 1)}     # :123-127
         return self.plain_get_llm_outpt(cat, None)[:, prefix["attention_mask"].shape[1]:]
+
+
+# ---- training (R/editor/vllm_editors/lte_vl/lte_vl.py:152-233) -------------------------------------------------------------------
+def logit_KL_loss(logits1, logits2, masks):  # lte_vl.py:254-265
+    L = masks.shape[1]
+    l1, l2 = logits1[:, -L:], logits2[:, -L:]
+    kl = (torch.softmax(l1, 2) * (torch.log_softmax(l1, -1) - torch.log_softmax(l2, -1))).sum(2)
+    return (kl * masks).sum() / masks.sum()
+
+
+class OracleLTETrainer:
+    """The reference's training step restated with autograd + torch.optim.Adam over an oracle model: `organize_batch_data` (:169-187)
+    on a FROZEN copy of the weights (the reference's `vllm_proc_data`), `train_a_batch` (:203-233) on the trained ones.  Pinned on
+    BLIP-2 by two steps of the reference's own loop (tests/test_oracle_lte.py::test_lte_oracle_training_matches_reference_goldens); the
+    LLaVA / MiniGPT-4 GPU tests use it as the checker for the LLaMA-family backward."""
+
+    def __init__(self, model, lm_prefix, lr, relia_lambda=1.0, gen_lambda=1.0, loc_lambda=1.0):
+        from copy import copy
+        from oracle.devqa_oracle import label_loss
+        self.label_loss = label_loss
+        self.model = model
+        self.frozen = copy(model)                         # shares tokenizer / config, private weight dict
+        self.frozen.w = {k: v.detach().clone() for k, v in model.w.items()}
+        self.names = [n for n in model.w if n.startswith(lm_prefix)]
+        for n in self.names:
+            model.w[n] = model.w[n].detach().clone().requires_grad_(True)
+        self.opt = torch.optim.Adam([model.w[n] for n in self.names], lr=lr)
+        self.lam = (relia_lambda, gen_lambda, loc_lambda)
+
+    @staticmethod
+    def edit_prefix(model, request):  # :112-121
+        p, t = request["prompt"], request["target_new"]
+        if p[-1] != " " and t[0] != " ":
+            t = " " + t
+        return model.get_llm_input_embeds([OracleLTEvl.edit_sign + p + t + OracleLTEvl.query_sign], [request["image"]])[0]
+
+    def organize_batch_data(self, d):
+        f = self.frozen
+        with torch.no_grad():
+            prefix = self.edit_prefix(f, d["requests"][0])
+            rel = f.prompts_imgs_target_to_xym([d["requests"][0]["prompt"]], [d["requests"][0]["image"]], [d["requests"][0]["target_new"]])
+            gen = {k: f.prompts_imgs_target_to_xym([v[0]["prompt"]], [v[0]["image"]], [v[0]["target"]]) for k, v in d["generality"].items()}
+            loc = {}
+            for k, v in d["locality"].items():
+                (x, vt), y, m = f.prompts_imgs_target_to_xym([v[0]["prompt"]], [v[0]["image"]], [v[0]["target"]])
+                loc[k] = ((x, vt), f.get_llm_outpt(x, vt), m)
+        return prefix, rel, gen, loc
+
+    def train_a_batch(self, batch):
+        prefix, rel, gen, loc = batch
+        mdl = self.model
+
+        def edited(x):
+            cat = {"attention_mask": torch.cat([prefix["attention_mask"], x["attention_mask"]], 1),
+                   "inputs_embeds": torch.cat([prefix["inputs_embeds"], x["inputs_embeds"]], 1)}
+            return mdl.get_llm_outpt(cat, None)
+        (x, vt), y, m = rel
+        rel_loss = self.label_loss(edited(x), y, m)
+        loss = rel_loss * self.lam[0]
+        gen_losses, loc_losses = {}, {}
+        for k, ((x, vt), y, m) in gen.items():
+            g = self.label_loss(edited(x), y, m)
+            gen_losses[k] = float(g.detach())
+            loss = loss + g * self.lam[1]
+        for k, ((x, vt), pre, m) in loc.items():
+            l_ = (logit_KL_loss(pre, mdl.get_llm_outpt(x, vt), m) + logit_KL_loss(pre, edited(x), m)) / 2
+            loc_losses[k] = float(l_.detach())
+            loss = loss + l_ * self.lam[2]
+        loss.backward()
+        self.opt.step()
+        self.opt.zero_grad()
+        return float(loss.detach()), {"Reliability loss": float(rel_loss.detach()), "Generality loss": gen_losses, "Locality loss": loc_losses}

@@ -72,12 +72,8 @@ def test_lte_needs_encoder(lte):
         LTEvl(vllm, ed.cfg, "cuda:0")
     ed.wrap_get_llm_outpt()     # the failed constructor never reached the hook; re-wrapping keeps ONE layer over the original
     assert ed.name_of_editor_and_model()[0] == "lte_vl" and not ed.if_can_batch_edit()
-    # training: OPT decoders in fp32 only (lr 5e-6 is below bf16 resolution; LLaMA-family backward of ALL parameters is not built)
-    kind = type(vllm.engine).__name__
-    if kind != "Blip2Engine":
-        with pytest.raises(NotImplementedError):
-            ed.set_train(True)
-    elif lte[5] != "fp32":
+    # training needs the fp32 wrapper (lr 5e-6 is below bf16 resolution)
+    if lte[5] != "fp32":
         with pytest.raises(RuntimeError):
             ed.set_train(True)
     else:
@@ -416,3 +412,73 @@ def test_lte_training_through_the_abc(lte, gold_dir, in_gold_dir, tmp_path):
     (x1, vt1), _, _ = tv.prompts_imgs_target_to_xym([r["prompt"]], [r["image"]], [r["target_new"]])
     b = tv.get_llm_outpt(x1, vt1).logits
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("fam", ["llava", "minigpt4"])
+def test_lte_training_llama_family_vs_oracle(fam, gold_dir, in_gold_dir):
+    """LTE_VL training on the LLaMA-family decoders (RMSNorm, RoPE, SwiGLU, untied lm_head; R/configs/lte_vl/llava-v1.5-7b.yaml and
+    minigpt-4-vicuna-7b.yaml fine-tune `language_model` / `llama_model`): two steps against the autograd restatement
+    oracle.lte_oracle.OracleLTETrainer, which tests/test_oracle_lte.py pins on BLIP-2 with the reference's own steps.  PARITY UNPINNED
+    by the reference for these two models (its wrappers do not run on the installed transformers)."""
+    import devqa_amd  # noqa: F401
+    from devqa_amd.editor.vllm_editors.lte_vl.lte_vl import LTEvl
+    from oracle.lte_oracle import OracleLTETrainer
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))["records"]
+    if fam == "llava":
+        from devqa_amd.editor.vllms_for_edit.llava.llava import LlavaForEdit
+        from oracle.llava_oracle import OracleLlava
+        mk = lambda: LlavaForEdit(os.path.join(gold_dir, "tiny_llava"), "cuda:0", True, dtype="fp32")  # noqa: E731
+        orc = OracleLlava.from_pretrained_dir(os.path.join(gold_dir, "tiny_llava"))
+        cfg, lm = _cfg("llava"), "language_model."
+    else:
+        from transformers import AutoTokenizer
+        from devqa_amd import minigpt4_spec as S
+        from devqa_amd.synth import param_init
+        from devqa_amd.editor.vllms_for_edit.minigpt4.minigpt4 import MiniGPT4ForEdit
+        from devqa_amd.editor.vllms_for_edit.minigpt4.modeling import MiniGPT4Native
+        from oracle.devqa_oracle import OracleTokenizer
+        from oracle.minigpt4_oracle import OracleMiniGPT4
+        mcfg = S.TINY_MINIGPT4
+        tok = AutoTokenizer.from_pretrained(os.path.join(gold_dir, "tiny_llava"))
+        mk = lambda: MiniGPT4ForEdit(None, "cuda:0", True, model=MiniGPT4Native.from_synth(mcfg, 31, "unit", "cuda:0", "fp32"),  # noqa: E731
+                                     tokenizer=tok, dtype="fp32")
+        w = {n: torch.from_numpy(param_init(n, s_, 31, "unit")) for n, s_ in S.param_shapes(mcfg).items()}
+        otok = OracleTokenizer(os.path.join(gold_dir, "tiny_llava", "tokenizer.json"), mcfg["text_config"]["pad_token_id"])
+        orc = OracleMiniGPT4(w, mcfg, otok)
+        cfg, lm = _cfg("minigpt4"), "llama_model."
+    assert cfg.fine_tune_modules_path == lm.rstrip(".")
+    tv, frozen = mk(), mk()
+    ted = LTEvl(tv, cfg, "cuda:0", vllm_proc_data=frozen, device_proc_data="cuda:0", encode=bow_encode)
+    tr = OracleLTETrainer(orc, lm, cfg.train_config.lr, cfg.train_config.relia_lambda, cfg.train_config.gen_lambda, cfg.train_config.loc_lambda)
+    w0 = {n: p_.detach().clone() for n, p_ in tv.model.named_parameters()}
+    ted.set_train(True)
+    ted.opt = ted.get_a_new_optimizer()
+    lr = cfg.train_config.lr
+    for step, ri in enumerate((1, 2)):
+        loss, log = ted.train_a_batch(ted.organize_batch_data([deepcopy(rec[ri])]))
+        oloss, olog = tr.train_a_batch(tr.organize_batch_data(deepcopy(rec[ri])))
+        assert abs(loss - oloss) < 1e-3 * abs(oloss), (loss, oloss)
+        for k in olog["Locality loss"]:
+            assert abs(log["Locality loss"][k] - olog["Locality loss"][k]) < 1e-3 * max(olog["Locality loss"][k], 1e-2)
+        worst, moved = 0.0, 0
+        sd = dict(tv.model.named_parameters())
+        for n in tr.names:
+            d_ref = (orc.w[n].detach() - w0[n].float().cpu()).double().reshape(-1)
+            d_got = (sd[n].detach().float().cpu() - w0[n].float().cpu()).double().reshape(-1)
+            if n.endswith("k_proj.weight") or n.endswith("embed_tokens.weight"):
+                # embed_tokens: no gradient on either side (inputs arrive as embeddings) -> untouched;  k_proj (no bias in LLaMA) is a
+                # regular parameter here, compared below like the rest
+                pass
+            if float(d_ref.abs().max()) == 0.0:
+                assert float(d_got.abs().max()) == 0.0, n
+                continue
+            moved += 1
+            e_all = (d_got - d_ref).abs().numpy() / ((step + 1) * lr)
+            err = float(e_all.max())
+            worst = max(worst, err)
+            # Adam's update lr * g / (|g| + 1e-8) amplifies gradient rounding noise (~1e-9) on the few elements whose gradient is of
+            # the size of eps: those may differ by ~10 % of lr; everything else agrees to a fraction of a percent
+            assert err < 0.25 and float(np.quantile(e_all, 0.999)) < 0.02, (n, err, float(np.quantile(e_all, 0.999)))
+        print(fam, "step", step, "loss", loss, "oracle", oloss, "params moved", moved, "worst |delta - delta_ref| / (steps * lr) = %.3g" % worst)
+        assert moved >= len(tr.names) - 1
+    ted.set_train(False)

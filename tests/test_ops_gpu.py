@@ -467,6 +467,13 @@ def test_layernorm_param_grads_and_colsum(L):
         dg3, db3 = torch.empty(D, device="cuda"), torch.empty(D, device="cuda")
         L.layernorm_bwd_params(dev(x), dev(dy), 1e-5, dg3, db3, add=dev(add), accumulate=False)
         assert torch.equal(dg2, dg3) and torch.equal(db2, db3)
+        # LlamaRMSNorm: xhat = x * rsqrt(mean(x^2) + eps), weight only
+        wr = torch.ones(D, dtype=torch.float64, requires_grad=True)
+        yr = xd * torch.rsqrt((xd * xd).mean(-1, keepdim=True) + 1e-6) * wr
+        (yr * dy.double()).sum().backward()
+        dgr = torch.zeros(D, device="cuda")
+        L.layernorm_bwd_params(dev(x), dev(dy), 1e-6, dgr, None, add=dev(add), accumulate=True, rms=True)
+        np.testing.assert_allclose(dgr.cpu().numpy(), wr.grad.float().numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
         cs = torch.zeros(D, device="cuda")
         L.colsum_(dev(dy), cs, True)
         L.colsum_(dev(dy), cs, True)

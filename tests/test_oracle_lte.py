@@ -115,3 +115,27 @@ def test_lte_oracle_matches_reference_goldens(gold_dir, in_gold_dir):
         assert len(a) == len(b) == 48
         assert [x[1] for x in a] == [x[1] for x in b]
         assert [x[0] for x in a] == [x[0] for x in b]
+
+
+def test_lte_oracle_training_matches_reference_goldens(gold_dir, in_gold_dir):
+    """oracle.lte_oracle.OracleLTETrainer against two steps of the reference's own `train_a_batch` (tools/make_goldens_lte.py)."""
+    from oracle.lte_oracle import OracleLTETrainer
+    j = json.load(open(os.path.join(gold_dir, "tiny_lte_goldens.json")))
+    z = np.load(os.path.join(gold_dir, "tiny_lte_goldens.npz"))
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))["records"]
+    model = _model(gold_dir)
+    w0 = {k: v.detach().clone() for k, v in model.w.items()}
+    tr = OracleLTETrainer(model, "language_model.", j["lr"])
+    for step, g in enumerate(j["train"]):
+        loss, log = tr.train_a_batch(tr.organize_batch_data(deepcopy(rec[g["record"]])))
+        assert abs(loss - g["loss"]) < 1e-4 * g["loss"]
+        for k in g["log"]["Locality loss"]:
+            assert abs(log["Locality loss"][k] - g["log"]["Locality loss"][k]) < 1e-4 * max(g["log"]["Locality loss"][k], 1e-2)
+        for n in j["train_param_names"]:
+            full = "language_model." + n
+            key = "train_s%d_w_%s" % (step, n)
+            if key not in z.files or n.endswith("k_proj.bias"):        # k_proj.bias: exactly-zero gradient, noise-driven Adam drift
+                continue
+            d_ref = z[key].astype(np.float64) - w0[full].numpy().reshape(-1)[:4096]
+            d_got = model.w[full].detach().numpy().reshape(-1)[:4096].astype(np.float64) - w0[full].numpy().reshape(-1)[:4096]
+            assert np.abs(d_got - d_ref).max() < 0.06 * (step + 1) * j["lr"], n
