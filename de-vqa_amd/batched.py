@@ -23,6 +23,7 @@ Multi-GPU: static contiguous block partition of splits over ran
 data-path collective; one gather of per-cycle score rows [n,16] fp32 (RCCL) plus a host-side
 gather of the decoded strings for results.json.
 """
+import os
 import time
 from copy import deepcopy
 from typing import Dict, List
@@ -163,7 +164,7 @@ class BatchedEditEval:
             return [self.run_batch(r, e) for r, e in batches]
         side = self.__dict__.get("_side_stream")
         if side is None:
-            side = self._side_stream = torch.cuda.Stream(device=self.eng.dev)
+            side = self._side_stream = torch.cuda.Stream(device=self.eng.dev, priority=int(os.environ.get("DEVQA_SIDE_PRIORITY", "0")))
         outs = []
         ctx = self._stage_a(*batches[0])
         for i in range(len(batches)):
@@ -281,7 +282,7 @@ class BatchedEditEval:
                 end = ps.start[p.seq] + ps.length[p.seq]
                 row_idx += list(range(end - p.L, end))
             cyc_rows.append((r0, len(row_idx)))
-        ridx = torch.tensor(row_idx, dtype=torch.int32, device=dev)
+        ridx = lib.h2d(row_idx, torch.int32, dev)     # pinned + non-blocking: a pageable copy would park the host behind the queued vision encoder
         a_tail = lib.gather_rows(a, ridx)                     # operand dtype [R, ffn]
         resid_tail = lib.gather_rows(x_mid, ridx)             # fp32 [R, d]
         # FT rows
@@ -297,9 +298,9 @@ class BatchedEditEval:
                     mask[e, j] = 1.0
                 else:
                     ft_idx.append(end - 1)  # padding row: mask 0 -> coef 0 -> no gradient
-        fidx = torch.tensor(ft_idx, dtype=torch.int32, device=dev)
+        fidx = lib.h2d(ft_idx, torch.int32, dev)
         a_ft = lib.gather_rows(a, fidx).to(torch.float32).view(E, kmax, -1).contiguous()
-        a_ft = a_ft * torch.from_numpy(mask).to(dev).unsqueeze(-1)   # zero the padding rows (plumbing)
+        a_ft = a_ft * lib.h2d(mask, torch.float32, dev).unsqueeze(-1)   # zero the padding rows (plumbing)
         resid_ft = lib.gather_rows(x_mid, fidx)                      # [E*kmax, d] (+ fc2 bias when the model has one)
         if b2 is not None:
             resid_ft = (resid_ft + b2).contiguous()
@@ -418,8 +419,8 @@ class BatchedEditEval:
             w0 = lib.gather_cols(w0, idx, cnt, npad, per_edit=False)        # [E, Dout, npad] pristine columns
             a_ft = lib.gather_cols(a_ft, idx, cnt, npad, per_edit=True)      # [E, kmax, npad]
         self.stats["npad_sum"] = self.stats.get("npad_sum", 0) + npad * E
-        t_lab = torch.from_numpy(labels.reshape(-1)).to(dev)
-        t_mask = torch.from_numpy(mask).to(dev)
+        t_lab = lib.h2d(labels.reshape(-1), torch.int32, dev)
+        t_mask = lib.h2d(mask, torch.float32, dev)
         clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else -1.0
         ctx = eng.path_ctx() if hasattr(eng, "path_ctx") else None
         if ctx is not None:     # the same loop behind the C ABI (devqa_ft_edit): one call, no Python between the steps

@@ -264,13 +264,13 @@ class Blip2Engine:
             length.append(n)
             r += n
         dev = self.dev
-        t_tok = torch.tensor(tok, dtype=torch.int32, device=dev)
-        t_src = torch.tensor(src, dtype=torch.int32, device=dev)
-        t_pos = torch.tensor(pos, dtype=torch.int32, device=dev)
+        t_tok = lib.h2d(tok, torch.int32, dev)
+        t_src = lib.h2d(src, torch.int32, dev)
+        t_pos = lib.h2d(pos, torch.int32, dev)
         rows = None if img_tokens is None else img_tokens.reshape(-1, img_tokens.shape[-1]).contiguous()
         x = lib.embed_rows(t_tok, t_src, t_pos, self._p("language_model.model.decoder.embed_tokens.weight"), rows,
                            self._p("language_model.model.decoder.embed_positions.weight"))
-        desc = torch.tensor([[s, n, 0, 0, s, n] for s, n in zip(start, length)], dtype=torch.int32, device=dev)
+        desc = lib.h2d([[s, n, 0, 0, s, n] for s, n in zip(start, length)], torch.int32, dev)
         return PackedSeqs(x, start, length, desc, max(length), True)
 
     def _pack_shared_prefix(self, seqs, img_tokens):
@@ -303,11 +303,11 @@ class Blip2Engine:
             r += n
         dev = self.dev
         rows = None if img_tokens is None else img_tokens.reshape(-1, img_tokens.shape[-1]).contiguous()
-        x = lib.embed_rows(torch.tensor(tok, dtype=torch.int32, device=dev), torch.tensor(src, dtype=torch.int32, device=dev),
-                           torch.tensor(pos, dtype=torch.int32, device=dev),
+        x = lib.embed_rows(lib.h2d(tok, torch.int32, dev), lib.h2d(src, torch.int32, dev),
+                           lib.h2d(pos, torch.int32, dev),
                            self._p("language_model.model.decoder.embed_tokens.weight"), rows,
                            self._p("language_model.model.decoder.embed_positions.weight"))
-        ps = PackedSeqs(x, start, length, torch.tensor(desc, dtype=torch.int32, device=dev), max(max(length), Qn), True)
+        ps = PackedSeqs(x, start, length, lib.h2d(desc, torch.int32, dev), max(max(length), Qn), True)
         ps.n_seq = len(desc)
         return ps
 

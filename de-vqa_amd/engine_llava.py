@@ -168,12 +168,12 @@ class LlavaEngine:
                 desc.append([r, n, 0, 0, r, n])
                 r += n
         dev = self.dev
-        t_pos = torch.tensor(pos, dtype=torch.int32, device=dev)
+        t_pos = lib.h2d(pos, torch.int32, dev)
         rows = None if img_tokens is None else img_tokens.reshape(-1, img_tokens.shape[-1]).contiguous()
         emb = self.embed_table()
-        x = lib.embed_rows(torch.tensor(tok, dtype=torch.int32, device=dev), torch.tensor(src, dtype=torch.int32, device=dev),
+        x = lib.embed_rows(lib.h2d(tok, torch.int32, dev), lib.h2d(src, torch.int32, dev),
                            torch.full((len(tok),), -2, dtype=torch.int32, device=dev), emb, rows, self._zero_pos(emb))
-        ps = PackedSeqs(x, start, length, torch.tensor(desc, dtype=torch.int32, device=dev),
+        ps = PackedSeqs(x, start, length, lib.h2d(desc, torch.int32, dev),
                         max(max(length), max([d_[1] for d_ in desc])))
         ps.pos = t_pos
         return ps
