@@ -156,21 +156,32 @@ class BatchedEditEval:
         return self._stage_b(self._stage_a(rds, eds))
 
     def run_batches(self, batches, pipelined=True):
-        """batches: list of (rds, eds).  Software pipeline over two HIP streams: stage A of batch i+1 (host bookkeeping,
-        vision encoder, frozen decoder prefix: the MFMA-heavy part) is queued on the current stream BEFORE stage B of
-        batch i (pre-edit tails, the FT_VL loop, post-edit tails: many small launches that leave most CUs idle) is queued
-        on a side stream, so the GPU runs them concurrently.  Same kernels, same results as run_batch per batch."""
+        """batches: list of (rds, eds).  Software pipeline: the host runs ONE BATCH AHEAD of the GPU and never waits inside the loop --
+        stage A of batch i+1 (host bookkeeping, vision encoder, frozen decoder prefix: the MFMA-heavy part) is queued, then stage B of
+        batch i (pre-edit tails, the FT_VL loop, post-edit tails: many small launches), whose results come back through pinned
+        buffers and are decoded one iteration later, when they have long arrived.  Same kernels, same results as run_batch per batch.
+        Two placements of stage B (DEVQA_PIPELINE):
+          serial      (default) on the main stream behind stage A of the next batch: no kernel of B shares the GPU with the GEMMs;
+          concurrent  on a side stream, so B's small launches fill the CUs the GEMMs' tail rounds leave idle: +1.5 % cycles/s with the
+                      column-compacted FT loop, but -24 % with dense FFN activations (the 22 GB AdamW sweeps and the GEMMs evict each
+                      other from L2 / MALL), and every kernel's in-situ time then includes the other stream's share of the GPU."""
         if not pipelined or len(batches) < 2:
             return [self.run_batch(r, e) for r, e in batches]
-        side = self.__dict__.get("_side_stream")
-        if side is None:
-            side = self._side_stream = torch.cuda.Stream(device=self.eng.dev, priority=int(os.environ.get("DEVQA_SIDE_PRIORITY", "0")))
+        side = None
+        if os.environ.get("DEVQA_PIPELINE", "serial") == "concurrent":
+            side = self.__dict__.get("_side_stream")
+            if side is None:
+                side = self._side_stream = torch.cuda.Stream(device=self.eng.dev)
         outs = []
         ctx = self._stage_a(*batches[0])
+        pending = None
         for i in range(len(batches)):
             nxt = self._stage_a(*batches[i + 1]) if i + 1 < len(batches) else None
-            outs.append(self._stage_b(ctx, side))
-            ctx = nxt
+            handle = self._stage_b(ctx, side, finish=False)
+            if pending is not None:
+                outs.append(self._stage_b_finish(pending))
+            pending, ctx = handle, nxt
+        outs.append(self._stage_b_finish(pending))
         return outs
 
     @torch.no_grad()
@@ -305,19 +316,32 @@ class BatchedEditEval:
         if b2 is not None:
             resid_ft = (resid_ft + b2).contiguous()
         del a, x_mid
+        # active columns of every edit (column compaction of the FT loop): counted HERE, with the largest count on its way to a pinned
+        # word, so that stage B can size its state without a device -> host read in the middle of the queued work
+        act = None
+        if cfg.weight_decay == 0:
+            idx, cnt = lib.active_columns(a_ft)
+            mx = torch.empty((1,), dtype=torch.int32, device="cpu", pin_memory=True)
+            mx.copy_(cnt.max().reshape(1), non_blocking=True)
+            act_ev = torch.cuda.Event()
+            act_ev.record()
+            act = (idx, cnt, mx, act_ev)
         ev[2].record()
         return dict(rds=rds, probes=probes, E=E, kmax=kmax, d=d, b2=b2, w0=w0, w0_op=w0_op, cyc_rows=cyc_rows, a_tail=a_tail,
-                    resid_tail=resid_tail, a_ft=a_ft, resid_ft=resid_ft, labels=labels, mask=mask, ev=ev)
+                    resid_tail=resid_tail, a_ft=a_ft, resid_ft=resid_ft, labels=labels, mask=mask, ev=ev, act=act)
 
     @torch.no_grad()
-    def _stage_b(self, c, stream=None):
-        """Stage B on `stream` (None: the current stream).  The tensors of stage A stay referenced by `c` until the
-        stream has been synchronised at the end, so the caching allocator cannot hand them out early."""
+    def _stage_b(self, c, stream=None, finish=True):
+        """Stage B on `stream` (None: the current stream).  The tensors of stage A stay referenced by the returned handle until its
+        results have been collected, so the caching allocator cannot hand them out early.  finish=False: returns the handle for
+        _stage_b_finish instead of waiting for the results."""
         if stream is None:
-            return self._stage_b_body(c)
-        stream.wait_event(c["ev"][2])
-        with torch.cuda.stream(stream):
-            return self._stage_b_body(c)
+            h = self._stage_b_body(c)
+        else:
+            stream.wait_event(c["ev"][2])
+            with torch.cuda.stream(stream):
+                h = self._stage_b_body(c)
+        return self._stage_b_finish(h) if finish else h
 
     def _stage_b_body(self, c):
         eng, vllm, cfg = self.eng, self.vllm, self.editor.cfg
@@ -331,7 +355,7 @@ class BatchedEditEval:
         pre_argmax = self._argmax_from_y(y_pre, "pre")
         # ---- 5. FT loop (on the active columns of each edit) --------------------------------------------
         evb[1].record()
-        n_steps, losses, delta_c, idx, cnt, npad = self._ft_loop(w0, a_ft, resid_ft, labels, mask, E, kmax, d, cfg)
+        n_steps, losses, delta_c, idx, cnt, npad = self._ft_loop(w0, a_ft, resid_ft, labels, mask, E, kmax, d, cfg, c.get("act"))
         evb[2].record()
         # ---- 6. post-edit tail:  y_post = y_pre + (dW_e restricted to its active columns) . a -------------
         delta_op = delta_c if eng.adt == torch.float32 else lib.cast_f32_bf16(delta_c)  # [E, d, npad]
@@ -344,12 +368,23 @@ class BatchedEditEval:
             self.debug["delta"] = (delta_c, idx, cnt, npad)
             self.debug["rows"] = [[(p.kind, p.name, p.row0, p.L) for p in plist] for plist in probes]
         evb[3].record()
-        pre_h = pre_argmax.cpu().numpy()
-        post_h = post_argmax.cpu().numpy()
-        steps_h = n_steps.cpu().numpy()
-        losses_h = losses.cpu().numpy()
-        upd_h = self._adam_t.cpu().numpy()
-        torch.cuda.current_stream().synchronize()
+
+        def to_host(t):      # asynchronous device -> pinned host copy on this stream
+            hbuf = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+            hbuf.copy_(t, non_blocking=True)
+            return hbuf
+        host = [to_host(t) for t in (pre_argmax, post_argmax, n_steps, losses, self._adam_t)]
+        done = torch.cuda.Event()
+        done.record()
+        return dict(c=c, evb=evb, host=host, done=done, ft_shape=self._ft_shape, keep=(y_pre, delta_c, idx, cnt))
+
+    def _stage_b_finish(self, h):
+        """Waits for stage B's results (they have usually arrived long ago) and fills the result records (host work)."""
+        vllm = self.vllm
+        c, evb = h["c"], h["evb"]
+        rds, probes, E = c["rds"], c["probes"], c["E"]
+        h["done"].synchronize()
+        pre_h, post_h, steps_h, losses_h, upd_h = (t.numpy() for t in h["host"])
         t5 = time.time()
         eva = c["ev"]
         ft_ms = evb[1].elapsed_time(evb[2])
@@ -381,7 +416,7 @@ class BatchedEditEval:
         self.stats["steps"] += int(steps_h.sum())
         # algorithmic HBM bytes of the executed AdamW updates (include/devqa.h, devqa_ft_adamw_step): the first update of an edit
         # reads w0 and writes w, m, v (4 tensors), every later one reads and writes w, m, v (6 tensors), fp32, on [Dout, npad]
-        Dout_, npad_ = self._ft_shape
+        Dout_, npad_ = h["ft_shape"]
         n_upd = int(upd_h.sum())
         self.stats["updates"] = self.stats.get("updates", 0) + n_upd
         self.stats["ft_bytes"] = self.stats.get("ft_bytes", 0) + 4 * Dout_ * npad_ * (6 * n_upd - 2 * int((upd_h > 0).sum()))
@@ -398,7 +433,7 @@ class BatchedEditEval:
             self.__dict__.setdefault("debug", {})[tag + "_logits"] = logits
         return am
 
-    def _ft_loop(self, w0, a_ft, resid_ft, labels, mask, E, kmax, d, cfg):
+    def _ft_loop(self, w0, a_ft, resid_ft, labels, mask, E, kmax, d, cfg, act=None):
         """Device-side FT_VL loop for E concurrent edits.  Returns (n_steps, losses, delta_c, idx, cnt, npad):
         delta_c fp32 [E, Dout, npad] is each edit's weight delta on its ACTIVE columns idx[e,:cnt[e]]
         (exactly zero elsewhere; csrc/ft_compact.hip).  With weight decay every column moves, so the
@@ -408,8 +443,13 @@ class BatchedEditEval:
         Dout, Din = w0.shape
         npad = Din
         if cfg.weight_decay == 0:
-            idx, cnt = lib.active_columns(a_ft)
-            npad = max(8, (int(cnt.max().item()) + 7) // 8 * 8)   # one small sync per batch: sizes the state
+            if act is not None:        # counted at the end of stage A; its event has normally completed long ago
+                idx, cnt, mx, act_ev = act
+                act_ev.synchronize()
+                npad = max(8, (int(mx[0]) + 7) // 8 * 8)
+            else:
+                idx, cnt = lib.active_columns(a_ft)
+                npad = max(8, (int(cnt.max().item()) + 7) // 8 * 8)   # one small sync per batch: sizes the state
         dense = npad * 10 >= Din * 9      # (nearly) every column is active somewhere: gathering would only copy the matrix E times
         if dense:
             idx = torch.arange(Din, dtype=torch.int32, device=dev).repeat(E, 1).contiguous()
