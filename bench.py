@@ -47,7 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cycles-per-step", type=int, default=127,
-                    help="cycles per batch; 127 -> 508 images = four ViT chunks of 127 images (32639 rows = 127.5 row tiles of 256: every GEMM round full)")
+                    help="cycles per batch; 127 -> 508 images through the vision encoder in one call (130556 rows = 510 row tiles of 256)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--ffn", choices=["sparse", "dense", "both"], default="both")
     ap.add_argument("--dense-steps", type=int, default=0, help="steps of the dense leg under --ffn both (default max(3, steps // 3))")

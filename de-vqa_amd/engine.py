@@ -123,10 +123,12 @@ class Blip2Engine:
             self._seq_desc_cache[key] = d
         return d
 
-    def image_chunks(self, n, max_chunk=128):
+    def image_chunks(self, n, max_chunk=None):
         """Split n images into encode_images() calls.  The ViT GEMMs run 256x256 tiles, one workgroup per CU, so a call
         costs ceil(tiles / 256) rounds per GEMM; pick the partition of n that minimises the summed rounds x K (DP over
         chunk sizes) instead of a fixed chunk."""
+        if max_chunk is None:
+            max_chunk = int(os.environ.get("DEVQA_VIT_CHUNK", "512"))   # 127-image chunks: 254 cycles/s, 255: 261, one call for 508 images: 264.5
         return plan_image_chunks(n, self._vit_tokens(), self._vit_gemm_shapes(), max_chunk)
 
     def _vit_tokens(self):
