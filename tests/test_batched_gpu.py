@@ -106,8 +106,10 @@ def test_early_stop_and_no_update_paths(gold_dir, in_gold_dir):
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_pipelined_batches_equal_sequential(gold_dir, in_gold_dir, dtype):
-    """run_batches with the two-stream pipeline (stage A of batch i+1 queued before stage B of batch i on a side
-    stream) returns exactly what running the batches one after the other returns."""
+    """run_batches with the software pipeline (the host one batch ahead: stage A of batch i+1 queued before stage B of batch i,
+    results decoded an iteration later; stage B on the same stream, or on a side stream with DEVQA_PIPELINE=concurrent) returns
+    exactly what running the batches one after the other returns."""
+    import os
     from devqa_amd.batched import BatchedEditEval
     vllm, ed, data = _setup(gold_dir, dtype)
 
@@ -121,7 +123,12 @@ def test_pipelined_batches_equal_sequential(gold_dir, in_gold_dir, dtype):
     seq = be.run_batches(batches(), pipelined=False)
     pip = be.run_batches(batches(), pipelined=True)
     pip2 = be.run_batches(batches() + batches(), pipelined=True)[3:]
-    for other in (pip, pip2):
+    os.environ["DEVQA_PIPELINE"] = "concurrent"
+    try:
+        pip3 = be.run_batches(batches(), pipelined=True)
+    finally:
+        del os.environ["DEVQA_PIPELINE"]
+    for other in (pip, pip2, pip3):
         assert len(seq) == len(other) == 3
         for (o1, m1), (o2, m2) in zip(seq, other):
             assert m1 == m2
