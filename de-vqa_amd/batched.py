@@ -57,10 +57,15 @@ class _Probe:
 
 
 class BatchedEditEval:
-    def __init__(self, editor, cycles_per_batch=16):
+    def __init__(self, editor, cycles_per_batch=None):
         self.editor = editor
         self.vllm = editor.vllm
         self.eng = editor.vllm.engine
+        if cycles_per_batch is None:
+            # large batches keep every 256 x 256 GEMM round full and amortise the launches: BLIP-2 127 cycles = 508 images (bench.py's
+            # default, measured; 4-5 GB of activations); the LLaMA-family models carry 576 image tokens per image through a 7B decoder
+            # and have only been timed at 8-16 cycles per batch
+            cycles_per_batch = int(os.environ.get("DEVQA_CYCLES_PER_BATCH", "127" if type(self.eng).__name__ == "Blip2Engine" else "16"))
         self.E = cycles_per_batch
         self.share_prefix = True  # pack each distinct image-token prefix once (exact; see engine._pack_shared_prefix)
         # parity tests only: keep the last batch's pre-/post-edit label-row logits, the probe -> row map and the compacted deltas
