@@ -11,8 +11,8 @@ import devqa_amd  # noqa: E402,F401
 from devqa_amd import lib  # noqa: E402
 
 
-def t_us(fn, n=20):
-    for _ in range(3):
+def t_us(fn, n=20, warm=600):
+    for _ in range(warm):      # clocks ramp over ~100 ms of continuous load: the first launches after an idle period run 10-15 % slower
         fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
