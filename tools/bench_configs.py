@@ -50,7 +50,35 @@ class Data:
     pass
 
 
-def run_eval(editor, n, batched, out_dir="/tmp/devqa_bench_cfg"):
+def distinct_records(n, image_size, seed=11):
+    """n records with DISTINCT images (pre-processed pixel tensors resident in HBM, as bench.py passes them) and distinct prompts, so
+    that the batched evaluator's image / sequence de-duplication finds nothing to share across cycles (records(n) repeats 8 records:
+    fine for one batch of 8, meaningless for larger ones)."""
+    base = records(n)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    words = ["red", "blue", "green", "seven", "north", "table", "glass", "river", "stone", "cloud", "paper", "light", "horse", "train"]
+    cache = {}
+
+    def img(tag):
+        if tag not in cache:
+            cache[tag] = torch.randn(3, image_size, image_size, generator=g).to(DEV)
+        return cache[tag]
+
+    def fix(item, i, k):
+        if item.get("image") is not None:
+            item["image"] = img((i, item["image"]))
+        item["prompt"] = "%s %s %s" % (words[(i * 7 + k) % len(words)], words[(i // len(words) + 3 * k) % len(words)], item["prompt"])
+    for i, r in enumerate(base):
+        for k, q in enumerate(r["requests"]):
+            fix(q, i, k)
+        for sec in ("generality", "locality"):
+            for k, name in enumerate(r[sec]):
+                for q in r[sec][name]:
+                    fix(q, i, 10 + k)
+    return base
+
+
+def run_eval(editor, n, batched, out_dir="/tmp/devqa_bench_cfg", distinct_image_size=None):
     from devqa_amd.dataset.vllm import BaseVLLMEditData
     from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation
 
@@ -58,10 +86,13 @@ def run_eval(editor, n, batched, out_dir="/tmp/devqa_bench_cfg"):
         def dataset_name(self):
             return "EVQA"
     os.chdir(GOLD)
-    ev = VLLMEditorEvaluation(editor, D(records(n), records(n)), "EVQA", out_dir)
+    mk = (lambda: distinct_records(n, distinct_image_size)) if distinct_image_size else (lambda: records(n))
+    ev = VLLMEditorEvaluation(editor, D(mk(), mk()), "EVQA", out_dir)
     ev.evaluate_sequential_edit(1, False, None, batched=batched, save=False)   # warm-up (kernel load, caches)
     torch.cuda.synchronize()
-    ev = VLLMEditorEvaluation(editor, D(records(n), records(n)), "EVQA", out_dir)
+    a, b = mk(), mk()
+    torch.cuda.synchronize()
+    ev = VLLMEditorEvaluation(editor, D(a, b), "EVQA", out_dir)
     t0 = time.time()
     res = ev.evaluate_sequential_edit(1, False, None, batched=batched, save=False)
     torch.cuda.synchronize()
@@ -84,9 +115,10 @@ def llava_ft(n=8):
     cfg = FTvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "ft_vl", "llava-v1.5-7b.yaml"))
     ed = FTvl(vllm, cfg, DEV)
     print("build %.1fs" % (time.time() - t0), flush=True)
-    cps, dt, res = run_eval(ed, n, True)
+    cps, dt, res = run_eval(ed, n, True, distinct_image_size=336 if n > 8 else None)
     r0 = res[0][0]
-    print(json.dumps({"config": "LLaVA-1.5-7B + FT_VL (batched engine, %d cycles/step)" % n, "cycles_per_s": round(cps, 2),
+    print(json.dumps({"config": "LLaVA-1.5-7B + FT_VL (batched engine, %d %scycles, DEVQA_CYCLES_PER_BATCH=%s)" % (
+                          n, "distinct " if n > 8 else "", os.environ.get("DEVQA_CYCLES_PER_BATCH", "default")), "cycles_per_s": round(cps, 2),
                       "s_per_step": round(dt, 3), "reliability_acc_first": r0["reliability"][0]["acc"]}))
 
 
