@@ -211,41 +211,55 @@ class MENDvl(VLLMBaseEditorWithTraining):
         eng, dev = self.vllm.engine, self.dev
         emb, am = llm_inpt["inputs_embeds"], llm_inpt["attention_mask"]
         B, T = emb.shape[:2]
-        ps = eng.pack_from_embeds(emb, am)
+        am_h = getattr(am, "_devqa_host", None)
+        ps = eng.pack_from_embeds(emb, am, lens=None if am_h is None else am_h.sum(1).tolist())
         save = {"layers": set(self.layers)}
         x_fin, _ = eng.decoder_layers(ps, save=save)
         L = label_ids.shape[1]
+        lm_h = getattr(label_masks, "_devqa_host", None)      # host originals attached by prompts_imgs_target_to_xym: no sync
+        li_h = getattr(label_ids, "_devqa_host", None)
+        lm_h = (label_masks.cpu() if lm_h is None else lm_h).tolist()
+        li_h = (label_ids.cpu() if li_h is None else li_h).tolist()
         rows, labels = [], []
         for b in range(B):
             for j in range(L):
-                if int(label_masks[b, j]) != 0:
+                if int(lm_h[b][j]) != 0:
                     rows.append(b * T + (T - L) + j)
-                    labels.append(int(label_ids[b, j]))
+                    labels.append(int(li_h[b][j]))
         k = len(rows)
-        idx = torch.tensor(rows, dtype=torch.int32, device=dev)
+        idx = lib.h2d(rows, torch.int32, dev)
         pre_ln = lib.gather_rows(x_fin, idx)
         logits = eng.lm_head(pre_ln)
         coef = torch.full((k,), 1.0 / k, dtype=torch.float32, device=dev)   # label_loss averages over masked tokens (:344-352)
-        _, nll, dlog = lib.vocab_rows(logits, torch.tensor(labels, dtype=torch.int32, device=dev), coef, want_argmax=False,
+        _, nll, dlog = lib.vocab_rows(logits, lib.h2d(labels, torch.int32, dev), coef, want_argmax=False,
                                       want_nll=True, want_dlogits=True, dlogits_dtype=eng.adt)
-        self.last_loss = float(nll.mean().item())
+        self._last_nll = nll                                                 # read through `last_loss` (a sync only when asked for)
         dH = lib.gemm_rows_longk(dlog, self.vllm.model.embed_T)
         dxr = eng.final_norm_bwd(pre_ln, dH)
         dx = torch.zeros_like(x_fin)
         dx.index_copy_(0, idx.long(), dxr)                                   # plumbing: scatter the k gradient rows
         caps, _ = eng.decoder_backward(ps, save, dx, {m["name"] for m in self.modules})
         self.last = {}
-        for m in self.modules:
-            xin, delta = caps[m["name"]]
-            xin32 = xin.to(torch.float32).contiguous()
-            d32 = delta.to(torch.float32).contiguous()
-            nz = ((xin32 != 0).any(-1) & (d32 != 0).any(-1)).nonzero().flatten().to(torch.int32)   # auxiliary_networks.py:118-120
+        # rows with a non-zero input AND a non-zero output gradient, per module (auxiliary_networks.py:118-120): the masks of all
+        # modules come to the host in ONE transfer (a .nonzero() per module is a device -> host synchronisation each)
+        caps32 = {m["name"]: (caps[m["name"]][0].to(torch.float32).contiguous(), caps[m["name"]][1].to(torch.float32).contiguous())
+                  for m in self.modules}
+        masks = torch.stack([(caps32[m["name"]][0] != 0).any(-1) & (caps32[m["name"]][1] != 0).any(-1) for m in self.modules]).cpu().numpy()
+        for mi, m in enumerate(self.modules):
+            xin32, d32 = caps32[m["name"]]
+            nz = lib.h2d(np.nonzero(masks[mi])[0].astype(np.int32), torch.int32, dev)
             xt, dt, trace = self._transform(m, xin32, d32, nz)
             m["X"].append(xt)
             m["D"].append(dt * m["lr"])
             m["n"] += int(nz.numel())
             self.last[m["name"]] = {"x": xin32, "delta": d32, "xt": xt, "dt": dt, "trace": trace}
         self._install_deltas()
+
+    @property
+    def last_loss(self):
+        """edit loss of the last edit (mean NLL over the label rows)"""
+        t = getattr(self, "_last_nll", None)
+        return None if t is None else float(t.mean().item())
 
     def _transform(self, m, xin32, d32, nz):
         """GradientTransform.forward + IDMLP (auxiliary_networks.py:112-151, 20-24, 62-83).  In training mode the running

@@ -86,7 +86,9 @@ class BaseVLLMForEdit(ABC):
     def prompts_imgs_target_to_xym(self, prompts: List[str], imgs: List, targets: List[str]):
         input_strs, y, m, _ = self.xym_token_bookkeeping(prompts, targets)
         input_embeds, vt_range = self.get_llm_input_embeds(input_strs, imgs)
-        return (input_embeds, vt_range), lib.h2d(y, y.dtype, self.device), lib.h2d(m, m.dtype, self.device)
+        yd, md = lib.h2d(y, y.dtype, self.device), lib.h2d(m, m.dtype, self.device)
+        yd._devqa_host, md._devqa_host = y, m        # the host originals: readers of single entries need no device -> host sync
+        return (input_embeds, vt_range), yd, md
 
     # base.py:111-119 (K9) -- masked NLL on the HIP vocab-rows kernel (no autograd graph)
     def label_loss(self, logits, label_ids, label_masks, average=True):

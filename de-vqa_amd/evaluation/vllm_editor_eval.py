@@ -153,15 +153,21 @@ class VLLMEditorEvaluation:
             idx = lib.h2d(label_rows, torch.int32, rows.device)
             logits = eng.lm_head(lib.gather_rows(x_fin, idx))
             pre, _, _ = lib.vocab_rows(logits)
-            pre = pre.to(torch.long)
+            pre = pre.to(torch.long).cpu()      # ONE device -> host transfer for the whole phase: decoding and accuracies are host work
             r0 = 0
             for p_ in order:
                 i, _, y, m, _k = items[p_]
                 L = y.shape[1]
-                out[i] = (pre[r0:r0 + L].unsqueeze(0), y, m)
+                out[i] = (pre[r0:r0 + L].unsqueeze(0), VLLMEditorEvaluation._host(y), VLLMEditorEvaluation._host(m))
                 r0 += L
             start = end
         return out
+
+    @staticmethod
+    def _host(t):
+        """CPU copy of a label tensor: the host original the wrapper attached (no synchronisation), else a transfer"""
+        h = getattr(t, "_devqa_host", None)
+        return h if h is not None else (t.cpu() if t.is_cuda else t)
 
     @staticmethod
     def _can_batch_probes(editor):
@@ -174,6 +180,9 @@ class VLLMEditorEvaluation:
 
     @staticmethod
     def _acc(pre_y, label_ids, label_masks):
+        if not pre_y.is_cuda:       # batched probe path: predictions are on the host already
+            label_ids = label_ids.cpu() if label_ids.is_cuda else label_ids
+            label_masks = label_masks.cpu() if label_masks.is_cuda else label_masks
         return float(((pre_y == label_ids) * label_masks).sum() / label_masks.sum())
 
     def __get_results_after_edit__(self, vllm, ed, rd, batch_probes=False, prefix_fn=None):
