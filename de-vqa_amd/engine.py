@@ -10,6 +10,7 @@ Reference call sites replaced (R/ = /root/reference/DE-VQA/):
   ft_edit_batch      <- FTvl.execute_ft hot loop                         (R/editor/vllm_editors/ft_vl/ft_vl.py:111-146)
 """
 import os
+import re
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -333,6 +334,20 @@ class Blip2Engine:
             a = ctx.llm_layers(x, ps.desc, n_seq, ps.max_len, ps.dense, last + 1, stop_before_fc2)
             return x, a
         deltas = getattr(self, "module_deltas", None) or {}
+        # the layers BELOW everything this call has to look into (saved activations, low-rank deltas, extra neurons) are plain frozen
+        # layers: one path-level call instead of ~10 Python-ordered launches per layer (MEND_VL edits layers 29-31 of 32: its forward
+        # was 320 launches from Python, 2.7 ms of host time per edit on a host-bound path)
+        if first_layer == 0:
+            touched = [last if (stop_before_fc2 or return_h) else last + 1]     # a stopping last layer is handled below
+            if save is not None:
+                touched.append(min(save["layers"]) if save["layers"] else last + 1)
+            touched += [int(re.search(r"layers\.(\d+)\.", n).group(1)) for n in deltas]
+            touched += list((getattr(self, "extra_neurons", None) or {}).keys())
+            lo = min(touched)
+            pctx = self.path_ctx() if lo > 0 else None
+            if pctx is not None:
+                pctx.llm_layers(x, ps.desc, n_seq, ps.max_len, ps.dense, lo, False)
+                first_layer = lo
         for i in range(first_layer, last + 1):
             p = "language_model.model.decoder.layers.%d." % i
             rec = None
