@@ -66,14 +66,23 @@ class BaseVLLMForEdit(ABC):
         targets = [" " + t if p[-1] not in [" ", "\n"] and t[0] not in [" ", "\n"] else t
                    for p, t in zip(prompts, targets)]
         tokenizer = self.get_llm_tokenizer()
+        cache = self.__dict__.setdefault("_tok_ids_cache", {})      # the evaluator tokenises every locality probe twice (before / after the edit)
+
+        def ids_of(text):
+            v = cache.get(text)
+            if v is None:
+                if len(cache) > 8192:
+                    cache.clear()
+                v = cache[text] = tuple(tokenizer(text)["input_ids"])
+            return v
         input_strs, label_ids, label_masks = [], [], []
         min_prompt_tok_n = 999
         for p, t in zip(prompts, targets):
             s = p + t
             input_strs.append(s)
-            ids = torch.as_tensor(tokenizer(s)["input_ids"], dtype=torch.long)
+            ids = torch.as_tensor(ids_of(s), dtype=torch.long)
             lab = torch.roll(ids, -1, 0)
-            n_prompt = len(tokenizer(p)["input_ids"])
+            n_prompt = len(ids_of(p))
             min_prompt_tok_n = min(min_prompt_tok_n, n_prompt)
             m = torch.zeros_like(lab)
             m[n_prompt - 1:-1] += 1
