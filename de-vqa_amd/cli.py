@@ -5,7 +5,8 @@ author's dataset paths, image roots, SentenceTransformer checkpoint and pickled 
 (R/test_vllm_edit.py:45-59, R/dataset/vllm.py:89-117).  Here those become OPTIONAL flags with defaults that mirror the
 reference's relative layout, so the reference's command lines parse unchanged:
 
-  --data_path   default  <data root>/easy-edit-mm/vqa/vqa_{eval,train}.json | <data root>/VLKEB/{eval,train}.json
+  --data_path   default  <data root>/easy-edit-mm/vqa/vqa_{eval,train}.json | <data root>/VLKEB/{eval,train}.json |
+                         <data root>/easy-edit-mm/caption/caption_{eval,train}_edit.json
   --img_root    default  $DEVQA_IMG_ROOT or <data root>/easy-edit-mm/images | <data root>/VLKEB/mmkb_images
   --embeddings  default  <data root>/embeddings/{vqa,vlkeb}_embeddings.npz   corpus {embeddings, prompts, images[, sentences]}
                          (the reference's pickle dict layout {sentences, images, prompts, embeddings}, stored as .npz so that
@@ -24,9 +25,10 @@ import os
 import numpy as np
 
 DATA_FILES = {("EVQA", "eval"): "easy-edit-mm/vqa/vqa_eval.json", ("EVQA", "train"): "easy-edit-mm/vqa/vqa_train.json",
-              ("VLKEB", "eval"): "VLKEB/eval.json", ("VLKEB", "train"): "VLKEB/train.json"}
-IMG_ROOTS = {"EVQA": "easy-edit-mm/images", "VLKEB": "VLKEB/mmkb_images"}
-EMB_FILES = {"EVQA": "embeddings/vqa_embeddings.npz", "VLKEB": "embeddings/vlkeb_embeddings.npz"}
+              ("VLKEB", "eval"): "VLKEB/eval.json", ("VLKEB", "train"): "VLKEB/train.json",
+              ("EIC", "eval"): "easy-edit-mm/caption/caption_eval_edit.json", ("EIC", "train"): "easy-edit-mm/caption/caption_train_edit.json"}
+IMG_ROOTS = {"EVQA": "easy-edit-mm/images", "VLKEB": "VLKEB/mmkb_images", "EIC": "easy-edit-mm/images"}
+EMB_FILES = {"EVQA": "embeddings/vqa_embeddings.npz", "VLKEB": "embeddings/vlkeb_embeddings.npz", "EIC": "embeddings/caption_embeddings.npz"}
 
 
 def data_root():
@@ -49,7 +51,7 @@ def resolve_paths(cfg, split):
     """Fill the optional path flags from the defaults above.  -> (data_path, img_root, embeddings)"""
     name = cfg.data_name.upper()
     if name not in IMG_ROOTS:
-        raise BaseException("Dataset %s is not built on this path (EVQA, VLKEB)." % name)
+        raise BaseException("Dataset %s is not built on this path (EVQA, EIC, VLKEB)." % name)
     data_path = cfg.data_path or os.path.join(data_root(), DATA_FILES[(name, split)])
     img_root = cfg.img_root or os.environ.get("DEVQA_IMG_ROOT") or os.path.join(data_root(), IMG_ROOTS[name])
     emb = cfg.embeddings or os.path.join(data_root(), EMB_FILES[name])
@@ -78,7 +80,7 @@ def load_encoder(cfg):
 
 def build_dataset(cfg, split):
     """EVQA / VLKEB with the cosine top-k retriever on the HIP kernel (R/test_vllm_edit.py:45-59, R/train_vllm_editor.py:59-83)."""
-    from .dataset.vllm import EVQA, VLKEB, EmbeddingRetriever
+    from .dataset.vllm import EIC, EVQA, VLKEB, EmbeddingRetriever
     data_path, img_root, emb = resolve_paths(cfg, split)
     enc = load_encoder(cfg)
     if enc is None:
@@ -89,7 +91,7 @@ def build_dataset(cfg, split):
     corpus = np.load(emb, allow_pickle=False)
     retriever = EmbeddingRetriever(enc, corpus["embeddings"], [tuple(p) for p in corpus["prompts"].tolist()],
                                    corpus["images"].tolist(), cfg.device)
-    ds = {"EVQA": EVQA, "VLKEB": VLKEB}[cfg.data_name.upper()]
+    ds = {"EVQA": EVQA, "EIC": EIC, "VLKEB": VLKEB}[cfg.data_name.upper()]
     n = getattr(cfg, "data_sample_n", None) if hasattr(cfg, "data_sample_n") else getattr(cfg, "data_n", None)
     return ds(data_path, img_root, n, retriever)
 

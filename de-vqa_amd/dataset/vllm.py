@@ -178,6 +178,31 @@ class EVQA(BaseVLLMEditData):
         return "EVQA"
 
 
+class EIC(BaseVLLMEditData):
+    """vllm.py:257-271: same 11-field records and probe recipe as EVQA (`__init_eic_evqa__`); only text_loc changes ('?' appended, no
+    ' The answer is:' anywhere).  The reference's constructor then indexes `d['locality']['image_loc']` (:265), a probe its builder no
+    longer makes (:131 is commented out), so `EIC(...)` raises KeyError there on any non-empty file; here that suffix is applied when
+    a record set carries an image_loc probe and skipped otherwise."""
+
+    def __init__(self, data_path: str = "data/easy-edit-mm/caption/caption_train_edit.json",
+                 img_root_dir: str = "data/easy-edit-mm/images", data_n=None, retriever: Optional[EmbeddingRetriever] = None):
+        if "caption" not in os.path.basename(data_path):
+            raise RuntimeError("not a caption file")
+        if retriever is None:
+            raise RuntimeError("EIC needs a retriever")
+        recs = _load_records(data_path, data_n)
+        retrieved = retriever.finds_sim_many([d["src"] for d in recs], [d["pred"] for d in recs])
+        data = build_probes(recs, img_root_dir, retrieved)
+        for d in data:
+            d["locality"]["text_loc"][0]["prompt"] += "?"
+            if "image_loc" in d["locality"]:
+                d["locality"]["image_loc"][0]["prompt"] += SUFFIX
+        super().__init__(deepcopy(data), data)
+
+    def dataset_name(self):
+        return "EIC"
+
+
 class VLKEB(BaseVLLMEditData):
     """vllm.py:274-297: only locality prompts get the suffix (+ '?' on text_loc)."""
 

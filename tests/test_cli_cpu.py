@@ -39,7 +39,10 @@ def test_path_defaults_and_encoders(tmp_path, monkeypatch):
     assert cli.resolve_paths(c, "train")[0] == "/d/easy-edit-mm/vqa/vqa_train.json"
     c = T.get_attr("-en ft_vl -mn blip2 -sen 1 -dvc cuda:0 -dn vlkeb --img_root /imgs".split())
     assert cli.resolve_paths(c, "eval") == ("/d/VLKEB/eval.json", "/imgs", "/d/embeddings/vlkeb_embeddings.npz")
-    c.data_name = "EIC"
+    c.data_name = "EIC"; c.img_root = None                                               # R/test_vllm_edit.py:50-54
+    assert cli.resolve_paths(c, "eval") == ("/d/easy-edit-mm/caption/caption_eval_edit.json", "/d/easy-edit-mm/images",
+                                            "/d/embeddings/caption_embeddings.npz")
+    c.data_name = "COCO"
     with pytest.raises(BaseException):
         cli.resolve_paths(c, "eval")
     # encoders: none -> a clear error from the dataset builder; lookup table; module:callable

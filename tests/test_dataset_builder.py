@@ -73,6 +73,35 @@ def test_evqa_rejects_non_vqa_file_and_missing_retriever():
         V.EVQA(os.path.join(DS, FILES["EVQA"]), "r", 2, None)
 
 
+def test_eic_probe_rules(tmp_path):
+    """EIC (R/dataset/vllm.py:257-271): EVQA's builder, '?' on text_loc only, no ' The answer is:' (the reference's own constructor
+    raises KeyError on `image_loc` at :265, so there is no reference output to pin this against: parity unpinned, rule read off
+    the source).  Checked against the EVQA golden probes with the EVQA suffixes stripped."""
+    import shutil
+    import devqa_amd  # noqa: F401
+    from devqa_amd.dataset import vllm as V
+    g = _gold()
+    path = str(tmp_path / "caption_eval_head.json")
+    shutil.copy(os.path.join(DS, FILES["EVQA"]), path)
+    ds = V.EIC(path, g["EVQA"]["img_root"], g["n"], OracleRetriever(g["corpus"]["EVQA"]))
+    assert ds.dataset_name() == "EIC" and len(ds.data) == g["n"]
+    SUF = " The answer is:"
+    for d, e in zip(ds.data_with_img_path, g["EVQA"]["data"]):
+        assert d["requests"][0]["prompt"] + SUF == e["requests"][0]["prompt"]
+        assert d["requests"][0]["target_new"] == e["requests"][0]["target_new"] and d["requests"][0]["image"] == e["requests"][0]["image"]
+        for k in ("text_rephrase", "image_rephrase"):
+            assert d["generality"][k][0]["prompt"] + SUF == e["generality"][k][0]["prompt"]
+        assert list(d["locality"]) == list(e["locality"])
+        for k in d["locality"]:
+            want = e["locality"][k][0]["prompt"]
+            want = want[:-len(SUF + "?")] + "?" if k == "text_loc" else want[:-len(SUF)]
+            assert d["locality"][k][0]["prompt"] == want and d["locality"][k][0]["target"] == e["locality"][k][0]["target"]
+    with pytest.raises(RuntimeError):
+        V.EIC(os.path.join(DS, FILES["EVQA"]), "r", 2, OracleRetriever(g["corpus"]["EVQA"]))      # 'caption' not in basename (:260)
+    with pytest.raises(RuntimeError):
+        V.EIC(path, "r", 2, None)
+
+
 def test_corpus_file_round_trip(tmp_path):
     import pickle
     import devqa_amd  # noqa: F401
