@@ -276,8 +276,8 @@ class BatchedEditEval:
             rows = [j for j in range(len(y)) if m[j] != 0]
             edits.append((seq_id(img_id(req["image"]), ids), len(y), rows, [y[j] for j in rows]))
         kmax = max(len(e[2]) for e in edits)
-        if kmax > 16:
-            raise NotImplementedError("batched FT_VL supports <= 16 target tokens per edit (got %d)" % kmax)
+        if kmax > lib.FT_MAX_ROWS:
+            raise NotImplementedError("batched FT_VL supports <= %d target tokens per edit (got %d)" % (lib.FT_MAX_ROWS, kmax))
         t1c = time.time()
         self.stats["t_host"] += (t1 - t0) + (t1c - t1b)
         ev[1].record()

@@ -239,6 +239,119 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
     }
 }
 
+// WIDE (17..64 loss rows per edit: long targets, e.g. captions): the G = 16 lane-group form with the a-rows NOT held in registers --
+// each float4 column step reads the L a-values twice (gradient, then next-forward dot products) from L1 / L2, where the [L, Din]
+// block of an edit (<= 2.6 MB) lives anyway.  Same per-element arithmetic and summation order over l as the kernels above.
+template <int L>
+__global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                                 const float* __restrict__ w0, const float* __restrict__ a,
+                                                                 const float* __restrict__ dy, float* __restrict__ y,
+                                                                 const int32_t* __restrict__ do_update, const int32_t* __restrict__ adam_t,
+                                                                 int Lmax, int Dout, int Din, float lr, float beta1, float beta2, float eps,
+                                                                 float wd, float clamp_eps, int row_blocks, int64_t w0_stride_e) {
+    constexpr int G = 16, RW = 64 / G;
+    const int e = blockIdx.x / row_blocks;
+    const int rb = blockIdx.x % row_blocks;
+    if (!do_update[e]) return;  // uniform
+    w0 += (int64_t)e * w0_stride_e;
+    const int t = adam_t[e];
+    const bool first = (t <= 1);
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)t));
+    const float bc2 = (float)(1.0 - pow((double)beta2, (double)t));
+    const float step_size = lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    const float decay = 1.f - lr * wd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % G;
+    const int i = (rb * 4 + wave) * RW + lane / G;
+    const bool row_ok = i < Dout;
+    const int ic = row_ok ? i : Dout - 1;
+    const int64_t mat = (int64_t)Dout * Din;
+    float* we = w + (int64_t)e * mat;
+    float* me = m + (int64_t)e * mat;
+    float* ve = v + (int64_t)e * mat;
+    const float* ae = a + (int64_t)e * Lmax * Din;
+    const float* dye = dy + (int64_t)e * Lmax * Dout;
+    float dyv[L], ysum[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        dyv[l] = (l < Lmax) ? dye[(int64_t)l * Dout + ic] : 0.f;
+        ysum[l] = 0.f;
+    }
+    const int nv = Din >> 2;
+    for (int c = sub; c < nv; c += G) {
+        const int64_t off = (int64_t)ic * nv + c;
+        float4 wv, mv, vv, w0v;
+        if (first) {
+            w0v = reinterpret_cast<const float4*>(w0)[off];
+            wv = w0v;
+            mv = make_float4(0.f, 0.f, 0.f, 0.f);
+            vv = mv;
+        } else {
+            wv = reinterpret_cast<const float4*>(we)[off];
+            mv = reinterpret_cast<const float4*>(me)[off];
+            vv = reinterpret_cast<const float4*>(ve)[off];
+            if (clamp_eps >= 0.f) w0v = reinterpret_cast<const float4*>(w0)[off];
+        }
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            if (l < Lmax) {
+                const float4 av = reinterpret_cast<const float4*>(ae + (int64_t)l * Din)[c];
+                g[0] += dyv[l] * av.x;
+                g[1] += dyv[l] * av.y;
+                g[2] += dyv[l] * av.z;
+                g[3] += dyv[l] * av.w;
+            }
+        }
+        float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+        float mq[4] = {mv.x, mv.y, mv.z, mv.w};
+        float vq[4] = {vv.x, vv.y, vv.z, vv.w};
+        const float w0q[4] = {w0v.x, w0v.y, w0v.z, w0v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wq[k] *= decay;
+            mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
+            vq[k] = vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
+            const float denom = sqrtf(vq[k]) / bc2_sqrt + eps;
+            wq[k] -= step_size * (mq[k] / denom);
+            if (clamp_eps >= 0.f) wq[k] = fminf(fmaxf(wq[k], w0q[k] - clamp_eps), w0q[k] + clamp_eps);
+        }
+        if (row_ok) {
+            reinterpret_cast<float4*>(we)[off] = make_float4(wq[0], wq[1], wq[2], wq[3]);
+            reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
+            reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            if (l < Lmax) {
+                const float4 av = reinterpret_cast<const float4*>(ae + (int64_t)l * Din)[c];
+                ysum[l] += (wq[0] * av.x + wq[1] * av.y) + (wq[2] * av.z + wq[3] * av.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        float s = ysum[l];
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (sub == 0 && row_ok && l < Lmax) y[((int64_t)e * Lmax + l) * Dout + i] = s;
+    }
+}
+
+template <int L>
+static int launch_adamw_wide(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
+                             const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din, float lr,
+                             float beta1, float beta2, float eps, float wd, float clamp_eps, int64_t w0_stride_e, hipStream_t st) {
+    const int row_blocks = (Dout + 15) / 16;
+    const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
+    hipLaunchKernelGGL((ft_adamw_step_wide_kernel<L>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update, adam_t,
+                       Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
+    devqa_prof_end(ph, 24.0 * E * (double)Dout * Din, st);
+    DEVQA_LAUNCH_CHECK("ft_adamw_step(wide)");
+    return DEVQA_OK;
+}
+
 template <int L, int ROWS>
 static int launch_adamw(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
                         const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din, float lr,
@@ -286,7 +399,7 @@ extern "C" int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0
                                    int64_t w0_stride_e, void* stream) {
     DEVQA_CHECK_ARG(w && m && v && w0 && a && dy && y && do_update && adam_t, "ft_adamw_step: null pointer");
     if (E == 0) return DEVQA_OK;
-    DEVQA_CHECK_SHAPE(E > 0 && Lmax >= 1 && Lmax <= 16, "ft_adamw_step: Lmax=%d unsupported (1..16)", Lmax);
+    DEVQA_CHECK_SHAPE(E > 0 && Lmax >= 1 && Lmax <= DEVQA_FT_MAX_ROWS, "ft_adamw_step: Lmax=%d unsupported (1..64)", Lmax);
     DEVQA_CHECK_SHAPE(Dout > 0 && Din > 0 && Din % 4 == 0, "ft_adamw_step: bad matrix dims %dx%d", Dout, Din);
     DEVQA_CHECK_SHAPE((long)E * ((Dout + 1) / 2) < 2147483647L, "ft_adamw_step: grid too large");
     hipStream_t st = (hipStream_t)stream;
@@ -295,7 +408,9 @@ extern "C" int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0
     if (Lmax <= 2) return launch_adamw<2, 4>(ARGS);
     if (Lmax <= 4) return launch_adamw<4, 2>(ARGS);
     if (Lmax <= 8) return launch_adamw<8, 2>(ARGS);
-    return launch_adamw<16, 1>(ARGS);
+    if (Lmax <= 16) return launch_adamw<16, 1>(ARGS);
+    if (Lmax <= 32) return launch_adamw_wide<32>(ARGS);
+    return launch_adamw_wide<64>(ARGS);
 #undef ARGS
 }
 
@@ -304,13 +419,13 @@ template <int L, int ROWS>
 __global__ __launch_bounds__(256) void rows_matvec_kernel(const float* __restrict__ w, int64_t w_stride_e,
                                                           const float* __restrict__ a, const float* __restrict__ bias,
                                                           const float* __restrict__ resid, float* __restrict__ y, int Lr,
-                                                          int Dout, int Din, int row_blocks) {
+                                                          int Ls, int Dout, int Din, int row_blocks) {
     __shared__ float red[4][ROWS * L];
     const int e = blockIdx.x / row_blocks;
     const int rb = blockIdx.x % row_blocks;
     const int i0 = rb * ROWS;
     const float* we = w + (int64_t)e * w_stride_e;
-    const float* ae = a + (int64_t)e * Lr * Din;
+    const float* ae = a + (int64_t)e * Ls * Din;       // Ls rows per edit, of which this launch takes Lr (from the caller's offset)
     float ysum[ROWS][L];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
@@ -345,7 +460,7 @@ __global__ __launch_bounds__(256) void rows_matvec_kernel(const float* __restric
         const int r = threadIdx.x / L, l = threadIdx.x % L;
         if (i0 + r < Dout && l < Lr) {
             float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-            const int64_t o = ((int64_t)e * Lr + l) * Dout + i0 + r;
+            const int64_t o = ((int64_t)e * Ls + l) * Dout + i0 + r;
             if (bias) s += bias[i0 + r];
             if (resid) s += resid[o];
             y[o] = s;
@@ -357,24 +472,30 @@ extern "C" int devqa_rows_matvec_f32(const float* w, int64_t w_stride_e, const f
                                      const float* resid, float* y, int E, int L, int Dout, int Din, void* stream) {
     DEVQA_CHECK_ARG(w && a && y, "rows_matvec: null pointer");
     if (E == 0 || L == 0) return DEVQA_OK;
-    DEVQA_CHECK_SHAPE(E > 0 && L >= 1 && L <= 16, "rows_matvec: L=%d unsupported (1..16)", L);
+    DEVQA_CHECK_SHAPE(E > 0 && L >= 1 && L <= DEVQA_FT_MAX_ROWS, "rows_matvec: L=%d unsupported (1..64)", L);
     DEVQA_CHECK_SHAPE(Dout > 0 && Din > 0 && Din % 4 == 0, "rows_matvec: bad matrix dims");
     hipStream_t st = (hipStream_t)stream;
     constexpr int ROWS = 4;
     const int row_blocks = (Dout + ROWS - 1) / ROWS;
     DEVQA_CHECK_SHAPE((long)E * row_blocks < 2147483647L, "rows_matvec: grid too large");
-    if (L <= 2)
-        hipLaunchKernelGGL((rows_matvec_kernel<2, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, a, bias,
-                           resid, y, L, Dout, Din, row_blocks);
-    else if (L <= 4)
-        hipLaunchKernelGGL((rows_matvec_kernel<4, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, a, bias,
-                           resid, y, L, Dout, Din, row_blocks);
-    else if (L <= 8)
-        hipLaunchKernelGGL((rows_matvec_kernel<8, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, a, bias,
-                           resid, y, L, Dout, Din, row_blocks);
-    else
-        hipLaunchKernelGGL((rows_matvec_kernel<16, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, a, bias,
-                           resid, y, L, Dout, Din, row_blocks);
+    for (int l0 = 0; l0 < L; l0 += 16) {       // more than 16 rows per edit: 16 at a time (the matrix streams once per chunk)
+        const int Lc = L - l0 < 16 ? L - l0 : 16;
+        const float* ac = a + (int64_t)l0 * Din;
+        const float* rc = resid ? resid + (int64_t)l0 * Dout : nullptr;
+        float* yc = y + (int64_t)l0 * Dout;
+        if (Lc <= 2)
+            hipLaunchKernelGGL((rows_matvec_kernel<2, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, ac, bias, rc, yc, Lc, L,
+                               Dout, Din, row_blocks);
+        else if (Lc <= 4)
+            hipLaunchKernelGGL((rows_matvec_kernel<4, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, ac, bias, rc, yc, Lc, L,
+                               Dout, Din, row_blocks);
+        else if (Lc <= 8)
+            hipLaunchKernelGGL((rows_matvec_kernel<8, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, ac, bias, rc, yc, Lc, L,
+                               Dout, Din, row_blocks);
+        else
+            hipLaunchKernelGGL((rows_matvec_kernel<16, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, w_stride_e, ac, bias, rc, yc, Lc, L,
+                               Dout, Din, row_blocks);
+    }
     DEVQA_LAUNCH_CHECK("rows_matvec");
     return DEVQA_OK;
 }

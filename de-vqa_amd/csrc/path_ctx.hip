@@ -565,7 +565,7 @@ extern "C" int devqa_ft_edit(devqa_ctx_t h, const float* w0, int64_t w0_stride_e
     DEVQA_CHECK_ARG(w0 && a_rows && resid_rows && labels && mask && cfg && out_delta && out_losses && out_steps && out_updates && workspace,
                     "ft_edit: null pointer");
     if (E == 0) return DEVQA_OK;
-    DEVQA_CHECK_SHAPE(E > 0 && kmax >= 1 && kmax <= 16 && npad > 0 && npad % 4 == 0 && cfg->num_steps >= 1, "ft_edit: bad dims E=%d kmax=%d npad=%d", E, kmax, npad);
+    DEVQA_CHECK_SHAPE(E > 0 && kmax >= 1 && kmax <= DEVQA_FT_MAX_ROWS && npad > 0 && npad % 4 == 0 && cfg->num_steps >= 1, "ft_edit: bad dims E=%d kmax=%d npad=%d", E, kmax, npad);
     DEVQA_CHECK_ARG((((uintptr_t)workspace) & 255) == 0, "ft_edit: workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int Dout = c.d.t_hidden, V = c.d.t_vocab, R = E * kmax;

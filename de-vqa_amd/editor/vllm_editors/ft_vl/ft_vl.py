@@ -104,8 +104,8 @@ class FTvl(VLLMBaseEditor):
                 if int(m[b, j]) != 0:
                     rows.append(b * T + (T - L) + j)
                     labels.append(int(y[b, j]))
-        if len(rows) > 16:
-            raise NotImplementedError("native FT_VL supports <= 16 loss-carrying label rows per chunk (got %d)" % len(rows))
+        if len(rows) > lib.FT_MAX_ROWS:
+            raise NotImplementedError("native FT_VL supports <= %d loss-carrying label rows per chunk (got %d)" % (lib.FT_MAX_ROWS, len(rows)))
         idx = torch.tensor(rows, dtype=torch.int32, device=eng.dev)
         a_rows = lib.gather_rows(a, idx).to(torch.float32).unsqueeze(0).contiguous()
         resid = lib.gather_rows(x_mid, idx)

@@ -747,6 +747,7 @@ class WeightEntry(ctypes.Structure):
 
 
 MEND_MAX_LAYERS = 4
+FT_MAX_ROWS = 64          # DEVQA_FT_MAX_ROWS (include/devqa.h): loss rows per edit in the FT_VL loop
 
 
 class MendLayer(ctypes.Structure):

@@ -300,8 +300,10 @@ int devqa_colsum_f32(const float* x, int M, int D, int accumulate, float* out, v
  *   w,m,v : fp32 [E][Dout][Din]      w0 : fp32 [Dout][Din] shared (w0_stride_e = 0) or per edit (= Dout*Din)
  *   a     : fp32 [E][Lmax][Din]      dy : fp32 [E][Lmax][Dout]     y : fp32 [E][Lmax][Dout]
  *   do_update, adam_t : int32 [E] (device, from devqa_ft_step_control)
- *   clamp_eps < 0 disables the clamp.  1 <= Lmax <= 16, Din % 4 == 0.
+ *   clamp_eps < 0 disables the clamp.  1 <= Lmax <= DEVQA_FT_MAX_ROWS, Din % 4 == 0 (Lmax <= 16: the a-rows stay in registers;
+ *   17..64: re-read from cache per column step -- long targets such as captions).
  */
+#define DEVQA_FT_MAX_ROWS 64
 int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
                         const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
                         float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
@@ -324,7 +326,7 @@ int devqa_scatter_cols_add_f32(const float* comp, int rows, const int32_t* idx, 
                                int64_t ld_dense, void* stream);
 
 /* y[e,r,:] = W[e or shared] . a[e,r,:] (+ bias) (+ resid[e,r,:]) : fc2 on a few cached rows with an
- * fp32 matrix (pre-/post-edit probe tails, step-0 forward).  w_stride_e = 0 shares one matrix. */
+ * fp32 matrix (pre-/post-edit probe tails, step-0 forward).  w_stride_e = 0 shares one matrix.  1 <= L <= DEVQA_FT_MAX_ROWS. */
 int devqa_rows_matvec_f32(const float* w, int64_t w_stride_e, const float* a, const float* bias, const float* resid,
                           float* y, int E, int L, int Dout, int Din, void* stream);
 
@@ -442,7 +444,7 @@ int devqa_llm_forward(devqa_ctx_t ctx, float* x, const int32_t* seq_desc, int n_
  *   w0        : pristine matrix, shared [t_hidden, npad] (w0_stride_e = 0) or per edit [E, t_hidden, npad] (= t_hidden * npad) --
  *               npad = t_ffn for the dense loop, or the padded count of ACTIVE columns (devqa_active_columns / devqa_gather_cols_*)
  *   a_rows    : fp32 [E, kmax, npad] fc2 inputs of the loss rows (padding rows zero);  resid_rows fp32 [E*kmax, t_hidden] residual
- *               (+ fc2 bias);  labels int32 [E*kmax];  mask fp32 [E, kmax] (1 = loss row)
+ *               (+ fc2 bias);  labels int32 [E*kmax];  mask fp32 [E, kmax] (1 = loss row);  1 <= kmax <= DEVQA_FT_MAX_ROWS
  *   out_delta : fp32 [E, t_hidden, npad] = W_e - w0 (0 for an edit that never updated);  out_losses fp32 [E, num_steps];
  *               out_steps int32 [E] executed steps;  out_updates int32 [E] AdamW updates taken */
 typedef struct devqa_ft_cfg {

@@ -89,6 +89,29 @@ def test_batched_ft_losses_match_reference_per_step(gold_dir, in_gold_dir):
     assert be.last_scores.shape == (3, 16) and be.last_scores[:, 0].tolist() == [0.0, 1.0, 2.0]
 
 
+def test_batched_long_targets_equal_generic(gold_dir, in_gold_dir):
+    """Edits with 17..64 target tokens in one batch with short ones: the device-side loop gives the generic path's per-step losses
+    (which tests/test_blip2_gpu.py::test_ft_long_targets_vs_oracle holds against the oracle)."""
+    from devqa_amd.batched import BatchedEditEval
+    from test_blip2_gpu import _long_requests
+    vllm, ed, data = _setup(gold_dir, "fp32")
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))
+    longs = _long_requests(rec)[:3]
+    rd = [[deepcopy(r)] for r in data.data_with_img_path[:4]]
+    edd = [[deepcopy(r)] for r in data.data_with_img[:4]]
+    for i, lr in enumerate(longs):
+        for side in (rd, edd):
+            side[i][0]["requests"][0]["target_new"] = lr["target_new"]
+    reqs = [deepcopy(r[0]["requests"][0]) for r in rd]            # run() consumes its records
+    be = BatchedEditEval(ed, cycles_per_batch=4)
+    be.run(rd, edd)
+    for e in range(4):
+        ed.execute_ft([reqs[e]])
+        n = len(ed.last_losses)
+        assert int(be.last_steps[e]) == n
+        np.testing.assert_allclose(be.last_losses[e, :n], ed.last_losses, rtol=1e-3, atol=1e-3)
+
+
 def test_early_stop_and_no_update_paths(gold_dir, in_gold_dir):
     """lr=3e-2 makes the loop hit the 1e-2 floor: executed steps equal the reference's (g4b)."""
     from devqa_amd.batched import BatchedEditEval

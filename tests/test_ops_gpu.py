@@ -280,7 +280,9 @@ def test_vocab_rows(L, R, V):
     np.testing.assert_allclose(dl.float().cpu().numpy(), ref_dl.numpy(), atol=1e-5, rtol=1e-2)
 
 
-@pytest.mark.parametrize("Lmax,wd,clamp", [(1, 0.0, -1.0), (3, 0.0, -1.0), (2, 0.1, -1.0), (3, 0.0, 2.5e-3), (6, 0.0, -1.0)])
+# Lmax > 16: the wide kernel (a-rows re-read per column step), 17..32 and 33..64 instantiations
+@pytest.mark.parametrize("Lmax,wd,clamp", [(1, 0.0, -1.0), (3, 0.0, -1.0), (2, 0.1, -1.0), (3, 0.0, 2.5e-3), (6, 0.0, -1.0), (13, 0.0, -1.0),
+                                           (17, 0.0, -1.0), (29, 0.1, 2.5e-3), (40, 0.0, -1.0), (64, 0.0, 2.5e-3)])
 def test_ft_adamw_step_matches_torch_adamw(L, Lmax, wd, clamp):
     g = torch.Generator().manual_seed(Lmax)
     E, Dout, Din = 3, 40, 80
@@ -313,6 +315,21 @@ def test_ft_adamw_step_matches_torch_adamw(L, Lmax, wd, clamp):
             ref_y = a[e] @ params[e].detach().T
             np.testing.assert_allclose(y[e].cpu().numpy(), ref_y.numpy(), atol=1e-4, rtol=1e-4)
     assert float(y[1].abs().sum()) == 0.0  # inactive edit untouched
+
+
+@pytest.mark.parametrize("Lr", [16, 17, 37, 64])
+def test_rows_matvec_many_rows(L, Lr):
+    """More than 16 rows per edit go 16 at a time with the edit stride of the whole block."""
+    g = torch.Generator().manual_seed(Lr)
+    E, Dout, Din = 3, 42, 72
+    w = torch.randn(E, Dout, Din, generator=g)
+    a = torch.randn(E, Lr, Din, generator=g)
+    b = torch.randn(Dout, generator=g)
+    r = torch.randn(E, Lr, Dout, generator=g)
+    y = L.rows_matvec(dev(w), dev(a), dev(b), dev(r))
+    np.testing.assert_allclose(y.cpu().numpy(), (torch.einsum("eoi,eli->elo", w, a) + b + r).numpy(), atol=1e-4, rtol=1e-4)
+    y2 = L.rows_matvec(dev(w[1]), dev(a), shared=True)
+    np.testing.assert_allclose(y2.cpu().numpy(), torch.einsum("oi,eli->elo", w[1], a).numpy(), atol=1e-4, rtol=1e-4)
 
 
 def test_rows_matvec_delta_and_control(L):
