@@ -233,7 +233,7 @@ static int gemm_mode() {
     return m;
 }
 extern "C" int devqa_gemm_set_mode(int mode) {
-    if (mode < 0 || (mode > 3 && (mode < 10 || mode > 26))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
+    if (mode < 0 || (mode > 3 && (mode < 10 || mode > 27))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
     g_gemm_mode_a.store(mode);
     return DEVQA_OK;
 }

@@ -124,6 +124,61 @@ __device__ __forceinline__ void pp_tile(const PPState& s, int t, float4_t (&acc)
     __builtin_amdgcn_s_barrier();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// HALF-WIDTH COLUMN TILE (the last column tile when N - n0 <= 128: N = 1408 is 5.5 tiles, 4224 is 16.5).  The same 2 x 4 wave
+// layout with 128 x 32 wave tiles: only the (a0, b0) and (a1, b0) quadrants exist, so a K-tile is TWO phases of 16 MFMAs and three
+// half-tiles of LDS-DMA ([A0 | A1 | B0], 48 KiB; B0 row r = column n0 + r).  Three K-tile buffers (144 KiB): tile t + 2 is staged
+// during tile t -- A0 and B0 in phase 0, A1 in phase 1 (each region was last read two phases earlier by the slowest wave: the WAR
+// distance of the full schedule) -- and read four phases after it was staged; the wait of the phase before the read allows the
+// younger loads of three phases in flight: phase 0 `vmcnt(10)` (A1(t) has landed behind 4 + 2 + 4 younger loads), phase 1 `vmcnt(8)`
+// (A0(t+1), B0(t+1) behind 2 + 4 + 2).  Tails: the tile before the last stages nothing (6 / 2), the last waits for everything.
+// Per K-tile the LDS reads are 12 + 8 fragments per wave against 12 + 4 + 8 + 0 of a full tile: 0.56 of its time, not 0.5.
+constexpr int PPH_BUF = 3 * PP_HALF;
+enum { H_A0 = 0, H_A1 = 1, H_B0 = 2 };
+
+template <int REGION>
+__device__ __forceinline__ void pph_stage(const PPState& s, int t, int buf) {
+    unsigned char* d = s.smem + buf * PPH_BUF + REGION * PP_HALF + s.dst;
+    const char* g = (REGION < 2 ? s.gA : s.gW) + (int64_t)t * (PP_BK * 2);
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + (uint64_t)s.off[REGION][0]), (lptr_t)d, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + (uint64_t)s.off[REGION][1]), (lptr_t)(d + 1024), 16, 0, 0);
+}
+
+// cur = buffer of tile t, nxt = buffer of tile t + 2
+template <int TAIL>
+__device__ __forceinline__ void pph_tile(const PPState& s, int t, int cur, int nxt, float4_t (&acc)[8][4], short8_t (&a)[4][2],
+                                         short8_t (&b0)[2][2]) {
+    const unsigned char* base = s.smem + cur * PPH_BUF;
+    // ---- phase 0: quadrant (a0, b0)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        b0[j][0] = *reinterpret_cast<const short8_t*>(base + H_B0 * PP_HALF + j * 2048 + s.lb0);
+        b0[j][1] = *reinterpret_cast<const short8_t*>(base + H_B0 * PP_HALF + j * 2048 + s.lb1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i][0] = *reinterpret_cast<const short8_t*>(base + H_A0 * PP_HALF + i * 2048 + s.la0);
+        a[i][1] = *reinterpret_cast<const short8_t*>(base + H_A0 * PP_HALF + i * 2048 + s.la1);
+    }
+    if constexpr (TAIL == 0) { pph_stage<H_A0>(s, t + 2, nxt); pph_stage<H_B0>(s, t + 2, nxt); pp_vmcnt<10>(); }
+    else if constexpr (TAIL == 1) { pp_vmcnt<6>(); } else { pp_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+    pp_mfma_block(acc, a, b0, 0, 0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: quadrant (a1, b0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i][0] = *reinterpret_cast<const short8_t*>(base + H_A1 * PP_HALF + i * 2048 + s.la0);
+        a[i][1] = *reinterpret_cast<const short8_t*>(base + H_A1 * PP_HALF + i * 2048 + s.la1);
+    }
+    if constexpr (TAIL == 0) { pph_stage<H_A1>(s, t + 2, nxt); pp_vmcnt<8>(); }
+    else if constexpr (TAIL == 1) { pp_vmcnt<2>(); } else { pp_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+    pp_mfma_block(acc, a, b0, 4, 0);
+    __builtin_amdgcn_s_barrier();
+}
+
 }  // namespace
 
 // Epilogue activation on 4 values; the bf16 kernels use a 1.5e-7-accurate erf (Abramowitz-Stegun 7.1.26) for GELU --
@@ -194,6 +249,7 @@ struct PPArgs {
     int* counters;
     int bf16_fast;      // bf16-only output that qualifies for pp_epilogue_bf16
     int gelu_poly;      // bf16-stored GELU on the packed polynomial (variant 4; default 0: the erf form)
+    int half_n;         // the last column tile runs the half-width schedule when N - n0 <= 128 (DEVQA_GEMM_HALFN=0 turns it off)
 };
 
 // tile id -> (tile_m, tile_n): grouped order (group_m row-tiles of one column-tile, then the next column-tile), so the
@@ -280,16 +336,22 @@ __device__ __forceinline__ void pp_mainloop(const PPArgs& g, unsigned char* smem
 // tile through a PRIVATE 16-KiB LDS region, 64 rows at a time, so that global accesses are row-contiguous: a lane owns
 // 4 consecutive columns of one row, 16 lanes cover 256 B (fp32) / 128 B (bf16) of it.
 // MFMA operands were fed swapped: acc[i][j][e] = C[i*16 + fr][j*16 + fq*4 + e].
-template <int ACT>
+// HALF (half-width column tile): the wave tile is 128 x 32 (acc[.][0..1]); 8 lanes cover a row's 128 B, 8 rows per step.
+template <int ACT, bool HALF = false>
 __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem, int m0, int n0, const float4_t (&acc)[8][4]) {
+    constexpr int NJ = HALF ? 2 : 4;        // 16-column blocks of the wave tile
+    constexpr int LPR = NJ * 4;             // lanes per row (4 columns each)
+    constexpr int RPI = 64 / LPR;           // rows per step
+    constexpr int NIT = 64 / RPI;           // steps per 64-row half
+    constexpr int RB = NJ * 64;             // staging row bytes
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     unsigned char* stg = smem + wave * 16384;
-    const int q = lane & 15;
-    const int gn = n0 + wc * 64 + q * 4;
+    const int q = lane % LPR, lrow = lane / LPR;
+    const int gn = n0 + wc * (NJ * 16) + q * 4;
     const bool col_ok = gn < g.N;
     const int M = g.M;
     const int64_t ldc = g.ldc;
@@ -299,14 +361,14 @@ __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem
     if (g.bias != nullptr && col_ok) bv = *reinterpret_cast<const float4*>(g.bias + gn);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        const int gm0 = m0 + wr * 128 + half * 64 + (lane >> 4);   // + it * 4
-        float4 rv[16];
-        if (residual != nullptr) {   // all 16 loads in flight before the first store (residual may alias out_f32).  Fetching the
+        const int gm0 = m0 + wr * 128 + half * 64 + lrow;   // + it * RPI
+        float4 rv[NIT];
+        if (residual != nullptr) {   // all loads in flight before the first store (residual may alias out_f32).  Fetching the
                                      // second half's rows under the first half's stores was measured 5-25 % SLOWER (loads
                                      // queue behind the stores, profiles/r01_summary.md section G)
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int gm = gm0 + it * 4;
+            for (int it = 0; it < NIT; ++it) {
+                const int gm = gm0 + it * RPI;
                 rv[it] = (col_ok && gm < M) ? *reinterpret_cast<const float4*>(residual + (int64_t)gm * ldc + gn)
                                             : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -314,15 +376,17 @@ __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int row = i * 16 + fr;
-                *reinterpret_cast<float4_t*>(stg + row * 256 + (((j * 4 + fq) ^ (row & 15)) << 4)) = acc[half * 4 + i][j];
+                const int sw = HALF ? ((row >> 1) & 7) : (row & 15);
+                *reinterpret_cast<float4_t*>(stg + row * RB + (((j * 4 + fq) ^ sw) << 4)) = acc[half * 4 + i][j];
             }
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 4 + (lane >> 4);
-            const float4_t sv = *reinterpret_cast<const float4_t*>(stg + row * 256 + ((q ^ (row & 15)) << 4));
-            const int gm = gm0 + it * 4;
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPI + lrow;
+            const int sw = HALF ? ((row >> 1) & 7) : (row & 15);
+            const float4_t sv = *reinterpret_cast<const float4_t*>(stg + row * RB + ((q ^ sw) << 4));
+            const int gm = gm0 + it * RPI;
             float4 v = make_float4((sv[0] + bv.x) * alpha, (sv[1] + bv.y) * alpha, (sv[2] + bv.z) * alpha, (sv[3] + bv.w) * alpha);
             v.x = pp_act<ACT>(v.x); v.y = pp_act<ACT>(v.y); v.z = pp_act<ACT>(v.z); v.w = pp_act<ACT>(v.w);
             if (residual != nullptr) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
@@ -345,8 +409,14 @@ __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem
 // 16-byte global stores (8 lanes cover the wave's 128-byte row segment).  Staging: per wave 2 x [64 rows][128 B], the 16-byte
 // chunk index XOR-swizzled with (row >> 1) & 7: the b64 writes of 16 rows x 2 lanes and the b128 reads of 2 rows x 8 lanes are
 // both bank-conflict-free.  Needs N % 8 == 0, ldc % 8 == 0 and a 16-byte aligned output (checked on the host: g.bf16_fast).
-template <int ACT>
+template <int ACT, bool HALF = false>
 __device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char* smem, int m0, int n0, const float4_t (&acc)[8][4]) {
+    constexpr int NJ = HALF ? 2 : 4;        // 16-column blocks of the wave tile (HALF: 128 x 32, a row is 64 B = 4 lanes)
+    constexpr int RB = NJ * 32;             // staging row bytes
+    constexpr int LPR = NJ * 2;             // lanes per row (16 B each)
+    constexpr int RPI = 64 / LPR;           // rows per step
+    constexpr int NIT = 64 / RPI;           // steps per 64-row half
+    constexpr int SWM = LPR - 1;            // chunk swizzle mask
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -354,22 +424,22 @@ __device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char*
     const int fr = lane & 15, fq = lane >> 4;
     unsigned char* stg = smem + wave * 16384;
     const float alpha = g.alpha;
-    float4 bj[4];
+    float4 bj[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wc * 64 + j * 16 + fq * 4;
+    for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wc * (NJ * 16) + j * 16 + fq * 4;
         bj[j] = (g.bias != nullptr && col < g.N) ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int rrow = lane >> 3, pc = lane & 7;
+    const int rrow = lane / LPR, pc = lane % LPR;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         unsigned char* area = stg + half * 8192;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = i * 16 + fr;
-            const int sw = (row >> 1) & 7;
+            const int sw = (row >> 1) & SWM;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const float4_t a = acc[half * 4 + i][j];
                 float v0, v1, v2, v3;
                 if (ACT == DEVQA_ACT_GELU && g.gelu_poly) {
@@ -383,18 +453,84 @@ __device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char*
                 uint2 p;
                 p.x = pp_pack2(v0, v1);
                 p.y = pp_pack2(v2, v3);
-                *reinterpret_cast<uint2*>(area + row * 128 + (((j * 2 + (fq >> 1)) ^ sw) << 4) + (fq & 1) * 8) = p;
+                *reinterpret_cast<uint2*>(area + row * RB + (((j * 2 + (fq >> 1)) ^ sw) << 4) + (fq & 1) * 8) = p;
             }
         }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + rrow;
-            const uint4 val = *reinterpret_cast<const uint4*>(area + row * 128 + (pc << 4));
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPI + rrow;
+            const uint4 val = *reinterpret_cast<const uint4*>(area + row * RB + (pc << 4));
             const int gm = m0 + wr * 128 + half * 64 + row;
-            const int gcol = n0 + wc * 64 + ((pc ^ ((row >> 1) & 7)) << 3);
+            const int gcol = n0 + wc * (NJ * 16) + ((pc ^ ((row >> 1) & SWM)) << 3);
             if (gm < g.M && gcol < g.N) *reinterpret_cast<uint4*>(g.out_bf16 + (int64_t)gm * g.ldc + gcol) = val;
         }
     }
+}
+
+// Half-width column tile: K-tiles [0, nk) of rows [m0, m0 + 256) x columns [n0, n0 + 128) -> acc[.][0..1] (wave (wr, wc): rows
+// wr * 128 + 0..127, columns wc * 32 + 0..31).  Same barrier count for every wave.
+__device__ __forceinline__ void pp_mainloop_half(const PPArgs& g, unsigned char* smem, int m0, int n0, int nk, float4_t (&acc)[8][4]) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    PPState s;
+    s.smem = smem;
+    s.gA = reinterpret_cast<const char*>(g.A);
+    s.gW = reinterpret_cast<const char*>(g.W);
+    s.dst = wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3);          // row inside the half-tile
+        const int sc = (lane & 7) ^ ((r >> 1) & 7);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int grow = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), g.M - 1);
+            s.off[h][i] = (unsigned)(((int64_t)grow * g.lda + sc * 8) * 2);          // H_A0 + h
+        }
+        const int gcol = min(n0 + r, g.N - 1);
+        s.off[H_B0][i] = (unsigned)(((int64_t)gcol * g.ldw + sc * 8) * 2);
+        s.off[3][i] = 0;
+    }
+    {
+        const int c0 = (fq ^ ((fr >> 1) & 7)) << 4;
+        s.la0 = wr * 8192 + fr * 128 + c0;
+        s.la1 = wr * 8192 + fr * 128 + (c0 ^ 64);
+        s.lb0 = wc * 4096 + fr * 128 + c0;
+        s.lb1 = wc * 4096 + fr * 128 + (c0 ^ 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    short8_t a[4][2], b0[2][2];
+    pph_stage<H_A0>(s, 0, 0);
+    pph_stage<H_B0>(s, 0, 0);
+    pph_stage<H_A1>(s, 0, 0);
+    if (nk > 1) {
+        pph_stage<H_A0>(s, 1, 1);
+        pph_stage<H_B0>(s, 1, 1);
+        pph_stage<H_A1>(s, 1, 1);
+        pp_vmcnt<8>();
+    } else {
+        pp_vmcnt<2>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier interval behind waves 0-3
+    int t = 0, cur = 0, nxt = 2;
+    for (; t + 2 < nk; ++t) {
+        pph_tile<0>(s, t, cur, nxt, acc, a, b0);
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt = nxt == 2 ? 0 : nxt + 1;
+    }
+    if (t + 1 < nk) {
+        pph_tile<1>(s, t, cur, nxt, acc, a, b0);
+        cur = cur == 2 ? 0 : cur + 1;
+        ++t;
+    }
+    pph_tile<2>(s, t, cur, nxt, acc, a, b0);
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // match the extra barrier of waves 4-7
 }
 
 template <int ACT, bool SK, bool BAL = false>
@@ -407,6 +543,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
         const int bid = blockIdx.x, nwg = g.dp_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         int tile_m, tile_n;
         pp_tile_coords(g, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx, tile_m, tile_n);
+        if (g.half_n && g.N - tile_n * PP_BN <= PP_BN / 2) {      // uniform: the half-width last column tile
+            pp_mainloop_half(g, smem, tile_m * PP_BM, tile_n * PP_BN, nk, acc);
+            if (g.bf16_fast) pp_epilogue_bf16<ACT, true>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
+            else pp_epilogue<ACT, true>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
+            return;
+        }
         pp_mainloop<BAL>(g, smem, tile_m * PP_BM, tile_n * PP_BN, 0, nk, acc);
         if (g.bf16_fast) pp_epilogue_bf16<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
         else pp_epilogue<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
@@ -482,10 +624,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
 
 template <int ACT, bool SK, bool BAL = false>
 static int launch_pp_k(const PPArgs& g, hipStream_t st) {
-    const size_t smem = 2 * PP_BUF;
+    const size_t smem = g.half_n ? 3 * PPH_BUF : 2 * PP_BUF;      // 144 KiB when the launch has a half-width column tile, else 128 KiB
     auto kern = gemm_bf16_pp_kernel<ACT, SK, BAL>;
     static std::atomic<unsigned> attr_done{0};
-    devqa_set_max_smem(kern, smem, attr_done);
+    devqa_set_max_smem(kern, 3 * PPH_BUF, attr_done);
     hipLaunchKernelGGL(kern, dim3(g.dp_tiles + g.sk_wgs), dim3(512), smem, st, g);
     DEVQA_LAUNCH_CHECK("gemm_bf16_pp");
     return DEVQA_OK;
@@ -502,6 +644,7 @@ static int launch_pp(const PPArgs& g, hipStream_t st) {
 }
 
 // id 6: group_m 4 with the fp32 LDS transposition for every output kind (A/B of pp_epilogue_bf16).
+// id 7: group_m 4 with a full-width schedule on every column tile (A/B of the half-width last column tile).
 // id: 0 group_m 8, 1 group_m 1 (plain column-major tile order), 2 group_m 4 (default), 3 group_m 16,
 //     4 = 2 (was: group_m 4 + a stream-K tail.  The partial-tile hand-off -- 256 KiB per segment through HBM/L2 plus an
 //       agent-scope acq_rel RMW whose release/acquire writes back / invalidates the XCD's L2 -- cost more than the partial round it
@@ -510,8 +653,8 @@ static int launch_pp(const PPArgs& g, hipStream_t st) {
 //       is kept but no longer instantiated.)
 int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K, float alpha,
                    int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc, hipStream_t st) {
-    static const int gms[7] = {8, 1, 4, 16, 4, -4, 4};
-    if (id < 0 || id > 6) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
+    static const int gms[8] = {8, 1, 4, 16, 4, -4, 4, 4};
+    if (id < 0 || id > 7) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
     if (K % PP_BK != 0 || K < PP_BK) return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: K=%d must be a positive multiple of 64", K);
     if ((int64_t)M * lda * 2 >= (1ll << 32) || (int64_t)N * ldw * 2 >= (1ll << 32))
         return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: operands must span < 4 GiB (32-bit lane offsets)");
@@ -527,6 +670,8 @@ int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_
                   (((uintptr_t)out_bf16) & 15) == 0 && (bias == nullptr || (((uintptr_t)bias) & 15) == 0);
     if (id == 6) g.bf16_fast = 0;       // A/B: the fp32 transposition for every output kind
     g.gelu_poly = id == 4;              // variant 4 (DEVQA_GEMM=24): bf16-stored GELU on the packed polynomial
+    static const int halfn_env = getenv("DEVQA_GEMM_HALFN") ? atoi(getenv("DEVQA_GEMM_HALFN")) : 1;
+    g.half_n = halfn_env && id != 7 && g.group_m > 0 && N - (g.tiles_n - 1) * PP_BN <= PP_BN / 2;     // id 7: A/B without it
     switch (act) {
         case DEVQA_ACT_NONE: return launch_pp<DEVQA_ACT_NONE>(g, st);
         case DEVQA_ACT_RELU: return launch_pp<DEVQA_ACT_RELU>(g, st);

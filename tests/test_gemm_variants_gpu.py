@@ -44,6 +44,47 @@ def test_gemm_variants(L, mode, M, N, K, act, res):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=3e-4, rtol=3e-4)
 
 
+# Last column tile at most 128 columns wide: the ping-pong kernel's half-width schedule (2 phases per K-tile, three 48-KiB K-tile
+# buffers, `pp_mainloop_half`); nk = 1, 2, 3 walk its prologue / tail waits, every epilogue kind its 128 x 32 wave tiles.
+@pytest.mark.parametrize("M,N,K,act,res,want", [
+    (700, 128, 64, 0, False, "bf16"),       # one half tile, one K-tile
+    (513, 384, 128, 1, False, "bf16"),      # 1.5 column tiles, two K-tiles, ragged M
+    (256, 1408, 192, 0, True, "f32"),       # 5.5 column tiles, three K-tiles, in-place fp32 residual
+    (1000, 96, 1408, 2, False, "bf16"),     # fewer than 128 columns, GELU
+    (300, 1404, 256, 0, False, "bf16"),     # N % 8 != 0: fp32 transposition on the half tile
+    (300, 1404, 256, 0, False, "f32"),
+    (2048, 4224, 1408, 0, False, "bf16"),   # ViT QKV: 16.5 column tiles
+    (1030, 1408, 1408, 0, True, "f32"),     # ViT projection
+    (600, 200, 320, 3, True, "both"),       # both outputs + residual, quick-GELU, ragged half tile (72 columns)
+])
+def test_gemm_half_width_column_tile(L, M, N, K, act, res, want):
+    L.gemm_set_mode(22)
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if res else None
+    ref = a.float() @ w.float().T + b
+    ref = {0: lambda t: t, 1: torch.relu, 2: torch.nn.functional.gelu, 3: lambda t: t * torch.sigmoid(1.702 * t)}[act](ref)
+    if res:
+        ref = ref + r
+    guard = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    gf = torch.full((M + 2, N), 7.0, device="cuda")
+    if res:
+        gf[1:M + 1] = r.cuda()
+    ob = guard[1:M + 1] if want in ("bf16", "both") else None
+    of = gf[1:M + 1] if (want in ("f32", "both") or res) else None
+    L.gemm(a.cuda(), w.cuda(), b.cuda(), 1.0, act, of if res else None, out_bf16=ob, out_f32=of)
+    torch.cuda.synchronize()
+    L.gemm_set_mode(0)
+    assert float(guard[0].float().min()) == 7.0 and float(guard[M + 1].float().max()) == 7.0
+    assert float(gf[0].min()) == 7.0 and float(gf[M + 1].max()) == 7.0
+    if of is not None:
+        np.testing.assert_allclose(of.cpu().numpy(), ref.numpy(), atol=3e-4, rtol=3e-4)
+    if ob is not None:
+        np.testing.assert_allclose(ob.float().cpu().numpy(), ref.numpy(), atol=1.2e-2, rtol=8e-3)
+
+
 @pytest.mark.parametrize("M,N,K,act,res,want", [
     (48, 10240, 2560, 1, False, "bf16"),    # OPT fc1 at B = 1: auto split-K (80 column tiles -> 6 K-slices) + fused epilogue
     (33, 2560, 10240, 0, True, "f32"),      # OPT fc2 with the in-place fp32 residual

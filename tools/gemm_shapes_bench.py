@@ -27,7 +27,7 @@ def t_us(fn, n=20):
 def main():
     lib.load()
     modes = [int(x) for x in sys.argv[1:]] or [0, 26]
-    M = 32639
+    M = int(os.environ.get("GEMM_M", 32639))        # 32639 = one 127-image ViT chunk; 130556 = the 508 images of a 127-cycle batch
     tot = {m: 0.0 for m in modes}
     for name, N, K, kind, m_rows in (("qkv", 4224, 1408, "bias", M), ("fc1", 6144, 1408, "gelu", M), ("proj", 1408, 1408, "resid", M),
                                      ("fc2", 1408, 6144, "resid", M), ("opt_fc1", 10240, 2560, "relu", 20400),
