@@ -16,7 +16,7 @@ def L():
     lib.gemm_set_mode(0)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
 @pytest.mark.parametrize("M,N,K,act,res", [
     (4099, 4224, 1408, 0, False),     # 128x128 (mode 0/1) or 256x128 (mode 2); ragged M
     (16448, 1408, 6144, 0, True),     # ViT fc2 shape, in-place residual
