@@ -397,8 +397,11 @@ __device__ __forceinline__ int am_swz(int R) {
     return CH == 8 ? (R & 7) : CH == 16 ? ((2 * R) & 15) : ((R >> 1) & 3);
 }
 
-template <int DHP, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 8 && DHP <= 96) ? 4 : 2) void attention_mfma_dma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+// SB (single-buffered, NW = 2: 32-query tiles) is the form for packs of SHORT sequences (the decoder pack of the edit+eval path: 32 image
+// tokens or <= ~25 text tokens per sequence behind a 32-key visible prefix, one or two chunks each): nothing to overlap a second image with,
+// so one image (24 KiB at dh 80: 6 workgroups per CU instead of 3) and two waves per (sequence, head) double the pairs in flight per CU.
+template <int DHP, int NW, bool SB = false>
+__global__ __launch_bounds__(64 * NW, ((NW == 8 && DHP <= 96) || SB) ? 4 : 2) void attention_mfma_dma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                  const bf16_t* __restrict__ k, int64_t ldk,
                                                                  const bf16_t* __restrict__ v, int64_t ldv,
                                                                  bf16_t* __restrict__ out, int64_t ldo,
@@ -413,8 +416,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DHP <= 96) ? 4 : 2) void atten
     constexpr int LD = 2 * NI / NW;        // ... per wave and chunk, K and V images together: instruction j * NW + wave of the list K | V
     constexpr int QT = 16 * NW;            // queries per workgroup
     static_assert(2 * NI % NW == 0, "chunk must split evenly over the waves");
-    __shared__ __attribute__((aligned(1024))) unsigned char Ks2[2 * IMG];
-    __shared__ __attribute__((aligned(1024))) unsigned char Vs2[2 * IMG];
+    __shared__ __attribute__((aligned(1024))) unsigned char Ks2[(SB ? 1 : 2) * IMG];
+    __shared__ __attribute__((aligned(1024))) unsigned char Vs2[(SB ? 1 : 2) * IMG];
 
     int bid = blockIdx.x;
     {
@@ -451,18 +454,28 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DHP <= 96) ? 4 : 2) void atten
     float m_run = -INFINITY, l_run = 0.f;
     const float sc2 = scale * 1.44269504088896340736f;
     // ---- staging: DMA instruction j of this wave fills LDS bytes [(j * 4 + wave) * 1024, + 1024) of an image ----
-    int st_row[LD], st_col[LD];
-    uint32_t f_off[LD];
+    // SB: the K and the V piece j, j + LD / 2 of a wave are the same block of their images (LD / 2 * NW == NI), so their row / column
+    // constants are kept once and the fast path's element offset is formed at use (two waves per workgroup: registers, not issue slots,
+    // bound how many of them a CU holds)
+    constexpr int LDH = SB ? LD / 2 : LD;
+    static_assert(!SB || (LD % 2 == 0 && (LD / 2 * NW) % NI == 0), "K / V pieces of a wave must pair up");
+    int st_row[LDH], st_col[LDH];
+    uint32_t f_off[SB ? 1 : LD];
 #pragma unroll
-    for (int j = 0; j < LD; ++j) {
+    for (int j = 0; j < LDH; ++j) {
         const int blk = (j * NW + wave) % NI;                 // 1-KiB block of its image (wave-uniform, as is the image)
-        const bool is_v = (j * NW + wave) >= NI;
         const int p = blk * 64 + lane;
         const int R = p / CH, cp = p - R * CH;
         const int c = cp ^ am_swz<CH>(R);
         st_row[j] = R;
         st_col[j] = h * dh + min(c * 8, dh - 8);     // channel padding re-reads the last real channels (see the kernel above)
-        f_off[j] = (uint32_t)(R * (int)(is_v ? ldv : ldk) + st_col[j]);
+    }
+    if constexpr (!SB) {
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            const bool is_v = (j * NW + wave) >= NI;
+            f_off[j] = (uint32_t)(st_row[j] * (int)(is_v ? ldv : ldk) + st_col[j]);
+        }
     }
     const bool one_range = kp_len == 0 || own_hi == 0;
     const bool fast_rows = one_range && (int64_t)(AM_KC - 1) * max(ldk, ldv) + h * dh + DHP < (1ll << 31);
@@ -475,13 +488,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DHP <= 96) ? 4 : 2) void atten
         if (blk * 64 / CH >= ((n_keys - (C0) + 31) & ~31)) continue;   /* a last, partial chunk: only the 32-key k-steps of P.V that hold a key (their rows must be finite: p = 0 multiplies them) */ \
         unsigned char* dst = (is_v ? Vs2 : Ks2) + (BUFI) * IMG + blk * 1024;                                                \
         const int64_t ld = is_v ? ldv : ldk;                                                                                \
+        const int jj = SB ? j % LDH : j;                                                                                    \
         if (fast_rows && (C0) + AM_KC <= n_keys) {                                                                          \
             const bf16_t* gb = (is_v ? v_own : k_own) + (int64_t)(C0) * ld;                                                 \
-            __builtin_amdgcn_global_load_lds((am_gptr_t)(gb + f_off[j]), (am_lptr_t)dst, 16, 0, 0);                         \
+            const uint32_t fo = SB ? (uint32_t)(st_row[jj] * (int)ld + st_col[jj]) : f_off[SB ? 0 : j];                     \
+            __builtin_amdgcn_global_load_lds((am_gptr_t)(gb + fo), (am_lptr_t)dst, 16, 0, 0);                               \
         } else {                                                                                                            \
-            const int kidx = min((C0) + st_row[j], n_keys - 1);                                                             \
+            const int kidx = min((C0) + st_row[jj], n_keys - 1);                                                            \
             const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);        \
-            __builtin_amdgcn_global_load_lds((am_gptr_t)((is_v ? v : k) + grow * ld + st_col[j]), (am_lptr_t)dst, 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((am_gptr_t)((is_v ? v : k) + grow * ld + st_col[jj]), (am_lptr_t)dst, 16, 0, 0); \
         }                                                                                                                   \
     }
     // ---- fragment addresses inside an image (lane constants; tile / k-step offsets are immediates) ----
@@ -498,12 +513,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DHP <= 96) ? 4 : 2) void atten
     if (n_keys > 0) { AMD_STAGE(0, 0) }
     int bi = 0;
     for (int c0 = 0; c0 < n_keys; c0 += AM_KC, bi ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk c0 have landed
-        __syncthreads();                                    // ... everybody's have, and buffer bi ^ 1 (chunk c0 - 64) is consumed
-        if (c0 + AM_KC < n_keys) { AMD_STAGE(c0 + AM_KC, bi ^ 1) }
+        if constexpr (SB) {
+            if (c0 > 0) {
+                __syncthreads();                            // every wave is done with chunk c0 - 64: the one image can be refilled
+                AMD_STAGE(c0, 0)
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk c0 have landed
+            __syncthreads();                                    // ... everybody's have, and buffer bi ^ 1 (chunk c0 - 64) is consumed
+            if (c0 + AM_KC < n_keys) { AMD_STAGE(c0 + AM_KC, bi ^ 1) }
+        }
         if (!wave_has_rows) continue;
-        const unsigned char* Ks = Ks2 + bi * IMG;
-        const unsigned char* Vs = Vs2 + bi * IMG;
+        const unsigned char* Ks = Ks2 + (SB ? 0 : bi) * IMG;
+        const unsigned char* Vs = Vs2 + (SB ? 0 : bi) * IMG;
         auto body = [&](auto full_tag) {
             constexpr bool FULLC = decltype(full_tag)::value;
             const int nt = FULLC ? 4 : min(4, (n_keys - c0 + 15) >> 4);
@@ -840,7 +864,16 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     // 133 -> 116 us); short sequences fill 64-query tiles better (T = 128: 43.6 vs 47.3 us)
     int dma_nw = max_q_len >= 224 ? 8 : 4;
     if (nw_env && (atoi(nw_env) == 8 || atoi(nw_env) == 4)) dma_nw = atoi(nw_env);
-    const int qt = dma ? 16 * dma_nw : 16 * nw * qb;
+    // causal packs of short sequences (decoder probes): 32-query tiles of two waves on ONE LDS-DMA image (attention_mfma_dma_kernel<D, 2, true>);
+    // non-causal short-query calls (Q-Former: 32 queries over 257 keys) keep the register-staged kernel
+    const char* short_env = getenv("DEVQA_ATTENTION_SHORT");
+    // measured on a 127-cycle probe pack (tools/debug/att_pack_bench.py, 2159 sequences): OPT heads (dh 80) 368.6 us against 362.6 us for the
+    // register-staged kernel -- the pack is bound by the instructions issued per (sequence, head), not by the pairs in flight, and both forms
+    // issue about the same; LLaMA heads (dh 128, where the register-staged form holds two workgroups per CU) 57.8 against 72.1 us.  Default:
+    // dh 128 only; DEVQA_ATTENTION_SHORT=1 forces it for every head size, =0 turns it off
+    const bool short_ok = short_env ? atoi(short_env) != 0 : dhp == 128;
+    const bool dma_short = causal && !dma && !dma_env && nw == 4 && qb == 1 && !dbuf && exp_id == 0 && !nw_env && max_q_len <= 64 && short_ok;
+    const int qt = dma_short ? 32 : dma ? 16 * dma_nw : 16 * nw * qb;
     const int q_tiles = (max_q_len + qt - 1) / qt;
     const long grid = (long)n_seq * H * q_tiles;
     DEVQA_CHECK_SHAPE(grid < 2147483647L, "attention: grid too large");
@@ -853,6 +886,9 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
         else if (dbuf)                                                                                                 \
             hipLaunchKernelGGL((attention_mfma_kernel<(D <= 96 ? D : 96), 1, true>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, \
                                k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                     \
+        else if (dma_short)                                                                                            \
+            hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 2, true>), dim3((unsigned)grid), dim3(128), 0, st, q, ldq, k, ldk, v, ldv, \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                     \
         else if (dma) {                                                                                                \
             if (dma_nw == 8)                                                                                           \
                 hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 8>), dim3((unsigned)grid), dim3(512), 0, st, q, ldq, k, ldk, v, ldv, \

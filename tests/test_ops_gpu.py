@@ -109,8 +109,8 @@ def _ref_attention(q, k, v, desc, H, dh, scale, causal):
     return out
 
 
-@pytest.mark.parametrize("name", ["vit", "qformer_cross", "opt_causal", "opt_prefix", "tiny_heads", "clip_l_577", "llama_dh128",
-                                  "llama_prefix_576"])
+@pytest.mark.parametrize("name", ["vit", "qformer_cross", "opt_causal", "opt_prefix", "opt_pack_short", "llama_pack_short", "tiny_heads",
+                                  "clip_l_577", "llama_dh128", "llama_prefix_576"])
 def test_attention(L, name):
     g = torch.Generator().manual_seed(11)
     if name == "vit":  # 2 images x 257 tokens, fused qkv buffer
@@ -163,6 +163,20 @@ def test_attention(L, name):
             v = bf(torch.randn(576 + 20 + 70, H * dh, generator=g))
             desc = [(0, 576, 0, 0, 0, 576), (576, 20, 0, 576, 576, 20), (596, 70, 0, 576, 596, 70)]
             causal, scale = 1, dh ** -0.5
+        elif name in ("opt_pack_short", "llama_pack_short"):
+            # a decoder probe pack: two 32-row prefixes + texts of 1..64 rows behind them (one or two key chunks, one or two 32-query
+            # tiles) and texts without a prefix -- the default for it is the single-image two-wave LDS-DMA kernel
+            H, dh = (32, 80) if name == "opt_pack_short" else (8, 128)
+            lens = [32, 5, 17, 31, 32, 25, 1, 64, 33, 9]
+            pre = [None, 0, 0, 0, None, 4, 4, 4, None, None]      # index of the prefix sequence each one sees
+            st = np.cumsum([0] + lens)
+            tot = int(st[-1])
+            q = bf(torch.randn(tot, H * dh, generator=g))
+            k = bf(torch.randn(tot, H * dh, generator=g))
+            v = bf(torch.randn(tot, H * dh, generator=g))
+            desc = [(int(st[i]), lens[i], int(st[pre[i]]) if pre[i] is not None else 0, lens[pre[i]] if pre[i] is not None else 0,
+                     int(st[i]), lens[i]) for i in range(len(lens))]
+            causal, scale = 1, (1.0 if dh == 80 else dh ** -0.5)
         elif name == "opt_prefix":  # prefix seq (32 rows) + two text seqs attending to it
             H, dh = 32, 80
             q = bf(torch.randn(32 + 16 + 21, H * dh, generator=g))
@@ -187,7 +201,7 @@ def test_attention(L, name):
     import os
     outs = {}
     for var in ({"DEVQA_ATTENTION_DMA": "0"}, {"DEVQA_ATTENTION_DMA": "1", "DEVQA_ATTENTION_NW": "4"},
-                {"DEVQA_ATTENTION_DMA": "1", "DEVQA_ATTENTION_NW": "8"}):
+                {"DEVQA_ATTENTION_DMA": "1", "DEVQA_ATTENTION_NW": "8"}, {"DEVQA_ATTENTION_SHORT": "0"}, {"DEVQA_ATTENTION_SHORT": "1"}):
         os.environ.update(var)
         try:
             o = L.attention(views[0], views[1], views[2], d, len(desc), max(x[1] for x in desc), H, dh, scale, causal)
@@ -197,7 +211,7 @@ def test_attention(L, name):
         np.testing.assert_allclose(o.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=2e-2, err_msg=str(var))
         outs[tuple(sorted(var.items()))] = o
     vals = list(outs.values())
-    assert torch.equal(vals[0], vals[1]) and torch.equal(vals[0], vals[2]) and torch.equal(vals[0], out)
+    assert all(torch.equal(vals[0], x) for x in vals[1:]) and torch.equal(vals[0], out)
     if name == "vit":   # the opt-in K/V-resident kernel (self_full promise; enough (sequence, head) pairs to be selected: 8 x 16)
         qkv8 = bf(torch.randn(8 * n, 3 * H * dh, generator=g))
         d8 = [(i * n, n, 0, 0, i * n, n) for i in range(8)]
