@@ -4,12 +4,12 @@ import it).
 Restates R/editor/vllms_for_edit/minigpt4/minigpt4.py:33-68 and modules/minigpt4.py:88-111,214-241 (`encode_img`,
 `get_context_emb`) in plain PyTorch fp32 on a flat {MiniGPT-4 state-dict name: tensor} dict.
 
-PARITY UNPINNED by the reference itself: MiniGPT4ForEdit cannot be imported here (needs omegaconf, peft and
-`LLAMA_INPUTS_DOCSTRING`, all absent), and the reference holds no fixture for it.  What pins this
-restatement instead: the EVA-ViT / Q-Former / projection arithmetic is the SAME code path as OracleBlip2's (pinned by
-HF-BLIP-2 goldens; tests/test_oracle_minigpt4.py feeds renamed tiny-BLIP-2 weights through this class and compares
-with those goldens), the LLaMA decoder is OracleLlava's (pinned by HF-LLaVA goldens); only the composition (segment
-tokenisation, [BOS] + 32 query rows + text, vt_range = [1, 33], right padding) is restated from the reference source.
+Pinning: the IMAGE HALF (`encode_img`) is checked against the reference's own `modules/eva_vit.py` + `modules/Qformer.py` run the way
+`encode_img` runs them (tests/golden/tiny_minigpt4_vision_goldens.npz from tools/make_goldens_minigpt4_vision.py;
+tests/test_oracle_minigpt4.py::test_vision_path_against_reference_modules: parameter names, ln_vision(ViT(x)), inputs_llama at 2e-5).
+The LLaMA decoder is OracleLlava's (HF LlamaForCausalLM goldens; the reference's modeling_llama.py subclasses that class).
+PARITY UNPINNED for the composition only (segment tokenisation, [BOS] + 32 query rows + text, vt_range = [1, 33], right padding):
+MiniGPT4ForEdit cannot be imported here (needs omegaconf and peft, absent) and the reference holds no fixture for it.
 """
 import torch
 
