@@ -1,6 +1,7 @@
 """GPU: native MiniGPT-4 wrapper + FT_VL + evaluator (generic and batched) against the CPU oracle on the same seeded
-tiny model.  PARITY UNPINNED by the reference for this model family (MiniGPT4ForEdit cannot be imported here and the
-reference ships no fixture); the oracle's two halves are pinned by HF goldens in tests/test_oracle_minigpt4.py."""
+tiny model.  The image path is pinned by the reference's own modules (test_image_path_against_reference_modules); the wrapper's
+COMPOSITION is parity-unpinned (MiniGPT4ForEdit needs omegaconf / peft and the reference ships no fixture): there the oracle, whose
+two halves are pinned in tests/test_oracle_minigpt4.py, is the checker."""
 import json
 import os
 from copy import deepcopy

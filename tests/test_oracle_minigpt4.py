@@ -1,5 +1,6 @@
 """CPU: the MiniGPT-4 oracle restatement.  The reference's MiniGPT4ForEdit cannot be imported (omegaconf / peft absent)
 and holds no fixture: PARITY UNPINNED by the reference for the composition.  What is pinned here:
+  * image path vs the REFERENCE's own modules/eva_vit.py + modules/Qformer.py (test_vision_path_against_reference_modules);
   * vision half: tiny-BLIP-2 weights renamed to MiniGPT-4 names through OracleMiniGPT4.encode_img must reproduce the
     image-token rows of the HF-BLIP-2 golden `inputs_embeds` (same EVA-ViT / Q-Former / projection arithmetic);
   * decoder half: OracleMiniGPT4 over tiny-LLaVA's LLaMA weights gives OracleLlava's logits on the same embeddings;
