@@ -56,6 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cycles", type=int, default=1, help="fully timed reference-style oracle cycles of the cpu_baseline leg")
     ap.add_argument("--no-hbm-micro", action="store_true", help="skip the dense-AdamW / cosine top-k HBM measurements")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-depth parity block (GPU bf16 / fp32 mode vs the oracle cycle of cpu_baseline)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs #3-#5 legs (LLaVA + FT_VL, BLIP-2 + MEND_VL, MiniGPT-4 + IKE_VL)")
+    ap.add_argument("--config-cycles", type=str, default="32,64,16", help="cycles of the three configs legs (llava_ft, blip2_mend, minigpt4_ike)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the two stages of every batch back to back on one stream")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--selftest-cpu", action="store_true")
@@ -135,7 +138,7 @@ def build_full_model(dev, seed, layers=None, threads=16, keep_host_copy=False, s
     return model, cfg, kept
 
 
-def cpu_baseline(cfg, seed, threads, arrays, cycles, n_cycles, style="opt"):
+def cpu_baseline(cfg, seed, threads, arrays, cycles, n_cycles, style="opt", trace=False):
     """The oracle (CPU restatement of the reference path, fp32, full BLIP-2-OPT-2.7B dims) timed on `n_cycles` COMPLETE
     reference-style cycles (oracle.devqa_oracle.faithful_cycle_pretokenized: 9 pre-edit forwards, <= 25 x [image encode + forward +
     backward + torch.optim.AdamW], 12 post-edit forwards; nothing cached -- SURVEY.md 3.1) after one un-timed warm-up call (one
@@ -164,8 +167,9 @@ def cpu_baseline(cfg, seed, threads, arrays, cycles, n_cycles, style="opt"):
         x, _, _ = O._pretok_xym(m, cyc[0]["requests"][0]["prompt"], cyc[0]["requests"][0]["image"], cyc[0]["requests"][0]["target_new"])
         m.get_llm_outpt(x, None)
     t0 = time.time()
-    info = [O.faithful_cycle_pretokenized(m, c, wname, 25, 1e-3, 0.0) for c in cyc]
+    info = [O.faithful_cycle_pretokenized(m, c, wname, 25, 1e-3, 0.0, trace=trace) for c in cyc]
     dt = time.time() - t0
+    cpu_baseline.last_traces = info
     return {"value": len(cyc) / dt, "unit": "cycles/s", "cores": threads, "kind": "port",
             "sample": "%d complete reference-style cycle(s) (%d image encodes, %d decoder forwards, %d FT steps with backward + "
                       "torch.optim.AdamW each), fp32 torch CPU oracle at full BLIP-2-OPT-2.7B dims, %.1f s after one warm-up "
@@ -222,6 +226,128 @@ def hbm_micro(dev, d_out=2560, d_in=10240):
                 "bytes_per_query_batch": 4 * N * D, "avg_call_us": round(us, 1), "achieved": round(4.0 * N * D / (us * 1e-6) / 1e9, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(4.0 * N * D / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "gflops": round(2.0 * N * D * q_n / (us * 1e-6) / 1e9, 1)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# full-depth parity of the BENCHMARKED configuration (39/12/32 layers): the batched HIP engine vs the oracle cycle that the
+# cpu_baseline leg runs anyway.  The oracle (oracle/devqa_oracle.py) is the checker here, never the thing measured.
+# ---------------------------------------------------------------------------------------------------------------------------------
+POST_ORDER = ["rel", "text_rephrase", "image_rephrase"]
+
+
+def gpu_parity_capture(editor, cycles_host, n_cmp, E, dev):
+    """The first n_cmp of `cycles_host` (devqa_amd.synth.evqa_cycles samples with pre-processed CPU pixel tensors) run as members
+    of ONE batch of E cycles through BatchedEditEval -- the benchmarked engine with its shared-prefix packing, column compaction
+    and device-side FT loop, at the batch size the timed region uses -- with the label-row logits kept.  -> per compared cycle:
+    {pre: {probe: [L, V]}, post: {probe: [L, V]}, steps, losses [steps], accs [12]} (host arrays)."""
+    import numpy as np
+    import torch
+    from devqa_amd.batched import BatchedEditEval, LOC_ORDER, copy_sample
+
+    def on_dev(c):
+        def fix(it):
+            return dict(it, image=None if it["image"] is None else it["image"].to(dev))
+        return {"requests": [fix(c["requests"][0])], "generality": {k: [fix(v[0])] for k, v in c["generality"].items()},
+                "locality": {k: [fix(v[0])] for k, v in c["locality"].items()}}
+    eds = [on_dev(c) for c in cycles_host[:E]]
+    be = BatchedEditEval(editor, cycles_per_batch=len(eds))
+    be.keep_debug = True
+    out, _ = be.run_batch([copy_sample(c) for c in eds], eds)
+    torch.cuda.synchronize()
+    caps = []
+    for i in range(n_cmp):
+        pre, post = {}, {}
+        for kind, name, row0, L in be.debug["rows"][i]:
+            key = "rel" if kind == "rel" else name
+            post[key] = be.debug["post_logits"][row0:row0 + L].float().cpu().numpy()
+            if kind == "loc":
+                pre[key] = be.debug["pre_logits"][row0:row0 + L].float().cpu().numpy()
+        n = int(be.last_steps[i])
+        r = out[i]
+        accs = [r["reliability"][0]["acc"]] + [r["generality"][k][0]["acc"] for k in ("text_rephrase", "image_rephrase")] + \
+               [r["locality"][k][0]["acc"] for k in LOC_ORDER]
+        caps.append({"pre": pre, "post": post, "steps": n, "losses": np.array(be.last_losses[i, :n]), "accs": accs, "batch": len(eds)})
+    be.debug.clear()
+    del be
+    torch.cuda.empty_cache()
+    return caps
+
+
+def fp32_parity_capture(cfg, arrays, cycles_host, n_cmp, E, dev, num_layers_last):
+    """The same cycles through the same engine in its fp32 ("faithful") compute mode -- exact-fp32 MFMA GEMMs, fp32 weights -- at
+    full depth: separates what the algorithmic restructuring (de-duplication, prefix sharing, compaction) changes (nothing, to
+    fp32 reassociation) from what bf16 rounding through 39 + 12 + 32 layers changes."""
+    import torch
+    from devqa_amd.editor.vllm_editors.ft_vl.ft_vl import FTvl, FTvlConfig
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from devqa_amd.editor.vllms_for_edit.blip2.modeling import Blip2Native
+    from devqa_amd.synth import IdTokenizer
+    model = Blip2Native(cfg, dev, "fp32")
+    for n in model._shapes:
+        model.load_named_tensors(lambda _n, a=arrays[n]: torch.from_numpy(a), names=[n], refresh=False)
+    model.refresh_derived(force=True)
+    vllm = BLIP2OPTForEdit(None, dev, model=model, tokenizer=IdTokenizer())
+    ft_cfg = FTvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "ft_vl", "blip2-opt-2.7b.yaml"))
+    ft_cfg.layers = [num_layers_last]
+    caps = gpu_parity_capture(FTvl(vllm, ft_cfg, dev), cycles_host, n_cmp, E, dev)
+    del vllm, model
+    torch.cuda.empty_cache()
+    return caps
+
+
+def parity_compare(cap, tr, bar):
+    """One cycle: engine capture vs oracle trace (faithful_cycle_pretokenized(trace=True)).  Relative errors are |got - ref| over
+    the largest |ref| of the probe's label rows (logits, row logsumexp) resp. over max(ref loss, 1) (per-step FT losses) -- the
+    scales tests/test_realdim_batched_gpu.py uses.  `decided` rows: the oracle's own top-1 margin exceeds 2 x bar x scale."""
+    import numpy as np
+    from devqa_amd.batched import LOC_ORDER
+
+    def lse(a):
+        m = a.max(1, keepdims=True)
+        return (m + np.log(np.exp(a - m).sum(1, keepdims=True)))[:, 0]
+
+    def cmp(got_map, refs, names):
+        w = wl = 0.0
+        rows = agree = dec_n = dec_ok = 0
+        for name, ref in zip(names, refs):
+            ref = ref.numpy().astype(np.float64)
+            got = got_map[name].astype(np.float64)
+            scale = float(np.abs(ref).max())
+            w = max(w, float(np.abs(got - ref).max()) / scale)
+            wl = max(wl, float(np.abs(lse(got) - lse(ref)).max()) / scale)
+            top2 = np.sort(np.partition(ref, -2, axis=1)[:, -2:], axis=1)
+            dec = (top2[:, 1] - top2[:, 0]) > 2 * bar * scale
+            ok = got.argmax(1) == ref.argmax(1)
+            rows += len(ok)
+            agree += int(ok.sum())
+            dec_n += int(dec.sum())
+            dec_ok += int((ok & dec).sum())
+        return w, wl, rows, agree, dec_n, dec_ok
+    pre = cmp(cap["pre"], tr["rows"][:9], LOC_ORDER)
+    post = cmp(cap["post"], tr["rows"][9:], POST_ORDER + LOC_ORDER)
+    m = min(cap["steps"], tr["steps"])
+    ref_l = np.asarray(tr["losses"][:m], np.float64)
+    loss_err = float((np.abs(cap["losses"][:m] - ref_l) / np.maximum(ref_l, 1.0)).max()) if m else 0.0
+    return {"steps_gpu": cap["steps"], "steps_ref": tr["steps"], "loss_rel_max": round(loss_err, 5),
+            "loss_first_ref": round(float(ref_l[0]), 4) if m else None, "loss_last_ref": round(float(ref_l[-1]), 5) if m else None,
+            "logit_rel_max_pre": round(pre[0], 5), "logit_rel_max_post": round(post[0], 5),
+            "lse_rel_max": round(max(pre[1], post[1]), 5),
+            "argmax_rows_equal": "%d/%d" % (pre[3] + post[3], pre[2] + post[2]),
+            "argmax_decided_rows_equal": "%d/%d" % (pre[5] + post[5], pre[4] + post[4]),
+            "probes_equal": "%d/12" % sum(abs(a - b) < 1e-6 for a, b in zip(cap["accs"], tr["accs"])),
+            "batch_cycles": cap["batch"], "bar": bar}
+
+
+def parity_block(traces, caps_bf16, caps_fp32):
+    out = {"reference": "oracle/devqa_oracle.py faithful_cycle_pretokenized: the reference's call sequence (nothing cached, B = 1), fp32 torch CPU, "
+                        "full depth 39/12/32 -- the same cycle cpu_baseline times",
+           "quantities": "label-row logits of the 9 pre-edit + 12 post-edit evaluator forwards (error / max |ref| of the probe's rows), their row "
+                         "logsumexp, argmax, per-step FT losses (error / max(ref, 1)), executed steps, the 12 per-probe accuracies"}
+    if caps_bf16 is not None:
+        out["bf16"] = [parity_compare(c, t, 1e-2) for c, t in zip(caps_bf16, traces)]
+    if caps_fp32 is not None:
+        out["fp32_mode"] = [parity_compare(c, t, 1e-3) for c, t in zip(caps_fp32, traces)]
     return out
 
 
@@ -487,13 +613,19 @@ def main():
         torch.cuda.synchronize()
 
     head_style = "survey" if args.ffn == "dense" else "opt"
+    want_parity = want_cpu and not args.no_parity and layers is None
+    n_cmp = max(1, args.cpu_cycles)
     leg = Leg(args, rank, world, dev, head_style, layers, keep_host_copy=want_cpu)
     elapsed, n_local, n_total, ranks = timed_leg(leg, K, W, barrier, use_dist, rank, world, dev)
     out = None
     if rank == 0:
         value = n_total / elapsed
         roof = gemm_roofline(n_local, elapsed)
-        roof["path_frac_of_mfma_peak"] = round(value / world * A_MIN_TFLOP_PER_CYCLE / MFMA_PEAK_TFLOPS, 4)
+        # the deduplicated algorithmic minimum is an upper bound on useful work only when the engine executes at least that much;
+        # with shared prefixes it executes LESS than SURVEY's A_min on this recipe, so the path fraction uses the smaller figure
+        roof["path_frac_of_mfma_peak"] = round(value / world * min(A_MIN_TFLOP_PER_CYCLE, roof["executed_tflop_per_cycle"] or A_MIN_TFLOP_PER_CYCLE)
+                                               / MFMA_PEAK_TFLOPS, 4)
+        roof["profile_dropped_launches"] = lib.profile_dropped()
         att, ln, ft = side_kernels(leg.be, elapsed)
         steps_mean = leg.be.stats["steps"] / max(leg.be.stats["cycles"], 1)
         d_in = leg.cfg["text_config"]["ffn_dim"]
@@ -516,16 +648,26 @@ def main():
             "phase_s": {k: round(v, 3) for k, v in leg.be.stats.items() if k.startswith("t_")},
             "build_s": round(leg.build_s, 1),
         }
-    cycles_for_cpu = leg.sample_cycles(max(1, args.cpu_cycles)) if want_cpu and rank == 0 else None
+        if head_style == "survey":
+            out["value_survey_recipe"] = out["value"]
+    # the cycles the CPU leg will run (and the batch around them for the parity capture): the head of this rank's own stream
+    cycles_for_cpu = leg.sample_cycles(E if want_parity else n_cmp) if want_cpu and rank == 0 else None
+    caps = {}
+    if want_parity and rank == 0:
+        caps["head_bf16"] = gpu_parity_capture(leg.editor, cycles_for_cpu, n_cmp, E, dev)
     host_arrays, cfg = leg.host_arrays, leg.cfg
+    last_layer = cfg["text_config"]["num_hidden_layers"] - 1
     leg.close()
+    if want_parity and rank == 0:
+        caps["head_fp32"] = fp32_parity_capture(cfg, host_arrays, cycles_for_cpu, n_cmp, max(n_cmp, 4), dev, last_layer)
     if rank == 0 and not args.no_hbm_micro and layers is None:
         out["roofline_hbm"].update(hbm_micro(dev))
     # ---- the dense-FFN leg beside the sparse headline ---------------------------------------------------------------------------
+    dense_arrays = None
     if args.ffn == "both":
         Kd = args.dense_steps or max(3, K // 3)
         torch.cuda.empty_cache()        # the 22 GB of per-edit AdamW state of this leg should not fight cached blocks of the legs before
-        dleg = Leg(args, rank, world, dev, "survey", layers, keep_host_copy=False)
+        dleg = Leg(args, rank, world, dev, "survey", layers, keep_host_copy=want_parity)
         d_elapsed, d_local, d_total, _ = timed_leg(dleg, Kd, 2, barrier, use_dist, rank, world, dev)
         if rank == 0:
             _, _, dft = side_kernels(dleg.be, d_elapsed)
@@ -534,18 +676,59 @@ def main():
                                 "mean_ft_steps": round(dleg.be.stats["steps"] / max(dleg.be.stats["cycles"], 1), 2),
                                 "ft_active_columns_mean": dft["npad_mean"], "ft_adamw_step": dft,
                                 "phase_s": {k: round(v, 3) for k, v in dleg.be.stats.items() if k.startswith("t_")}}
+            out["value_survey_recipe"] = out["dense_ffn"]["value"]      # SURVEY 8(d)'s weight recipe verbatim: the contract figure
+            if want_parity:
+                caps["dense_bf16"] = gpu_parity_capture(dleg.editor, cycles_for_cpu, n_cmp, E, dev)
+        dense_arrays = dleg.host_arrays
         dleg.close()
+    # ---- BASELINE configs #3-#5 on this GPU (bounded; one rank only) ------------------------------------------------------------
+    if rank == 0 and world == 1 and not args.no_configs and layers is None:
+        out["configs"] = run_config_legs(args)
     if rank == 0:
         if want_cpu and cycles_for_cpu is not None:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(cfg, args.seed, threads, host_arrays, cycles_for_cpu, max(1, args.cpu_cycles), head_style)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.seed, threads, host_arrays, cycles_for_cpu, n_cmp, head_style, trace=want_parity)
+            if want_parity:
+                out["parity"] = parity_block(cpu_baseline.last_traces, caps.get("head_bf16"), caps.get("head_fp32"))
+                out["parity"]["recipe"] = "dense (survey)" if head_style == "survey" else "sparse (opt)"
+                host_arrays = None
+                if dense_arrays is not None and "dense_bf16" in caps:
+                    dcpu = cpu_baseline(cfg, args.seed, threads, dense_arrays, cycles_for_cpu, n_cmp, "survey", trace=True)
+                    out["dense_ffn"]["parity"] = parity_block(cpu_baseline.last_traces, caps["dense_bf16"], None)
+                    out["dense_ffn"]["parity"]["cpu_seconds_per_cycle"] = dcpu["seconds_per_cycle"]
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_config_legs(args):
+    """BASELINE.json configs #3, #4, #5 at full model dims on this GPU, a bounded number of cycles each (tools/bench_configs.py):
+    cycles/s, the GEMM family's roofline fraction from the slot profiler, the algorithmic TFLOP/cycle used.  A leg that fails
+    reports its error instead of ending the run."""
+    import gc
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as bc
+    n = [int(x) for x in args.config_cycles.split(",")]
+    legs = [("llava_ft_vl", lambda: bc.llava_ft(n[0], 16)), ("blip2_mend_vl", lambda: bc.blip2_mend(n[1])),
+            ("minigpt4_ike_vl", lambda: bc.minigpt4_ike(n[2]))]
+    out = {}
+    cwd = os.getcwd()
+    import contextlib
+    for name, fn in legs:
+        try:
+            with contextlib.redirect_stdout(sys.stderr):     # the evaluator's progress prints: stdout carries the JSON line only
+                out[name] = fn()
+        except Exception as e:      # reported, never silent
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        os.chdir(cwd)
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

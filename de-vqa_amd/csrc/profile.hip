@@ -13,12 +13,14 @@ std::vector<hipEvent_t> g_ev;     // pairs: start, stop
 std::vector<int> g_slot;
 std::vector<double> g_work;
 size_t g_used = 0;
+int64_t g_dropped = 0;        // launches that found the event pool full since devqa_profile(1): reported, never silent
 }  // namespace
 
 int devqa_prof_begin(int slot, hipStream_t st) {
     if (!g_on) return -1;           // unsynchronised fast path: a launch racing with devqa_profile(1) is simply not recorded
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_on || g_used >= PROF_MAX_PAIRS || slot < 0 || slot >= DEVQA_PROF_SLOTS) return -1;
+    if (!g_on || slot < 0 || slot >= DEVQA_PROF_SLOTS) return -1;
+    if (g_used >= PROF_MAX_PAIRS) { ++g_dropped; return -1; }
     const int idx = (int)g_used++;
     g_slot[idx] = slot;
     g_work[idx] = -1.0;             // closed by devqa_prof_end
@@ -44,6 +46,7 @@ extern "C" int devqa_profile(int enable) {
             g_work.resize(PROF_MAX_PAIRS);
         }
         g_used = 0;
+        g_dropped = 0;
     }
     g_on = enable != 0;
     return DEVQA_OK;
@@ -60,6 +63,13 @@ extern "C" int devqa_profile_read(int slot, double* ms, double* work, int64_t* l
         if (hipEventElapsedTime(&t, g_ev[2 * i], g_ev[2 * i + 1]) != hipSuccess) return devqa_fail(DEVQA_E_HIP, "profile: elapsed");
         *ms += t; *work += g_work[i]; *launches += 1;
     }
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_profile_dropped(int64_t* dropped) {
+    DEVQA_CHECK_ARG(dropped, "profile_dropped: bad argument");
+    std::lock_guard<std::mutex> lock(g_mu);
+    *dropped = g_dropped;
     return DEVQA_OK;
 }
 

@@ -121,6 +121,15 @@ class BaseVLLMForEdit(ABC):
         return loss / msk.sum() if average else loss
 
     # ---- image-feature cache (native path only) --------------------------------------------------------------
+    @staticmethod
+    def image_key(img):
+        """Hashable identity of an image object, or None (PIL images / arrays: no identity, never cached or shared)."""
+        if isinstance(img, str):
+            return img
+        if isinstance(img, torch.Tensor):
+            return ("px", img.data_ptr(), img._version, tuple(img.shape))
+        return None
+
     def image_features(self, imgs):
         """[len(imgs), n_img, d] fp32 features of images given as paths / PIL / arrays.  An image addressed by PATH is
         encoded once and kept (160-entry LRU) for as long as no parameter outside the language model changes: the
@@ -137,8 +146,12 @@ class BaseVLLMForEdit(ABC):
         stamp = tuple(p._version for p in watched)
         if self.__dict__.get("_img_feat_stamp") != stamp:
             cache.clear()
+            self.__dict__.get("_img_feat_pins", {}).clear()
             self._img_feat_stamp = stamp
-        keys = [i if isinstance(i, str) else None for i in imgs]
+        # identity of an image: its path, or -- for pre-processed pixel values already resident in HBM ([3,S,S] tensors, the form
+        # synthetic benchmark data arrives in) -- the tensor's storage + version; such an entry keeps the tensor referenced, so
+        # its address cannot be handed to another image while the entry lives
+        keys = [self.image_key(i) for i in imgs]
         need = [j for j, k in enumerate(keys) if k is None or k not in cache]
         feats = {}
         if need:
@@ -146,13 +159,19 @@ class BaseVLLMForEdit(ABC):
             for j in need:   # encode each distinct missing path once
                 if keys[j] is None or keys[j] not in [keys[u] for u in uniq]:
                     uniq.append(j)
-            pix = torch.from_numpy(np.stack([self.load_pixels(imgs[j]) for j in uniq])).to(self.device)
+            if all(isinstance(imgs[j], torch.Tensor) for j in uniq):
+                pix = torch.stack([imgs[j].to(self.device, torch.float32) for j in uniq])
+            else:
+                pix = torch.from_numpy(np.stack([self.load_pixels(imgs[j]) for j in uniq])).to(self.device)
             enc = self.engine.encode_images(pix)
             for r, j in enumerate(uniq):
                 if keys[j] is not None:
                     cache[keys[j]] = enc[r]
+                    if isinstance(imgs[j], torch.Tensor):
+                        self.__dict__.setdefault("_img_feat_pins", {})[keys[j]] = imgs[j]
                     while len(cache) > 160:
-                        cache.popitem(last=False)
+                        old, _ = cache.popitem(last=False)
+                        self.__dict__.get("_img_feat_pins", {}).pop(old, None)
                 else:
                     feats[j] = enc[r]
         out = []

@@ -93,7 +93,7 @@ class BLIP2OPTForEdit(BaseVLLMForEdit):
         llm_inpt = {"attention_mask": msk, "inputs_embeds": emb}
         if B == 1:   # hashable identity of every input row (image rows: (path, j); text rows: token id) -- lets the evaluator's
             # batched probe path compute a prefix that several probes share only once (same mathematics: attention is causal)
-            ik = imgs if isinstance(imgs, str) else None
+            ik = self.image_key(imgs)
             if imgs is None or ik is not None:
                 llm_inpt["row_keys"] = ([("img", ik, j) for j in range(self.get_img_token_n())] if imgs is not None else []) + \
                     tk["input_ids"][0].tolist()

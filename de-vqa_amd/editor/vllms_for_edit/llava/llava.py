@@ -95,8 +95,8 @@ class LlavaForEdit(BaseVLLMForEdit):
             ids_l = tk["input_ids"][0].tolist()
             if imgs is None:
                 out["row_keys"] = ids_l
-            elif isinstance(imgs[0], str):
-                out["row_keys"] = ids_l[:pos] + [("img", imgs[0], j) for j in range(self.get_img_token_n())] + ids_l[pos + 1:]
+            elif self.image_key(imgs[0]) is not None:
+                out["row_keys"] = ids_l[:pos] + [("img", self.image_key(imgs[0]), j) for j in range(self.get_img_token_n())] + ids_l[pos + 1:]
         return out, vt_range
 
     def get_llm_outpt(self, llm_inpt, vt_range=None):

@@ -83,9 +83,9 @@ class MiniGPT4ForEdit(BaseVLLMForEdit):
                 emb[b, :r.shape[0]] = r
                 msk[b, :r.shape[0]] = 1
             llm_inpt = {"inputs_embeds": emb, "attention_mask": msk}
-            if len(texts) == 1 and isinstance(imgs[0], str):   # row identities (see BLIP2OPTForEdit.get_llm_input_embeds)
+            if len(texts) == 1 and self.image_key(imgs[0]) is not None:   # row identities (see BLIP2OPTForEdit.get_llm_input_embeds)
                 s0, s1 = self._segments(texts[0])
-                llm_inpt["row_keys"] = list(s0) + [("img", imgs[0], j) for j in range(feats.shape[1])] + list(s1)
+                llm_inpt["row_keys"] = list(s0) + [("img", self.image_key(imgs[0]), j) for j in range(feats.shape[1])] + list(s1)
         else:
             tk = self.tokenizer(texts, return_tensors="pt", padding=True)
             B, T = tk["input_ids"].shape

@@ -102,9 +102,13 @@ class VLLMEditorEvaluation:
         items = []
         share = os.environ.get("DEVQA_PROBE_PREFIX_SHARE", "1") != "0"
         if hasattr(vllm, "image_features"):   # one batched encoder call for the phase's distinct images (fills the cache)
-            uniq = list(dict.fromkeys(img for _, img, _ in probes if isinstance(img, str)))
+            uniq = {}
+            for _, img, _ in probes:
+                k = vllm.image_key(img) if hasattr(vllm, "image_key") else (img if isinstance(img, str) else None)
+                if k is not None:
+                    uniq.setdefault(k, img)
             if uniq:
-                vllm.image_features(uniq)
+                vllm.image_features(list(uniq.values()))
         for i, (prompt, image, target) in enumerate(probes):
             (x, vt), y, m = vllm.prompts_imgs_target_to_xym([prompt], [image], [target])
             assert len(y) == 1 and len(m) == 1

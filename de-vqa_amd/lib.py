@@ -53,6 +53,7 @@ def load():
     _sig(L.devqa_profile_gemm_read, [P, P, P])
     _sig(L.devqa_profile, [I])
     _sig(L.devqa_profile_read, [I, P, P, P])
+    _sig(L.devqa_profile_dropped, [P])
     _sig(L.devqa_layernorm, [P, P, P, P, I, I, F, P, P, P])
     _sig(L.devqa_attention_f32, [P, I64, P, I64, P, I64, P, I64, P, I, I, I, I, F, I, P])
     _sig(L.devqa_im2col_patches_f32, [P, I, I, I, I, P, P])
@@ -134,7 +135,7 @@ EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "dev
            "devqa_mend_transform", "devqa_mend_apply_workspace", "devqa_mend_apply", "devqa_llm_head_workspace", "devqa_llm_head", "devqa_llm_forward_workspace",
            "devqa_llm_forward", "devqa_ft_edit_workspace", "devqa_ft_edit", "devqa_ctx_bind_edit_target", "devqa_apply_delta", "devqa_restore",
            "devqa_token_acc", "devqa_comm_unique_id", "devqa_comm_create", "devqa_comm_destroy", "devqa_gather_scores",
-           "devqa_profile", "devqa_profile_read", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
+           "devqa_profile", "devqa_profile_read", "devqa_profile_dropped", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
            "devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
@@ -208,6 +209,13 @@ def profile_read(slot):
     ms, wk, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     _chk(load().devqa_profile_read(int(slot), ctypes.byref(ms), ctypes.byref(wk), ctypes.byref(ln)), "devqa_profile_read")
     return ms.value, wk.value, ln.value
+
+
+def profile_dropped():
+    """launches the slot profiler could not record since profile(1) (event pool full); 0 in a trustworthy measurement"""
+    n = ctypes.c_int64()
+    _chk(load().devqa_profile_dropped(ctypes.byref(n)), "devqa_profile_dropped")
+    return n.value
 
 
 def _chk(rc, name):

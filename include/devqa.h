@@ -89,6 +89,8 @@ int devqa_gemm_set_mode(int mode);
 #define DEVQA_PROF_SLOT_LAYERNORM 7
 int devqa_profile(int enable);
 int devqa_profile_read(int slot, double* ms, double* work, int64_t* launches);
+/* launches that were NOT recorded since devqa_profile(1) because the event pool was full: a reader reports it beside the figures */
+int devqa_profile_dropped(int64_t* dropped);
 int devqa_profile_gemm(int enable);
 int devqa_profile_gemm_read(double* ms, double* flops, int64_t* launches);
 

@@ -213,3 +213,24 @@ def test_shared_prefix_plan_keys_by_stored_edit_not_by_view_object():
             n = hits.count(h)
             assert grouped.get(h, 0) == (n if n >= 2 else 0), (hits, groups)  # every repeat retrieval DOES share
         assert sorted(alone + [m for g, _ in groups for m in g]) == list(range(12))
+
+
+def test_every_editor_model_pair_has_a_config():
+    """load_vllm_editor resolves configs/<editor>/<model>.yaml (R/utils/__init__.py:101-103) for every editor branch it has and
+    every model name get_full_model_name maps to: each pair must exist and parse into the editor's config dataclass, so that
+    `test_vllm_edit.py -en <editor> -mn <model>` never dies on FileNotFoundError (BASELINE config #5 = ike_vl + minigpt4)."""
+    import devqa_amd  # noqa: F401
+    from devqa_amd.utils import get_editor_config_path
+    from devqa_amd.editor.vllm_editors.ft_vl.ft_vl import FTvlConfig
+    from devqa_amd.editor.vllm_editors.ike_vl.ike_vl import IKEvlConfig
+    from devqa_amd.editor.vllm_editors.mend_vl.mend_vl import MENDvlConfig
+    from devqa_amd.editor.vllm_editors.tp_vl.tp_vl import TPvlConfig
+    from devqa_amd.editor.vllm_editors.lte_vl.lte_vl import LTEvlConfig
+    classes = {"ft_vl": FTvlConfig, "ike_vl": IKEvlConfig, "mend_vl": MENDvlConfig, "tp_vl": TPvlConfig, "lte_vl": LTEvlConfig}
+    full = {"blip2": "blip2-opt-2.7b", "llava": "llava-v1.5-7b", "minigpt4": "minigpt-4-vicuna-7b"}
+    for editor, cls in classes.items():
+        for short, name in full.items():
+            path = get_editor_config_path(editor, short)
+            assert os.path.isfile(path), path
+            cfg = cls.from_yaml(path)
+            assert cfg.edit_model_name == name, (path, cfg.edit_model_name)

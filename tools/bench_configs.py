@@ -78,6 +78,69 @@ def distinct_records(n, image_size, seed=11):
     return base
 
 
+MFMA_PEAK_TFLOPS = 2500.0
+
+
+def a_min_tflop(family, text_tokens=16):
+    """SURVEY.md 8(d)'s deduplicated algorithmic work of ONE edit+eval cycle for the other model families (same rule as the
+    BLIP-2 A_min = 3.81): 4 unique image encodes, the decoder over 4 image prefixes + 12 probe texts, 25 FT steps and 21 probe
+    tails on the label rows.  FLOPs = 2 per MAC."""
+    if family == "llava":       # CLIP-L/336 366 GFLOP/image + projector 24; Vicuna-7B: 32 x 2 x (4 d^2 + 3 d f) per token position
+        d, f, layers, img_tok, vocab = 4096, 11008, 32, 576, 32064
+        vision = 4 * (366.0 + 24.0) * 1e9
+    elif family == "minigpt4":  # EVA ViT-g 520.7 + Q-Former 12.7 + llama_proj 0.2 GFLOP per image; 32 query tokens
+        d, f, layers, img_tok, vocab = 4096, 11008, 32, 32, 32000
+        vision = 4 * (520.7 + 12.7 + 0.2) * 1e9
+    elif family == "blip2":
+        return 3.81
+    else:
+        raise ValueError(family)
+    pos = 4 * img_tok + 12 * text_tokens
+    per_tok = layers * 2.0 * (4 * d * d + 3 * d * f)
+    attn = layers * 4.0 * d * (4 * img_tok * img_tok / 2 + 12 * text_tokens * (img_tok + text_tokens / 2))
+    tails = (25 * 2 + 21) * 3 * 2.0 * (d * f + d * vocab)
+    return (vision + pos * per_tok + attn + tails) / 1e12
+
+
+def measured(fn):
+    """Run fn() with the library's slot profiler on (HIP events around every instrumented launch) -> (fn's result, wall seconds,
+    {gemm_ms, gemm_tflop, gemm_launches, attention_ms, ft_ms, ln_ms, dropped})."""
+    from devqa_amd import lib
+    torch.cuda.synchronize()
+    lib.profile(1)
+    t0 = time.time()
+    out = fn()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    lib.profile(0)
+    prof = [lib.profile_read(i) for i in range(4)]
+    g_ms, g_fl, g_n = (sum(p_[j] for p_ in prof) for j in range(3))
+    return out, dt, {"gemm_ms": g_ms, "gemm_tflop": g_fl / 1e12, "gemm_launches": int(g_n),
+                     "attention_ms": lib.profile_read(lib.PROF_ATTENTION)[0], "ft_ms": lib.profile_read(lib.PROF_FT_ADAMW)[0],
+                     "ln_ms": lib.profile_read(lib.PROF_LAYERNORM)[0], "cosine_ms": lib.profile_read(lib.PROF_COSINE)[0],
+                     "dropped": lib.profile_dropped()}
+
+
+def config_line(name, n_cycles, dt, prof, a_min, extra=None):
+    """One entry of bench.py's `configs` object.  `roofline`: the dominant kernel family of every config is the bf16 GEMM
+    (gemm_bf16_pp_kernel and its smaller-tile siblings); achieved = executed 2MNK FLOPs / summed HIP-event time of the launches,
+    scaled down by A_min / executed when more than the deduplicated algorithmic work is executed."""
+    exec_pc = prof["gemm_tflop"] / max(n_cycles, 1)
+    scale = min(1.0, a_min / exec_pc) if exec_pc > 0 else 0.0
+    ach = prof["gemm_tflop"] * scale / (prof["gemm_ms"] / 1e3) if prof["gemm_ms"] > 0 else 0.0
+    inst_ms = prof["gemm_ms"] + prof["attention_ms"] + prof["ft_ms"] + prof["ln_ms"] + prof["cosine_ms"]
+    out = {"workload": name, "cycles": n_cycles, "cycles_per_s": round(n_cycles / dt, 3), "ms_per_cycle": round(1e3 * dt / n_cycles, 2),
+           "a_min_tflop_per_cycle": round(a_min, 2), "executed_gemm_tflop_per_cycle": round(exec_pc, 2),
+           "path_frac_of_mfma_peak": round(min(a_min, exec_pc if exec_pc > 0 else a_min) * n_cycles / dt / MFMA_PEAK_TFLOPS, 4),
+           "roofline": {"bound": "mfma", "kernel": "gemm_bf16 family (pp 256x256 / glds / tn)", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "launches": prof["gemm_launches"],
+                        "gemm_time_frac": round(prof["gemm_ms"] / 1e3 / dt, 3)},
+           "instrumented_kernel_time_frac": round(inst_ms / 1e3 / dt, 3), "profile_dropped": prof["dropped"]}
+    if extra:
+        out.update(extra)
+    return out
+
+
 def run_eval(editor, n, batched, out_dir="/tmp/devqa_bench_cfg", distinct_image_size=None):
     from devqa_amd.dataset.vllm import BaseVLLMEditData
     from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation
@@ -93,20 +156,21 @@ def run_eval(editor, n, batched, out_dir="/tmp/devqa_bench_cfg", distinct_image_
     a, b = mk(), mk()
     torch.cuda.synchronize()
     ev = VLLMEditorEvaluation(editor, D(a, b), "EVQA", out_dir)
-    t0 = time.time()
-    res = ev.evaluate_sequential_edit(1, False, None, batched=batched, save=False)
-    torch.cuda.synchronize()
-    dt = time.time() - t0
+    res, dt, prof = measured(lambda: ev.evaluate_sequential_edit(1, False, None, batched=batched, save=False))
+    run_eval.last_profile = prof
     return len(res) / dt, dt, res
 
 
-def llava_ft(n=8):
+def llava_ft(n=8, per_batch=None):
+    """config #3: LLaVA-1.5-7B + FT_VL on the batched engine, n DISTINCT cycles -> one `configs` entry (config_line)"""
     from transformers import AutoTokenizer
     from devqa_amd.llava_spec import LLAVA_1_5_7B
     from devqa_amd.editor.vllms_for_edit.llava.modeling import LlavaNative
     from devqa_amd.editor.vllms_for_edit.llava.llava import LlavaForEdit
     from devqa_amd.editor.vllm_editors.ft_vl.ft_vl import FTvl, FTvlConfig
     t0 = time.time()
+    if per_batch:
+        os.environ["DEVQA_CYCLES_PER_BATCH"] = str(per_batch)
     cfg7b = dict(LLAVA_1_5_7B, image_token_index=4)   # the stand-in tokenizer (tiny fixture) maps '<image>' to id 4
     model = LlavaNative(cfg7b, DEV, "bf16")
     fill(model, 3, "llava")
@@ -114,21 +178,20 @@ def llava_ft(n=8):
     vllm = LlavaForEdit(None, DEV, True, model=model, tokenizer=tok)
     cfg = FTvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "ft_vl", "llava-v1.5-7b.yaml"))
     ed = FTvl(vllm, cfg, DEV)
-    print("build %.1fs" % (time.time() - t0), flush=True)
-    cps, dt, res = run_eval(ed, n, True, distinct_image_size=336 if n > 8 else None)
-    r0 = res[0][0]
-    print(json.dumps({"config": "LLaVA-1.5-7B + FT_VL (batched engine, %d %scycles, DEVQA_CYCLES_PER_BATCH=%s)" % (
-                          n, "distinct " if n > 8 else "", os.environ.get("DEVQA_CYCLES_PER_BATCH", "default")), "cycles_per_s": round(cps, 2),
-                      "s_per_step": round(dt, 3), "reliability_acc_first": r0["reliability"][0]["acc"]}))
+    build_s = time.time() - t0
+    cps, dt, res = run_eval(ed, n, True, distinct_image_size=336)
+    os.environ.pop("DEVQA_CYCLES_PER_BATCH", None)
+    return config_line("BASELINE config #3: LLaVA-1.5-7B (CLIP-L/336 + Vicuna-7B dims) + FT_VL on layers.31.mlp.down_proj, batched engine, %d distinct "
+                       "synthetic EVQA-shaped cycles in batches of %s, bf16" % (n, per_batch or 16), n, dt, run_eval.last_profile,
+                       a_min_tflop("llava"), {"build_s": round(build_s, 1), "reliability_acc_first": res[0][0]["reliability"][0]["acc"]})
 
 
-def blip2_mend(n=4):
+def _mend_editor():
     from transformers import AutoTokenizer
     from devqa_amd import blip2_spec
     from devqa_amd.editor.vllms_for_edit.blip2.modeling import Blip2Native
     from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
     from devqa_amd.editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
-    t0 = time.time()
     model = Blip2Native(blip2_spec.BLIP2_OPT_2_7B, DEV, "bf16")
     fill(model, 20251121, "opt")
     tok = AutoTokenizer.from_pretrained(os.path.join(GOLD, "tiny_blip2"))
@@ -146,11 +209,21 @@ def blip2_mend(n=4):
     with ThreadPoolExecutor(8) as ex:
         aux = dict(zip(shapes, ex.map(lambda kv: torch.from_numpy(mend_aux_init("aux_models." + kv[0], kv[1], 11)), shapes.items())))
     tm = {"aux_models": aux, "edit_lrs": {str(i): torch.tensor(1e-4) for i in range(6)}}
-    ed = MENDvl(vllm, cfg, DEV, train_modules=tm)
-    print("build %.1fs" % (time.time() - t0), flush=True)
-    cps, dt, res = run_eval(ed, n, None)
-    print(json.dumps({"config": "BLIP-2-OPT-2.7B + MEND_VL (generic per-sample evaluator)", "cycles_per_s": round(cps, 3),
-                      "s_per_cycle": round(dt / n, 3), "edit_time_s": res[0][0]["reliability"][0].get("edit_time")}))
+    return MENDvl(vllm, cfg, DEV, train_modules=tm)
+
+
+def blip2_mend(n=4, batched=None):
+    """config #4 on one GPU: BLIP-2-OPT-2.7B + MEND_VL (layers 29-31 fc1/fc2, hyper-network 12800 -> rank 1920), n distinct cycles"""
+    t0 = time.time()
+    ed = _mend_editor()
+    build_s = time.time() - t0
+    cps, dt, res = run_eval(ed, n, batched, distinct_image_size=224)
+    # per cycle beyond the BLIP-2 A_min: backward through the 3 edited layers on the edit sequence (~2x their forward) and the
+    # hyper-network (2 transforms x 2 LRLinear x 2 GEMMs of [T x 12800] . [12800 x 1920]) -- < 0.1 TFLOP, within the figure's rounding
+    return config_line("BASELINE config #4 (one GPU's shard): BLIP-2-OPT-2.7B + MEND_VL (decoder layers 29-31 fc1/fc2, hyper-network 12800 -> 1920), "
+                       "%d distinct synthetic EVQA-shaped cycles, bf16" % n, n, dt, run_eval.last_profile, a_min_tflop("blip2"),
+                       {"build_s": round(build_s, 1), "edit_time_s": res[0][0]["reliability"][0].get("edit_time"),
+                        "evaluator": getattr(run_eval, "last_mode", "generic")})
 
 
 def blip2_mend_train(n=6):
@@ -207,6 +280,7 @@ def _hash_encode(sentences, dim=384):
 
 
 def minigpt4_ike(n=4):
+    """config #5 on one GPU: MiniGPT-4 (EVA ViT-g + Q-Former + Vicuna-7B dims) + IKE_VL, k = 32 over a 15000 x 384 corpus"""
     from transformers import AutoTokenizer
     from devqa_amd.minigpt4_spec import MINIGPT4_VICUNA_7B
     from devqa_amd.editor.vllms_for_edit.minigpt4.modeling import MiniGPT4Native
@@ -220,12 +294,20 @@ def minigpt4_ike(n=4):
     N = 15000
     sents = ["New Fact: fact %d is %d\nPrompt: fact %d is %d\n\n" % (i, i * 7 % 13, i, i * 7 % 13) for i in range(N)]
     corpus = {"sentences": sents, "embeddings": np.random.default_rng(1).standard_normal((N, 384), dtype=np.float32)}
-    ed = IKEvl(vllm, IKEvlConfig("minigpt-4-vicuna-7b", k=32), DEV, corpus, _hash_encode)
-    print("build %.1fs" % (time.time() - t0), flush=True)
-    cps, dt, res = run_eval(ed, n, None)
-    print(json.dumps({"config": "MiniGPT-4 (Vicuna-7B) + IKE_VL k=32 over 15000x384 (generic per-sample evaluator)",
-                      "cycles_per_s": round(cps, 3), "s_per_cycle": round(dt / n, 3)}))
+    cfg = IKEvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "ike_vl", "minigpt-4-vicuna-7b.yaml"))
+    ed = IKEvl(vllm, cfg, DEV, corpus, _hash_encode)
+    build_s = time.time() - t0
+    cps, dt, res = run_eval(ed, n, None, distinct_image_size=224)
+    # the in-context prefix (k = 32 retrieved demonstrations + the new fact) is part of every probe's input: the decoder term of
+    # A_min counts it once per cycle (shared by the 21 probes) on top of the image prefixes and probe texts
+    demo_rows = len(tok("".join(ed.retrieve("fact 1 is", "7")))["input_ids"])
+    a_min = a_min_tflop("minigpt4") + (32 * 2.0 * (4 * 4096 ** 2 + 3 * 4096 * 11008)) * demo_rows / 1e12
+    return config_line("BASELINE config #5 (one GPU's shard): MiniGPT-4 (Vicuna-7B dims) + IKE_VL, cosine top-k k=%d over a 15000 x 384 corpus, "
+                       "%d distinct synthetic cycles, bf16, generic evaluator with shared-prefix probe packing" % (cfg.k, n), n, dt,
+                       run_eval.last_profile, a_min, {"build_s": round(build_s, 1), "icl_prefix_rows": demo_rows})
 
 
 if __name__ == "__main__":
-    {"llava_ft": llava_ft, "blip2_mend": blip2_mend, "minigpt4_ike": minigpt4_ike, "blip2_mend_train": blip2_mend_train}[sys.argv[1]](*[int(a) for a in sys.argv[2:]])
+    r = {"llava_ft": llava_ft, "blip2_mend": blip2_mend, "minigpt4_ike": minigpt4_ike, "blip2_mend_train": blip2_mend_train}[sys.argv[1]](*[int(a) for a in sys.argv[2:]])
+    if r is not None:
+        print(json.dumps(r))
