@@ -701,7 +701,10 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if use_dist:
+        from devqa_amd.dist import close_score_comms
         dist.barrier()
+        torch.cuda.synchronize()
+        close_score_comms()             # the library's own RCCL communicator goes before torch's process group
         dist.destroy_process_group()
 
 

@@ -44,6 +44,8 @@ struct Ctx {
 std::mutex g_ctx_mu;
 std::set<Ctx*> g_ctx_live;
 
+// Validates the handle against the live set.  The pointer is used after the lock is dropped: destroying a context while another
+// thread is inside a call on it is outside the contract (include/devqa.h: calls on a context are serialised by the caller).
 Ctx* ctx_of(devqa_ctx_t h) {
     Ctx* c = reinterpret_cast<Ctx*>(static_cast<uintptr_t>(h));
     std::lock_guard<std::mutex> lock(g_ctx_mu);
@@ -714,6 +716,14 @@ int rccl_load() {
     return DEVQA_OK;
 }
 struct Comm { void* nccl; int rank, world; };
+// live handles: a stale / foreign handle (or a call before librccl was ever loaded) is an error, not a dereference
+std::mutex g_comm_mu;
+std::set<Comm*> g_comm_live;
+Comm* comm_of(devqa_comm_t h) {
+    Comm* cm = reinterpret_cast<Comm*>(static_cast<uintptr_t>(h));
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    return (g_rccl.lib && g_comm_live.count(cm)) ? cm : nullptr;
+}
 int rccl_fail(const char* what, int rc) {
     return devqa_fail(DEVQA_E_HIP, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "rccl error");
 }
@@ -739,21 +749,30 @@ extern "C" int devqa_comm_create(int rank, int world, const void* id128, int dev
     if (!cm) return devqa_fail(DEVQA_E_OOM, "comm_create: host allocation failed");
     const int rc = g_rccl.CommInitRank(&cm->nccl, world, u, rank);
     if (rc != 0) { delete cm; return rccl_fail("ncclCommInitRank", rc); }
+    {
+        std::lock_guard<std::mutex> lock(g_comm_mu);
+        g_comm_live.insert(cm);
+    }
     *out = (devqa_comm_t)(uintptr_t)cm;
     return DEVQA_OK;
 }
 
 extern "C" int devqa_comm_destroy(devqa_comm_t h) {
-    Comm* cm = reinterpret_cast<Comm*>(static_cast<uintptr_t>(h));
-    DEVQA_CHECK_ARG(cm, "comm_destroy: null handle");
+    Comm* cm = comm_of(h);
+    if (!cm) return devqa_fail(DEVQA_E_STATE, "comm_destroy: invalid or destroyed communicator handle");
+    {
+        std::lock_guard<std::mutex> lock(g_comm_mu);
+        g_comm_live.erase(cm);
+    }
     const int rc = g_rccl.CommDestroy(cm->nccl);
     delete cm;
     return rc == 0 ? DEVQA_OK : rccl_fail("ncclCommDestroy", rc);
 }
 
 extern "C" int devqa_gather_scores(devqa_comm_t h, const float* local, int n_rows, float* out, void* stream) {
-    Comm* cm = reinterpret_cast<Comm*>(static_cast<uintptr_t>(h));
-    DEVQA_CHECK_ARG(cm && local && out && n_rows > 0, "gather_scores: bad argument");
+    Comm* cm = comm_of(h);
+    if (!cm) return devqa_fail(DEVQA_E_STATE, "gather_scores: invalid or destroyed communicator handle");
+    DEVQA_CHECK_ARG(local && out && n_rows > 0, "gather_scores: bad argument");
     const int rc = g_rccl.AllGather(local, out, (size_t)n_rows * DEVQA_SCORE_COLS, /*ncclFloat32*/ 7, cm->nccl, (hipStream_t)stream);
     return rc == 0 ? DEVQA_OK : rccl_fail("ncclAllGather", rc);
 }

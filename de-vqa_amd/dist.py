@@ -42,7 +42,9 @@ def gather_score_rows(local_rows: np.ndarray, n_total: int, rank: int, world: in
     if len(local_rows):
         buf[:len(local_rows)] = torch.from_numpy(local_rows).to(device)
     if torch.device(device).type == "cuda" and os.environ.get("DEVQA_GATHER_ABI", "1") != "0":
-        # the path-level entry point (include/devqa.h, devqa_gather_scores): ONE RCCL all-gather on the library's own communicator
+        # the path-level entry point (include/devqa.h, devqa_gather_scores): ONE RCCL all-gather on the library's own communicator.
+        # N > 1 on hardware is UNPINNED until a multi-GPU run is recorded (SCALE_r01/r02 were skipped by the driver): this leg has run
+        # with one rank on the GPU box and with two ranks on gloo only; DEVQA_GATHER_ABI=0 takes torch.distributed's all_gather
         allrows = _score_comm(rank, world, torch.device(device)).gather_scores(buf.contiguous())
         outs = list(allrows.view(world, mx, -1).unbind(0))
     else:
@@ -66,6 +68,17 @@ def _score_comm(rank, world, device):
             dist.broadcast_object_list(uid, src=0)
         _SCORE_COMM[key] = lib.ScoreComm(rank, world, uid[0], device.index or 0)
     return _SCORE_COMM[key]
+
+
+def close_score_comms():
+    """Destroy the library's RCCL communicators of this process (call before dist.destroy_process_group())."""
+    for key in list(_SCORE_COMM):
+        c = _SCORE_COMM.pop(key)
+        try:
+            c.close()
+        except Exception as e:      # a failed teardown must not mask the run's result
+            import warnings
+            warnings.warn("ScoreComm close failed: %s" % e)
 
 
 def gather_results(local_results, local_rows, n_total, rank, world, device):

@@ -257,6 +257,85 @@ class VLLMBaseEditorWithTraining(VLLMBaseEditor):
         return ckpt["i"], ckpt["epoch"], ckpt["loss"], ckpt["ema_loss"]
 
 
+class HipAdamState(dict):
+    """Adam moments of an editor's trainable tensors as plain device buffers -- {"t": step, "m": {key: tensor}, "v": {key: tensor}}
+    -- with the optimizer interface the checkpoint code needs (`state_dict` / `load_state_dict`), readable and writable in the
+    layout of `torch.optim.Adam.state_dict()`, which is what the `opt` entry of a reference `Best` checkpoint holds
+    (R/editor/vllm_editors/base.py:237-255: `self.opt.state_dict()`).
+
+    `torch_order`: [(key, element index or None)] -- the optimizer's parameters in torch's numbering (param_groups in order, the
+    parameters of a group in order); an entry with an element index i is one scalar parameter stored as element i of a vector
+    buffer (MEND_VL's `edit_lrs` ParameterList).  `group_sizes` / `group_lrs`: the param_groups.  Without `torch_order` only the
+    private layout is understood.  A foreign `opt` that cannot be mapped (other layout, other shapes) is NOT an error: the state
+    stays fresh (zero moments, step 0) and a warning says so -- training resumes from the checkpoint's modules."""
+
+    def __init__(self, *a, torch_order=None, group_sizes=None, group_lrs=None, **k):
+        super().__init__(*a, **k)
+        self.torch_order, self.group_sizes, self.group_lrs = torch_order, group_sizes, group_lrs
+
+    def state_dict(self):
+        if not self.torch_order:
+            return {"t": self["t"], "m": dict(self["m"]), "v": dict(self["v"])}
+        state = {}
+        if self["t"] > 0:
+            for i, (key, el) in enumerate(self.torch_order):
+                m, v = self["m"][key], self["v"][key]
+                if el is not None:
+                    m, v = m[el].clone(), v[el].clone()
+                state[i] = {"step": torch.tensor(float(self["t"])), "exp_avg": m, "exp_avg_sq": v}
+        groups, i0 = [], 0
+        for n, lr in zip(self.group_sizes, self.group_lrs):
+            groups.append({"lr": float(lr), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                           "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                           "decoupled_weight_decay": False, "params": list(range(i0, i0 + n))})
+            i0 += n
+        return {"state": state, "param_groups": groups}
+
+    def _fresh(self, why):
+        import warnings
+        warnings.warn("checkpoint 'opt' not loaded (%s): continuing with fresh Adam moments" % why)
+        self["t"] = 0
+        for mv in ("m", "v"):
+            for t in self[mv].values():
+                t.zero_()
+
+    def load_state_dict(self, sd):
+        if isinstance(sd, dict) and {"t", "m", "v"} <= set(sd):          # the private layout (round-2 checkpoints)
+            if set(sd["m"]) != set(self["m"]):
+                return self._fresh("moment keys differ")
+            self["t"] = int(sd["t"])
+            for mv in ("m", "v"):
+                for k, v in sd[mv].items():
+                    self[mv][k].copy_(v.to(self[mv][k].device))
+            return
+        if not (isinstance(sd, dict) and "state" in sd and "param_groups" in sd):
+            return self._fresh("unknown layout")
+        if not self.torch_order:
+            return self._fresh("no parameter order known for this editor")
+        n_params = sum(len(g["params"]) for g in sd["param_groups"])
+        if n_params != len(self.torch_order):
+            return self._fresh("%d parameters in the checkpoint, %d here" % (n_params, len(self.torch_order)))
+        state = sd["state"]
+        if len(state) == 0:                                              # saved before the first step
+            self["t"] = 0
+            return
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        steps = set()
+        for i, (key, el) in zip(ids, self.torch_order):
+            st = state.get(i)
+            dst = self["m"][key] if el is None else self["m"][key][el]
+            if st is None or tuple(st["exp_avg"].shape) != tuple(dst.shape):
+                return self._fresh("state of parameter %d does not fit %s" % (i, key))
+            steps.add(int(float(st["step"])))
+        if len(steps) != 1:
+            return self._fresh("parameters at different step counts")
+        for i, (key, el) in zip(ids, self.torch_order):
+            for mv, name in (("m", "exp_avg"), ("v", "exp_avg_sq")):
+                dst = self[mv][key] if el is None else self[mv][key][el]
+                dst.copy_(state[i][name].to(dst.device, dst.dtype))
+        self["t"] = steps.pop()
+
+
 def _cpu_state(sd):
     if isinstance(sd, torch.Tensor):
         return sd.detach().cpu()

@@ -37,7 +37,7 @@ import torch
 import yaml
 
 from ...base import BaseConfig
-from ..base import VLLMBaseEditor, VLLMBaseEditorWithTraining
+from ..base import HipAdamState, VLLMBaseEditor, VLLMBaseEditorWithTraining
 from .... import lib
 
 
@@ -66,19 +66,6 @@ class LTEvlConfig(BaseConfig):
     @classmethod
     def from_json(cls, fpath):
         raise
-
-
-class _AdamState(dict):
-    """{'t': step, 'm': {name: tensor}, 'v': {...}} with the two methods the training ABC's checkpoint code calls."""
-
-    def state_dict(self):
-        return {"t": self["t"], "m": dict(self["m"]), "v": dict(self["v"])}
-
-    def load_state_dict(self, sd):
-        self["t"] = int(sd["t"])
-        for k in ("m", "v"):
-            for n, t in sd[k].items():
-                self[k][n].copy_(t.to(self[k][n].device))
 
 
 class LTEvl(VLLMBaseEditorWithTraining):
@@ -225,7 +212,7 @@ class LTEvl(VLLMBaseEditorWithTraining):
 
     def get_a_new_optimizer(self):  # :195-198: Adam(lr), torch defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay)
         ps = self._train_params()
-        return _AdamState(t=0, m={n: torch.zeros_like(p_) for n, p_ in ps.items()}, v={n: torch.zeros_like(p_) for n, p_ in ps.items()})
+        return HipAdamState(t=0, m={n: torch.zeros_like(p_) for n, p_ in ps.items()}, v={n: torch.zeros_like(p_) for n, p_ in ps.items()})
 
     def other_train_init_final(self):  # :200-201
         self.restore_to_original_model()

@@ -32,7 +32,7 @@ import torch
 import yaml
 
 from ...base import BaseConfig
-from ..base import VLLMBaseEditorWithTraining
+from ..base import HipAdamState, VLLMBaseEditorWithTraining
 from .... import lib
 
 
@@ -96,23 +96,6 @@ class _EditLrState:
 
     def load_state_dict(self, sd, strict=True):
         self.ed._load_lrs(sd)
-
-
-class _AdamState(dict):
-    """Adam moments of the trainable tensors as plain device buffers ({"t", "m", "v"}) with the optimizer interface the
-    checkpoint code needs."""
-
-    def state_dict(self):
-        return {"t": self["t"], "m": dict(self["m"]), "v": dict(self["v"])}
-
-    def load_state_dict(self, sd):
-        if not (isinstance(sd, dict) and {"t", "m", "v"} <= set(sd)):
-            raise RuntimeError("checkpoint 'opt' is not a MEND_VL Adam state (a torch.optim state dict of the reference cannot be "
-                               "mapped onto the HIP buffers; load with load_opt=False)")
-        self["t"] = int(sd["t"])
-        for mv in ("m", "v"):
-            for k, v in sd[mv].items():
-                self[mv][k].copy_(v)
 
 
 class MENDvl(VLLMBaseEditorWithTraining):
@@ -384,7 +367,22 @@ class MENDvl(VLLMBaseEditorWithTraining):
 
     def get_a_new_optimizer(self):
         """torch.optim.Adam([{aux_models, lr = cfg.aux_model.lr}, {edit_lrs, lr = cfg.edit_lr_lr}]) (:293-296) as plain state."""
-        st = _AdamState(t=0, m={}, v={})
+        # torch's numbering of the reference's optimizer: group 0 = aux_models.parameters() -- per GradientTransform (ModuleDict
+        # order = first appearance of a weight shape in edit_modules, mend_vl.py:200-223), per LRLinear of its IDMLP: the module's own
+        # parameters in registration order (u, v, bias), then its sub-modules' (mode_shift.weight, mode_scale.weight;
+        # auxiliary_networks.py:31-55) -- group 1 = the edit_lrs ParameterList, one scalar per edited module (:153)
+        order = []
+        for shape in dict.fromkeys(m["shape"] for m in self.modules):
+            for l in range(self.n_layers):
+                for leaf in ("u", "v", "bias", "mode_shift.weight", "mode_scale.weight"):
+                    k = "%s.mlp.layers.%d.%s" % (str(shape), l, leaf)
+                    if k in self.aux:
+                        order.append((k, None))
+        n_aux = len(order)
+        order += [("edit_lrs", i) for i in range(len(self.modules))]
+        known = set(self._trainable())
+        st = HipAdamState(t=0, m={}, v={}, torch_order=order if {k for k, _ in order[:n_aux]} == known else None,
+                          group_sizes=[n_aux, len(self.modules)], group_lrs=[self.cfg.aux_model.lr, self.cfg.edit_lr_lr])
         for k in self._trainable():
             st["m"][k] = torch.zeros_like(self.aux[k])
             st["v"][k] = torch.zeros_like(self.aux[k])

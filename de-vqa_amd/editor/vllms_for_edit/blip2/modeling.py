@@ -131,7 +131,7 @@ class Blip2Native(nn.Module):
     def refresh_derived(self, force=False):
         pw = self.get("vision_model.embeddings.patch_embedding.weight")
         emb = self.get("language_model.model.decoder.embed_tokens.weight")
-        ver = (pw._version, emb._version)
+        ver = (pw._version, emb._version, pw.data_ptr(), emb.data_ptr())   # in-place writes AND out-of-place replacement
         if not force and ver == self._derived_version:
             return
         self.patch_w_gemm.zero_()
@@ -140,7 +140,7 @@ class Blip2Native(nn.Module):
             self.embed_T = emb.t().contiguous()
         else:
             self.embed_T.copy_(emb.t())      # in place: the path-level context (lib.PathContext) holds this buffer's address
-        self._derived_version = (pw._version, emb._version)
+        self._derived_version = (pw._version, emb._version, pw.data_ptr(), emb.data_ptr())
 
     @classmethod
     def from_pretrained_dir(cls, path, device="cuda", dtype="bf16"):
@@ -231,6 +231,27 @@ class Blip2Native(nn.Module):
         t["derived.patch_w_gemm"] = self.patch_w_gemm
         t["derived.embed_T"] = self.embed_T
         return t
+
+    def storage_fingerprint(self):
+        """Cheap identity of every buffer the path-level context (lib.PathContext) holds a raw pointer to: the device address of
+        each parameter's CURRENT storage (looked up through the module tree on every call, so a Parameter object replaced by
+        `promote_to_fp32`, a `p.data = ...` reassignment, a reload into new storage or a device move all show), the bf16 shadows of
+        the fp32 masters and the derived GEMM operands.  ~0.15 ms for ~1100 tensors; in-place writes keep addresses and need no
+        rebuild.  The engine rebuilds its context when this value changes (stale pointers meant silently wrong logits)."""
+        slots = self.__dict__.get("_fp_slots")
+        if slots is None:
+            slots = []
+            for name, _ in self.named_parameters():
+                node = self
+                parts = name.split(".")
+                for q in parts[:-1]:
+                    node = node._modules[q]
+                slots.append((node._parameters, parts[-1]))
+            self.__dict__["_fp_slots"] = slots
+        extra = [ent[1].data_ptr() for ent in self._fp32_masters.values()]
+        extra += [w.data_ptr() for w in self.fused_w.values()] + [b.data_ptr() for b in self.fused_b.values()]
+        extra += [self.patch_w_gemm.data_ptr(), 0 if self.embed_T is None else self.embed_T.data_ptr()]
+        return hash((tuple(d[k].data_ptr() for d, k in slots), tuple(extra)))
 
     def mark_dirty(self, name):
         """Call after writing an fp32 master through a raw pointer (torch's version counter

@@ -51,7 +51,7 @@ class LlavaNative(Blip2Native):
     def refresh_derived(self, force=False):
         pw = self.get("vision_tower.vision_model.embeddings.patch_embedding.weight")
         head = self.get("language_model.lm_head.weight")
-        ver = (pw._version, head._version)
+        ver = (pw._version, head._version, pw.data_ptr(), head.data_ptr())
         if not force and ver == self._derived_version:
             return
         self.patch_w_gemm.zero_()

@@ -60,7 +60,7 @@ class MiniGPT4Native(Blip2Native):
         pw = self.get("visual_encoder.patch_embed.proj.weight")
         head = self.get("llama_model.lm_head.weight")
         b0 = self.get("visual_encoder.blocks.0.attn.q_bias")
-        ver = (pw._version, head._version, b0._version)
+        ver = (pw._version, head._version, b0._version, pw.data_ptr(), head.data_ptr(), b0.data_ptr())
         if not force and ver == self._derived_version:
             return
         self.patch_w_gemm.zero_()

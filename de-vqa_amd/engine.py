@@ -72,8 +72,11 @@ class Blip2Engine:
         neurons), or DEVQA_PATH_ABI=0 (A/B tests of the two drivers of the same kernels)."""
         if type(self) is not Blip2Engine or not hasattr(self.m, "weight_table") or os.environ.get("DEVQA_PATH_ABI", "1") == "0":
             return None
-        masters = frozenset(self.m._fp32_masters)
-        if self.__dict__.get("_ctx") is None or self._ctx_masters != masters:      # an editor promoted a new edit target
+        # the context caches raw device pointers of the whole weight table: rebuild it whenever any of those buffers has moved (an
+        # editor promoted a new edit target, a parameter was reassigned out of place or reloaded, the model changed device)
+        self.m.refresh_derived()
+        fp = self.m.storage_fingerprint()
+        if self.__dict__.get("_ctx") is None or self._ctx_fp != fp:
             v, q, t = self.v, self.q, self.t
             d = lib.ModelDesc(family=lib.FAMILY_BLIP2_OPT, compute_dtype=lib.DTYPE_BF16 if self.adt == torch.bfloat16 else lib.DTYPE_F32,
                               image_size=v["image_size"], patch_size=v["patch_size"], v_hidden=v["hidden_size"], v_layers=v["num_hidden_layers"],
@@ -88,8 +91,7 @@ class Blip2Engine:
                 torch.cuda.current_stream(self.dev).synchronize()
                 old.close()
             self._ctx = lib.PathContext(self.dev.index or 0, d, self.m.weight_table())
-            self._ctx_masters = masters
-        self.m.refresh_derived()
+            self._ctx_fp = fp
         self.m.refresh_shadows()
         return self._ctx
 

@@ -234,9 +234,38 @@ def test_mend_training_steps(gold_dir, in_gold_dir, mode):
     ck = torch.load(path, map_location="cpu", weights_only=True)
     assert set(ck) == {"i", "epoch", "loss", "ema_loss", "train_modules", "opt", "lr_scheduler"} and ck["i"] == 2
     assert set(ck["train_modules"]) == {"aux_models", "edit_lrs"} and "(40, 80).mlp.layers.0.u" in ck["train_modules"]["aux_models"]
-    assert set(ck["opt"]) == {"t", "m", "v"}
+    assert set(ck["opt"]) == {"state", "param_groups"}     # torch.optim.Adam's layout, as the reference writes it
+    assert [len(g_["params"]) for g_ in ck["opt"]["param_groups"]] == [20, 4] and len(ck["opt"]["state"]) == 24
     ed2 = MENDvl(vllm, cfg, "cuda:0", ckpt_path=path)
     assert torch.equal(ed2.aux["(40, 80).mlp.layers.1.v"], ed.aux["(40, 80).mlp.layers.1.v"])
+    # the reference's OWN `Best` after the same two steps (tools/make_goldens_mend.py --train): its `opt` is a torch Adam state dict
+    # over [aux_models.parameters(), edit_lrs]; mapped onto the HIP moment buffers it must hold the moments this run produced
+    ref = torch.load(os.path.join(gold_dir, "tiny_mend_train_best.pt"), map_location="cpu", weights_only=True)
+    st = ed.get_a_new_optimizer()
+    st.load_state_dict(ref["opt"])
+    assert st["t"] == 2 == ed.opt["t"]
+    if mode == "fp32":
+        for mv in ("m", "v"):
+            for k_ in st[mv]:
+                a_, b_ = st[mv][k_].cpu(), ed.opt[mv][k_].cpu()
+                assert float((a_ - b_).abs().max()) <= 1e-4 * float(a_.abs().max()) + 1e-12, (mv, k_)
+        # `train_vllm_editor.py -lkpt <reference Best>`: train_init loads modules AND optimizer state, then training goes on
+        from devqa_amd.dataset.vllm import BaseVLLMEditData
+
+        class D(BaseVLLMEditData):
+            def dataset_name(self):
+                return "EVQA"
+        ed3 = MENDvl(vllm, cfg, "cuda:0", for_train=True)
+        recs = [deepcopy(r) for r in rec[:2]]
+        ed3.train_init(D(recs, deepcopy(recs)), 1, records_dir="/tmp/devqa_mend_resume", load_ckpt_path=os.path.join(gold_dir, "tiny_mend_train_best.pt"),
+                       random_seed=1)
+        assert ed3.train_i == 2 and ed3.opt["t"] == 2
+        assert float((ed3.opt["m"]["(40, 80).mlp.layers.0.v"].cpu() - st["m"]["(40, 80).mlp.layers.0.v"].cpu()).abs().max()) == 0.0
+        gold = ref["train_modules"]["aux_models"]["(40, 80).mlp.layers.1.u"]
+        assert float((ed3.aux["(40, 80).mlp.layers.1.u"].cpu() - gold).abs().max()) == 0.0
+        loss3, _ = ed3.train_a_batch(ed3.organize_batch_data([deepcopy(rec[2])]))
+        assert np.isfinite(loss3) and ed3.opt["t"] == 3
+        ed3.data_generator.close()
 
 
 def test_mend_train_from_scratch_then_edit(gold_dir, in_gold_dir, tmp_path):

@@ -198,6 +198,52 @@ def test_engine_over_the_context_equals_python_schedule(tiny, in_gold_dir):
                 assert r1[0][sec][sub][0]["acc"] == r2[0][sec][sub][0]["acc"]
 
 
+def test_context_follows_reassigned_parameter_storage(gold_dir):
+    """The path-level context caches raw device pointers of the weight table.  A parameter whose STORAGE is replaced (an editor
+    assigning `p.data = ...`, a reload into fresh buffers) must be seen by the next call: the engine keys the context on the
+    model's storage fingerprint and rebuilds it.  Checked against the Python-ordered schedule, which looks parameters up by name
+    on every call (DEVQA_PATH_ABI=0)."""
+    import devqa_amd  # noqa: F401
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    vllm = BLIP2OPTForEdit(os.path.join(gold_dir, "tiny_blip2"), "cuda:0", dtype="bf16")
+    eng, m = vllm.engine, vllm.model
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))["records"]
+    old = os.getcwd()
+    os.chdir(gold_dir)
+    try:
+        pix = torch.from_numpy(np.stack([vllm.load_pixels(rec[0]["requests"][0]["image"])])).cuda()
+    finally:
+        os.chdir(old)
+    seqs = [(0, [2, 17, 33, 21, 9])]
+
+    def logits():
+        it = eng.encode_images(pix)
+        ps = eng.pack_from_tokens(seqs, it)
+        return eng.full_logits(ps).clone()
+    base = logits()
+    ctx0 = eng.path_ctx()
+    assert ctx0 is not None and eng.path_ctx() is ctx0           # unchanged storage: the context is kept
+    names = ["language_model.model.decoder.layers.0.fc1.weight", "vision_model.encoder.layers.1.mlp.fc2.weight",
+             "language_model.model.decoder.layers.1.final_layer_norm.bias"]
+    for n in names:                                              # out-of-place: new storage, new values
+        p = m.get(n)
+        p.data = (p.data.float() * 1.5 + 0.01).to(p.dtype)
+    got = logits()
+    assert eng.path_ctx() is not ctx0                            # rebuilt
+    os.environ["DEVQA_PATH_ABI"] = "0"
+    try:
+        want = logits()
+    finally:
+        del os.environ["DEVQA_PATH_ABI"]
+    assert torch.equal(got, want)
+    assert not torch.equal(got, base)
+    # in-place writes keep the addresses: no rebuild, values still followed
+    ctx1 = eng.path_ctx()
+    m.get(names[0]).mul_(0.5)
+    got2 = logits()
+    assert eng.path_ctx() is ctx1 and not torch.equal(got2, got)
+
+
 def test_path_level_error_behaviour(tiny):
     from devqa_amd import lib
     vllm = tiny[0]
@@ -239,7 +285,14 @@ def test_gather_scores_single_rank():
     out = comm.gather_scores(rows)
     torch.cuda.synchronize()
     assert torch.equal(out, rows)
+    h = comm.h
     comm.close()
+    # a destroyed (or never created) communicator handle is an error status, not a dereference
+    L = lib.load()
+    assert L.devqa_gather_scores(ctypes.c_uint64(h), ctypes.c_void_p(rows.data_ptr()), 5, ctypes.c_void_p(out.data_ptr()), None) == -5
+    assert b"communicator" in L.devqa_last_error()
+    assert L.devqa_comm_destroy(ctypes.c_uint64(h)) == -5
+    assert L.devqa_gather_scores(ctypes.c_uint64(0xdeadbeef), ctypes.c_void_p(rows.data_ptr()), 5, ctypes.c_void_p(out.data_ptr()), None) == -5
 
 
 def test_mend_transform_and_apply_entry_points():

@@ -166,3 +166,57 @@ def test_toy_editor_trains_through_the_reference_api(tmp_path):
     assert float(ed2.net.weight) == pytest.approx(float(ck["train_modules"]["net"]["weight"]))
     i, ep, loss, ema = ed2.load_ckpt(str(root / "checkpoints" / "Best"), True, False)
     assert (i, ep) == (ck["i"], ck["epoch"])
+
+
+def test_hip_adam_state_reads_and_writes_torch_adam_layout():
+    """The `opt` entry of a reference `Best` checkpoint is `torch.optim.Adam.state_dict()` (R/editor/vllm_editors/base.py:237-255)
+    over [{aux_models.parameters()}, {edit_lrs.parameters()}] (mend_vl.py:273-275).  HipAdamState maps it onto its named moment
+    buffers (scalar ParameterList entries -> elements of one vector), writes the same layout back, and continues with fresh
+    moments -- with a warning, never an exception -- when a foreign state cannot be mapped."""
+    import warnings
+    import torch
+    import devqa_amd  # noqa: F401
+    from devqa_amd.editor.vllm_editors.base import HipAdamState
+    g = torch.Generator().manual_seed(0)
+    shapes = {"a.u": (6, 3), "a.v": (3, 6), "a.bias": (6,)}
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes.values()]
+    lrs = [torch.nn.Parameter(torch.tensor(1e-4 * (i + 1))) for i in range(3)]
+    opt = torch.optim.Adam([{"params": params, "lr": 1e-6}, {"params": lrs, "lr": 1e-4}])
+    for _ in range(3):
+        opt.zero_grad()
+        (sum((p_ ** 2).sum() for p_ in params) + sum(l ** 2 for l in lrs)).backward()
+        opt.step()
+
+    def fresh():
+        st = HipAdamState(t=0, m={}, v={}, torch_order=[(k, None) for k in shapes] + [("edit_lrs", i) for i in range(3)],
+                          group_sizes=[3, 3], group_lrs=[1e-6, 1e-4])
+        for k, s in shapes.items():
+            st["m"][k], st["v"][k] = torch.zeros(s), torch.zeros(s)
+        st["m"]["edit_lrs"], st["v"]["edit_lrs"] = torch.zeros(3), torch.zeros(3)
+        return st
+    st = fresh()
+    st.load_state_dict(opt.state_dict())
+    assert st["t"] == 3
+    for i, k in enumerate(shapes):
+        assert torch.equal(st["m"][k], opt.state[params[i]]["exp_avg"]) and torch.equal(st["v"][k], opt.state[params[i]]["exp_avg_sq"])
+    for i in range(3):
+        assert float(st["m"]["edit_lrs"][i]) == float(opt.state[lrs[i]]["exp_avg"])
+    # written back in torch's layout: a torch Adam over the same parameters loads it and holds the same moments
+    opt2 = torch.optim.Adam([{"params": params, "lr": 1e-6}, {"params": lrs, "lr": 1e-4}])
+    opt2.load_state_dict(st.state_dict())
+    for p_ in params + lrs:
+        assert torch.equal(opt2.state[p_]["exp_avg"], opt.state[p_]["exp_avg"]) and float(opt2.state[p_]["step"]) == 3.0
+    assert opt2.param_groups[1]["lr"] == 1e-4
+    # the private round-2 layout still loads
+    st3 = fresh()
+    st3.load_state_dict({"t": 5, "m": {k: v + 1 for k, v in st["m"].items()}, "v": dict(st["v"])})
+    assert st3["t"] == 5 and torch.equal(st3["m"]["a.u"], st["m"]["a.u"] + 1)
+    # foreign / unmappable state: warn, fresh moments, no exception (train_init -lkpt must not die on it)
+    bad = opt.state_dict()
+    bad["param_groups"][0]["params"] = bad["param_groups"][0]["params"][:-1]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        st.load_state_dict(bad)
+        st4 = fresh()
+        st4.load_state_dict({"something": "else"})
+    assert len(w) == 2 and st["t"] == 0 and float(st["m"]["a.u"].abs().max()) == 0.0

@@ -249,6 +249,16 @@ def train():
                 npz["s%d_state_%s.%s" % (si, mname, n)] = t2n(t).astype(np.float32)
     np.savez_compressed(os.path.join(GOLD, "tiny_mend_train_goldens.npz"), **npz)
     json.dump(js, open(os.path.join(GOLD, "tiny_mend_train_goldens.json"), "w"), indent=1)
+    # the reference's own `Best` checkpoint after these two steps (base.py:237-255): its `opt` entry is the torch.optim.Adam state
+    # dict a resumed training (-lkpt) has to map onto the HIP moment buffers
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    ed.opt.step = orig_step
+    ed.save_ckpt_dir, ed.lr_scheduler = tmp, None
+    ed.save_ckpt(2, 0, js["steps"][-1]["loss"], js["steps"][-1]["loss"])
+    shutil.copy(os.path.join(tmp, "Best"), os.path.join(GOLD, "tiny_mend_train_best.pt"))
+    shutil.rmtree(tmp, ignore_errors=True)
     print("mend train goldens written:", len(npz), "arrays; losses", [s_["loss"] for s_ in js["steps"]])
 
 
