@@ -18,6 +18,8 @@
 //                      normaliser never cross lanes and the output leaves in 8-byte packed stores.
 // head dims that are not multiples of 32 (88, 80) are zero-padded in LDS to DHP = 96.
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include "common.h"
 #include <type_traits>
 
@@ -807,10 +809,43 @@ __global__ __launch_bounds__(512, 1) void attention_mfma_resident_kernel(const b
     }
 }
 
+// Variant switches (A/B measurements and the variant tests): read from the environment ONCE, and again only when the host asks
+// (devqa_attention_reload_env; lib.attention re-reads when it sees a DEVQA_ATTENTION_* variable change).  -1 = unset.
+namespace {
+struct AttnEnv { int resident = -1, qb = -1, dbuf = -1, nw = -1, exp = -1, dma = -1, shrt = -1; };
+AttnEnv g_attn_env;
+std::atomic<int> g_attn_env_ready{0};
+std::mutex g_attn_env_mu;
+int env_int(const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; }
+void attn_env_load() {
+    std::lock_guard<std::mutex> lock(g_attn_env_mu);
+    AttnEnv e;
+    e.resident = env_int("DEVQA_ATTENTION_RESIDENT");
+    e.qb = env_int("DEVQA_ATTENTION_QB");
+    e.dbuf = env_int("DEVQA_ATTENTION_DBUF");
+    e.nw = env_int("DEVQA_ATTENTION_NW");
+    e.dma = env_int("DEVQA_ATTENTION_DMA");
+    e.shrt = env_int("DEVQA_ATTENTION_SHORT");
+#ifdef DEVQA_EXPERIMENTS
+    e.exp = env_int("DEVQA_ATTENTION_EXP");      // timing experiments (WRONG results): compiled in only with -DDEVQA_EXPERIMENTS
+#endif
+    g_attn_env = e;
+    g_attn_env_ready.store(1, std::memory_order_release);
+}
+}  // namespace
+
+extern "C" int devqa_attention_reload_env() {
+    attn_env_load();
+    return DEVQA_OK;
+}
+
 int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t ldk, const bf16_t* v, int64_t ldv, bf16_t* out,
                           int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale,
                           int causal, void* stream) {
     const int dhp = (dh + 31) / 32 * 32;
+    if (dhp != 32 && dhp != 64 && dhp != 96 && dhp != 128) return devqa_fail(DEVQA_E_SHAPE, "attention: dh=%d unsupported", dh);
+    if (!g_attn_env_ready.load(std::memory_order_acquire)) attn_env_load();
+    const AttnEnv env = g_attn_env;
     hipStream_t st0 = (hipStream_t)stream;
     // causal bit 2 (value 4, include/devqa.h): the caller asserts plain non-causal self-attention (kp_len == 0, ko_len == q_len) for
     // EVERY sequence -> short sequences MAY take the K/V-resident kernel (opt-in: DEVQA_ATTENTION_RESIDENT=1)
@@ -819,8 +854,7 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     if (self_full && causal == 0 && max_q_len <= 320 && (dhp == 96 || dhp == 64) && (long)n_seq * H >= 128) {
         // built, tested and NOT the default: 233 us against 214 us for the chunked kernel on ViT-g (127 x 16 x 257): one 8-wave
         // workgroup per CU (140 KiB of LDS) hides less latency than three 4-wave ones, and the staging is not overlapped
-        const char* e = getenv("DEVQA_ATTENTION_RESIDENT");
-        if (e && atoi(e) == 1) {
+        if (env.resident == 1) {
             const int nkp = (max_q_len + AM_KC - 1) / AM_KC * AM_KC;
             const size_t smem = (size_t)2 * nkp * (2 * dhp + 32);
             const long grid = (long)n_seq * H;
@@ -842,42 +876,51 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     // QB = 2 (128-query tiles) is built and tested (DEVQA_ATTENTION_QB=2) but NOT the default: on ViT-g (127 images x 16 heads x
     // 257 tokens) it measured 223 us against 207 us for QB = 1 -- halving the LDS fragment traffic does not pay for the occupancy
     // lost to 221 VGPRs; the kernel is bound by its ~19 VALU instructions per MFMA (SQ counters, profiles/r01_summary.md H).
-    const char* qb_env = getenv("DEVQA_ATTENTION_QB");     // read per launch: the tests flip it
-    const int qb = (qb_env && atoi(qb_env) == 2 && max_q_len > 2 * AM_QT && dhp <= 96) ? 2 : 1;
-    const char* db_env = getenv("DEVQA_ATTENTION_DBUF");
-    const bool dbuf = db_env && atoi(db_env) == 1 && qb == 1 && dhp <= 96;
+    const int qb = (env.qb == 2 && max_q_len > 2 * AM_QT && dhp <= 96) ? 2 : 1;
+    const bool dbuf = env.dbuf == 1 && qb == 1 && dhp <= 96;
     // 96-query tiles (6 waves) when they need fewer wave slots than 64-query tiles for the longest sequence (257 -> 18 vs 20)
-    const char* nw_env = getenv("DEVQA_ATTENTION_NW");
+    const bool nw_env = env.nw != -1;
     const int slots4 = (max_q_len + 63) / 64 * 4, slots6 = (max_q_len + 95) / 96 * 6;
     int nw = 4;   // 6 waves measured 40 % SLOWER on ViT-g (6 waves over 4 SIMDs: two SIMDs carry twice the work): opt-in only
     (void)slots4; (void)slots6;
-    if (nw_env && dhp == 96 && qb == 1 && !dbuf) nw = atoi(nw_env) == 6 ? 6 : 4;
-    const char* exp_env = getenv("DEVQA_ATTENTION_EXP");      // timing experiments (wrong results), tools/debug/att_tail_cost.py
-    const int exp_id = (exp_env && nw == 4 && qb == 1 && !dbuf) ? atoi(exp_env) : 0;
-    const char* dma_env = getenv("DEVQA_ATTENTION_DMA");      // 0: the register-staged kernel (previous default)
+    if (nw_env && dhp == 96 && qb == 1 && !dbuf) nw = env.nw == 6 ? 6 : 4;
+    // timing experiments (wrong results, tools/debug/att_tail_cost.py): exist only in a -DDEVQA_EXPERIMENTS build
+    const int exp_id = (env.exp > 0 && nw == 4 && qb == 1 && !dbuf) ? env.exp : 0;
+    const bool dma_env = env.dma != -1;                       // 0: the register-staged kernel (previous default)
     // default for long sequences only: on the decoder pack of the bench (960 sequences of 32-80 keys, visible prefix + causal own
     // range, one or two chunks each) the DMA kernel measured 198 us against 135 us for the register-staged one (rocprofv3 trace of
     // bench.py) -- nothing to overlap the DMA with; DEVQA_ATTENTION_DMA=1 forces it, =0 disables it
     const bool dma = nw == 4 && qb == 1 && !dbuf && exp_id == 0 &&
-                     (dma_env ? atoi(dma_env) != 0 : max_q_len >= 224);
+                     (dma_env ? env.dma != 0 : max_q_len >= 224);
     // 128-query tiles (8 waves) halve the K / V staging per query, which is what bounds the kernel on long sequences (ViT-g, T = 256:
     // 133 -> 116 us); short sequences fill 64-query tiles better (T = 128: 43.6 vs 47.3 us)
     int dma_nw = max_q_len >= 224 ? 8 : 4;
-    if (nw_env && (atoi(nw_env) == 8 || atoi(nw_env) == 4)) dma_nw = atoi(nw_env);
+    if (env.nw == 8 || env.nw == 4) dma_nw = env.nw;
     // causal packs of short sequences (decoder probes): 32-query tiles of two waves on ONE LDS-DMA image (attention_mfma_dma_kernel<D, 2, true>);
     // non-causal short-query calls (Q-Former: 32 queries over 257 keys) keep the register-staged kernel
-    const char* short_env = getenv("DEVQA_ATTENTION_SHORT");
+    const bool short_env = env.shrt != -1;
     // measured on a 127-cycle probe pack (tools/debug/att_pack_bench.py, 2159 sequences): OPT heads (dh 80) 368.6 us against 362.6 us for the
     // register-staged kernel -- the pack is bound by the instructions issued per (sequence, head), not by the pairs in flight, and both forms
     // issue about the same; LLaMA heads (dh 128, where the register-staged form holds two workgroups per CU) 57.8 against 72.1 us.  Default:
     // dh 128 only; DEVQA_ATTENTION_SHORT=1 forces it for every head size, =0 turns it off
-    const bool short_ok = short_env ? atoi(short_env) != 0 : dhp == 128;
+    const bool short_ok = short_env ? env.shrt != 0 : dhp == 128;
     const bool dma_short = causal && !dma && !dma_env && nw == 4 && qb == 1 && !dbuf && exp_id == 0 && !nw_env && max_q_len <= 64 && short_ok;
     const int qt = dma_short ? 32 : dma ? 16 * dma_nw : 16 * nw * qb;
     const int q_tiles = (max_q_len + qt - 1) / qt;
     const long grid = (long)n_seq * H * q_tiles;
     DEVQA_CHECK_SHAPE(grid < 2147483647L, "attention: grid too large");
     hipStream_t st = (hipStream_t)stream;
+#ifdef DEVQA_EXPERIMENTS
+#define LAUNCH_EXP()                                                                                                   \
+    do {                                                                                                               \
+        if (exp_id == 1) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
+        if (exp_id == 2) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
+        if (exp_id == 3) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
+        if (exp_id == 4) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
+    } while (0)
+#else
+#define LAUNCH_EXP() do { } while (0)     /* exp_id is always 0 in a product build */
+#endif
 #define LAUNCH(D)                                                                                                      \
     do {                                                                                                               \
         if (qb == 2)                                                                                                   \
@@ -897,10 +940,7 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
                 hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
                                    out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                 \
         } else if (exp_id >= 1 && exp_id <= 4 && D == 96) {                                                              \
-            if (exp_id == 1) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
-            if (exp_id == 2) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
-            if (exp_id == 3) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
-            if (exp_id == 4) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
+            LAUNCH_EXP();                                                                                              \
         } else if (nw == 6)                                                                                            \
             hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 6>), dim3((unsigned)grid), dim3(384), 0, st, q, ldq, k, ldk, v, ldv, \
                                out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                     \
@@ -913,9 +953,9 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     if (dhp == 32) LAUNCH(32);
     else if (dhp == 64) LAUNCH(64);
     else if (dhp == 96) LAUNCH(96);
-    else if (dhp == 128) LAUNCH(128);
-    else return devqa_fail(DEVQA_E_SHAPE, "attention: dh=%d unsupported", dh);
+    else LAUNCH(128);
 #undef LAUNCH
+#undef LAUNCH_EXP
     devqa_prof_end(ph, 4.0 * (double)n_seq * H * (double)max_q_len * (double)max_q_len * dh * ((causal & 1) ? 0.5 : 1.0), st);
     DEVQA_LAUNCH_CHECK("attention_mfma");
     return DEVQA_OK;

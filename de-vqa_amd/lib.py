@@ -60,6 +60,7 @@ def load():
     _sig(L.devqa_embed_rows_f32, [P, P, P, P, P, P, I, I, I, I, I, P, P])
     _sig(L.devqa_vocab_rows_f32, [P, I64, I, I, P, P, P, P, P, I64, P])
     _sig(L.devqa_attention, [P, I64, P, I64, P, I64, P, I64, P, I, I, I, I, F, I, P])
+    _sig(L.devqa_attention_reload_env, [])
     _sig(L.devqa_im2col_patches, [P, I, I, I, I, P, P])
     _sig(L.devqa_vit_assemble, [P, P, P, I, I, I, P, P])
     _sig(L.devqa_embed_rows, [P, P, P, P, P, P, I, I, I, I, I, P, P])
@@ -135,7 +136,7 @@ EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "dev
            "devqa_mend_transform", "devqa_mend_apply_workspace", "devqa_mend_apply", "devqa_llm_head_workspace", "devqa_llm_head", "devqa_llm_forward_workspace",
            "devqa_llm_forward", "devqa_ft_edit_workspace", "devqa_ft_edit", "devqa_ctx_bind_edit_target", "devqa_apply_delta", "devqa_restore",
            "devqa_token_acc", "devqa_comm_unique_id", "devqa_comm_create", "devqa_comm_destroy", "devqa_gather_scores",
-           "devqa_profile", "devqa_profile_read", "devqa_profile_dropped", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
+           "devqa_profile", "devqa_profile_read", "devqa_profile_dropped", "devqa_attention_reload_env", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
            "devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
@@ -409,6 +410,22 @@ def colsum_(x, out, accumulate=True):
     _chk(load().devqa_colsum_f32(_p(x), M, D, int(bool(accumulate)), _p(out), _stream()), "devqa_colsum_f32")
 
 
+_ATT_ENV_KEYS = ("DEVQA_ATTENTION_DMA", "DEVQA_ATTENTION_NW", "DEVQA_ATTENTION_QB", "DEVQA_ATTENTION_DBUF", "DEVQA_ATTENTION_SHORT",
+                 "DEVQA_ATTENTION_RESIDENT", "DEVQA_ATTENTION_EXP")
+_att_env_seen = None
+
+
+def attention_env_sync():
+    """The library reads its DEVQA_ATTENTION_* variant switches once; tests and A/B tools flip them between calls, so the op-level
+    wrapper has them re-read when this process changed one (a handful of dict lookups per call)."""
+    global _att_env_seen
+    cur = tuple(os.environ.get(k) for k in _ATT_ENV_KEYS)
+    if cur != _att_env_seen:
+        if _att_env_seen is not None or any(v is not None for v in cur):
+            _chk(load().devqa_attention_reload_env(), "devqa_attention_reload_env")
+        _att_env_seen = cur
+
+
 def attention(q, k, v, seq_desc, n_seq, max_q_len, H, dh, scale, causal, out=None, self_full=False):
     """q,k,v: bf16 2-D views (rows x >=H*dh, unit inner stride). seq_desc int32 [n_seq,6] on device.
     self_full=True promises plain non-causal self-attention for every sequence (kp_len == 0, ko_len == q_len): devqa.h, causal bit 2."""
@@ -421,6 +438,7 @@ def attention(q, k, v, seq_desc, n_seq, max_q_len, H, dh, scale, causal, out=Non
     assert seq_desc.dtype == torch.int32 and seq_desc.is_cuda and seq_desc.is_contiguous()
     if out is None:
         out = torch.empty((q.shape[0], H * dh), dtype=q.dtype, device=q.device)
+    attention_env_sync()
     fn = load().devqa_attention if q.dtype == torch.bfloat16 else load().devqa_attention_f32
     _chk(fn(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
                                 _p(seq_desc), int(n_seq), int(max_q_len), int(H), int(dh), float(scale), int(causal),

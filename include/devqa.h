@@ -145,6 +145,10 @@ int devqa_attention(const devqa_bf16* q, int64_t ldq, const devqa_bf16* k, int64
                     int64_t ldv, devqa_bf16* out, int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len,
                     int H, int dh, float scale, int causal, void* stream);
 
+/* The kernel-variant switches of devqa_attention (DEVQA_ATTENTION_DMA / _NW / _QB / _DBUF / _SHORT / _RESIDENT: A/B measurements and
+ * the variant tests) are read from the environment once; a host that changes them afterwards calls this to have them read again. */
+int devqa_attention_reload_env(void);
+
 int devqa_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out,
                         int64_t ldo, const int32_t* seq_desc, int n_seq, int max_q_len, int H, int dh, float scale,
                         int causal, void* stream);
