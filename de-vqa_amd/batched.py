@@ -398,10 +398,28 @@ class BatchedEditEval:
         self.stats["t_ft"] += ft_ms * 1e-3
         self.stats["t_tail"] += (evb[0].elapsed_time(evb[1]) + evb[2].elapsed_time(evb[3])) * 1e-3
         # ---- 7. host: results -----------------------------------------------------------------------------
-        tok = vllm.tokenizer
         edit_time = ft_ms * 1e-3 / E
-        out, meta = [], []
-        for e, (rd, plist) in enumerate(zip(rds, probes)):
+        out = self._fill_results(rds, probes, pre_h, post_h, edit_time)
+        meta = [(int(steps_h[e]), float(losses_h[e, max(int(steps_h[e]) - 1, 0)])) for e in range(E)]
+        self.stats["cycles"] += E
+        self.stats["steps"] += int(steps_h.sum())
+        # algorithmic HBM bytes of the executed AdamW updates (include/devqa.h, devqa_ft_adamw_step): the first update of an edit
+        # reads w0 and writes w, m, v (4 tensors), every later one reads and writes w, m, v (6 tensors), fp32, on [Dout, npad]
+        Dout_, npad_ = h["ft_shape"]
+        n_upd = int(upd_h.sum())
+        self.stats["updates"] = self.stats.get("updates", 0) + n_upd
+        self.stats["ft_bytes"] = self.stats.get("ft_bytes", 0) + 4 * Dout_ * npad_ * (6 * n_upd - 2 * int((upd_h > 0).sum()))
+        self.last_losses = losses_h
+        self.last_steps = steps_h
+        self.stats["t_host"] += time.time() - t5
+        return out, meta
+
+    def _fill_results(self, rds, probes, pre_h, post_h, edit_time):
+        """Result records of one batch from the host copies of the label-row argmax (R/evaluation/vllm_editor_eval.py:137-175):
+        locality probes are scored against the PRE-edit argmax, the others against the gold labels."""
+        tok = self.vllm.tokenizer
+        out = []
+        for rd, plist in zip(rds, probes):
             for p in plist:
                 m = np.asarray(p.mask) != 0
                 post = post_h[p.row0:p.row0 + p.L]
@@ -415,20 +433,8 @@ class BatchedEditEval:
                     p.rd["edit_time"] = edit_time
                 p.rd["predict_after_edit"] = tok.decode(torch.from_numpy(post[m].astype(np.int64)))
                 p.rd["acc"] = float(np.float32(((post == ref) & m).sum()) / np.float32(m.sum()))
-            meta.append((int(steps_h[e]), float(losses_h[e, max(int(steps_h[e]) - 1, 0)])))
             out.append(rd)
-        self.stats["cycles"] += E
-        self.stats["steps"] += int(steps_h.sum())
-        # algorithmic HBM bytes of the executed AdamW updates (include/devqa.h, devqa_ft_adamw_step): the first update of an edit
-        # reads w0 and writes w, m, v (4 tensors), every later one reads and writes w, m, v (6 tensors), fp32, on [Dout, npad]
-        Dout_, npad_ = h["ft_shape"]
-        n_upd = int(upd_h.sum())
-        self.stats["updates"] = self.stats.get("updates", 0) + n_upd
-        self.stats["ft_bytes"] = self.stats.get("ft_bytes", 0) + 4 * Dout_ * npad_ * (6 * n_upd - 2 * int((upd_h > 0).sum()))
-        self.last_losses = losses_h
-        self.last_steps = steps_h
-        self.stats["t_host"] += time.time() - t5
-        return out, meta
+        return out
 
     # ------------------------------------------------------------------------------------------
     def _argmax_from_y(self, y, tag=None):

@@ -476,6 +476,39 @@ extern "C" int devqa_cast_f32_bf16(const float* in, devqa_bf16* out, int64_t n, 
     return DEVQA_OK;
 }
 
+// out = act(in) on fp32 pre-activations (act: DEVQA_ACT_NONE / DEVQA_ACT_RELU), written as bf16 and / or fp32.  Used where a low-rank
+// term has to enter BEFORE the activation (MEND_VL's edited fc1: relu(h W^T + b + (h x~^T) d~), mend_vl.py:72-79), which the GEMM
+// epilogue (residual after the activation) cannot express: the GEMM leaves fp32 pre-activations, this pass finishes them.
+__global__ void act_cast_kernel(const float* __restrict__ in, int relu, bf16_t* __restrict__ ob, float* __restrict__ of, int64_t n4, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(in)[i];
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (ob) {
+            uint2 p;
+            p.x = pack_bf16x2(v.x, v.y);
+            p.y = pack_bf16x2(v.z, v.w);
+            reinterpret_cast<uint2*>(ob)[i] = p;
+        }
+        if (of) reinterpret_cast<float4*>(of)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        float v = in[n4 * 4 + threadIdx.x];
+        if (relu) v = fmaxf(v, 0.f);
+        if (ob) ob[n4 * 4 + threadIdx.x] = f32_to_bf16(v);
+        if (of) of[n4 * 4 + threadIdx.x] = v;
+    }
+}
+extern "C" int devqa_act_cast(const float* in, int act, devqa_bf16* out_bf16, float* out_f32, int64_t n, void* stream) {
+    DEVQA_CHECK_ARG(in && (out_bf16 || out_f32) && n >= 0 && (act == 0 || act == 1), "act_cast: bad args");
+    if (n == 0) return DEVQA_OK;
+    DEVQA_CHECK_SHAPE((((uintptr_t)in) & 15) == 0 && (((uintptr_t)out_bf16) & 7) == 0 && (((uintptr_t)out_f32) & 15) == 0, "act_cast: misaligned");
+    const int64_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(act_cast_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, (hipStream_t)stream, in, act, out_bf16, out_f32, n4, n);
+    DEVQA_LAUNCH_CHECK("act_cast");
+    return DEVQA_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ void delta_op_kernel(int mode, float* __restrict__ w, const float* __restrict__ w0, float* __restrict__ delta,
                                 int64_t n4) {

@@ -285,6 +285,17 @@ class MENDvl(VLLMBaseEditorWithTraining):
             inp = out
         return inp[:, :din].contiguous(), inp[:, din:].contiguous(), (trace if self.training else None)
 
+    def transform_rows(self, m, x32, d32):
+        """Inference-mode GradientTransform of EVERY given row (fp32 x [n, d_in], delta [n, d_out]) for edited module `m` -> (x~, d~):
+        K16 as one path-level call.  The transform is row-wise, so rows of many edits may share a call (batched_mend.py)."""
+        pre = "%s." % str(m["shape"])
+        A = self.aux
+        layers = [{"u": A[pre + "mlp.layers.%d.u" % l], "v": A[pre + "mlp.layers.%d.v" % l], "bias": A[pre + "mlp.layers.%d.bias" % l],
+                   "mode_scale": A[pre + "mlp.layers.%d.mode_scale.weight" % l][m["idx"]].contiguous(),
+                   "mode_shift": A[pre + "mlp.layers.%d.mode_shift.weight" % l][m["idx"]].contiguous()} for l in range(self.n_layers)]
+        stats = (A[pre + "u_mean"], A[pre + "u_std"], A[pre + "v_mean"], A[pre + "v_std"]) if bool(self.cfg.aux_model.norm) else None
+        return lib.mend_transform(x32, d32, None, layers, stats)
+
     def _install_deltas(self):
         """Factors of the running-mean delta weight for the engine: dW = X^T D / n with X, D the concatenated rows of
         all edits since the last restore (mend_vl.py:106-114), zero-padded to a multiple of 64 rows."""

@@ -287,9 +287,18 @@ class VLLMEditorEvaluation:
         eval_data, eval_data_ns = self.split_data(eval_data, edit_n)
         result_data, _ = self.split_data(result_data, edit_n)
         from ..batched import BatchedEditEval
-        use_batched = BatchedEditEval.supports(editor, eval_data, edit_n) if batched is None else batched
-        if use_batched:
-            results = BatchedEditEval(editor).run(result_data, eval_data)
+        from ..batched_mend import BatchedMendEval
+        # fully batched engines: FT_VL (batched.py) and MEND_VL (batched_mend.py); every other editor / shape of data runs the
+        # reference's call sequence per split (_sequential_generic)
+        engine_cls = next((cls for cls in (BatchedEditEval, BatchedMendEval) if cls.supports(editor, eval_data, edit_n)), None)
+        if batched is not None:
+            if not batched:
+                engine_cls = None
+            elif engine_cls is None:
+                engine_cls = BatchedMendEval if type(editor).__name__ == "MENDvl" else BatchedEditEval
+        self.last_mode = "generic" if engine_cls is None else engine_cls.__name__
+        if engine_cls is not None:
+            results = engine_cls(editor).run(result_data, eval_data)
         else:
             results = self._sequential_generic(editor, result_data, eval_data)
         if results is None:   # non-zero rank of a sharded run: rank 0 owns the files

@@ -61,6 +61,7 @@ def load():
     _sig(L.devqa_vocab_rows_f32, [P, I64, I, I, P, P, P, P, P, I64, P])
     _sig(L.devqa_attention, [P, I64, P, I64, P, I64, P, I64, P, I, I, I, I, F, I, P])
     _sig(L.devqa_attention_reload_env, [])
+    _sig(L.devqa_act_cast, [P, I, P, P, I64, P])
     _sig(L.devqa_im2col_patches, [P, I, I, I, I, P, P])
     _sig(L.devqa_vit_assemble, [P, P, P, I, I, I, P, P])
     _sig(L.devqa_embed_rows, [P, P, P, P, P, P, I, I, I, I, I, P, P])
@@ -136,7 +137,7 @@ EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "dev
            "devqa_mend_transform", "devqa_mend_apply_workspace", "devqa_mend_apply", "devqa_llm_head_workspace", "devqa_llm_head", "devqa_llm_forward_workspace",
            "devqa_llm_forward", "devqa_ft_edit_workspace", "devqa_ft_edit", "devqa_ctx_bind_edit_target", "devqa_apply_delta", "devqa_restore",
            "devqa_token_acc", "devqa_comm_unique_id", "devqa_comm_create", "devqa_comm_destroy", "devqa_gather_scores",
-           "devqa_profile", "devqa_profile_read", "devqa_profile_dropped", "devqa_attention_reload_env", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
+           "devqa_profile", "devqa_profile_read", "devqa_profile_dropped", "devqa_attention_reload_env", "devqa_act_cast", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
            "devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
@@ -489,6 +490,17 @@ def cast_f32_bf16(x, out=None):
         out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     _chk(load().devqa_cast_f32_bf16(_p(x), _p(out), x.numel(), _stream()), "devqa_cast_f32_bf16")
     return out
+
+
+def act_cast(x, act=ACT_RELU, want="bf16"):
+    """act(x) of fp32 pre-activations -> bf16 (new tensor) or fp32 (in place)"""
+    _need(x, torch.float32, "act_cast in")
+    if want == "bf16":
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        _chk(load().devqa_act_cast(_p(x), int(act), _p(out), None, x.numel(), _stream()), "devqa_act_cast")
+        return out
+    _chk(load().devqa_act_cast(_p(x), int(act), None, _p(x), x.numel(), _stream()), "devqa_act_cast")
+    return x
 
 
 def vocab_rows(logits, labels=None, coef=None, want_argmax=True, want_nll=False, want_dlogits=False,

@@ -265,6 +265,10 @@ int devqa_embed_rows_f32(const int32_t* token, const int32_t* src_row, const int
 int devqa_gather_rows(const void* in, const int32_t* idx, int R, int D, int elem_bytes, void* out, void* stream);
 /* fp32 -> bf16 (round to nearest even), n elements */
 int devqa_cast_f32_bf16(const float* in, devqa_bf16* out, int64_t n, void* stream);
+/* out = act(in) over n fp32 values (act: DEVQA_ACT_NONE or DEVQA_ACT_RELU), written as bf16 and / or fp32 (either may be NULL, out_f32
+ * may alias in).  Finishes fp32 pre-activations that received a low-rank term before the activation (MEND_VL's edited fc1,
+ * R/editor/vllm_editors/mend_vl/mend_vl.py:72-79). */
+int devqa_act_cast(const float* in, int act, devqa_bf16* out_bf16, float* out_f32, int64_t n, void* stream);
 
 /* ---- K9/K14 rows over the vocabulary ------------------------------------------------------
  * For each logits row r (fp32 [R,V], row stride ldl): argmax (first max wins, as torch.argmax),

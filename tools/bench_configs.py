@@ -158,6 +158,7 @@ def run_eval(editor, n, batched, out_dir="/tmp/devqa_bench_cfg", distinct_image_
     ev = VLLMEditorEvaluation(editor, D(a, b), "EVQA", out_dir)
     res, dt, prof = measured(lambda: ev.evaluate_sequential_edit(1, False, None, batched=batched, save=False))
     run_eval.last_profile = prof
+    run_eval.last_mode = getattr(ev, "last_mode", "generic")
     return len(res) / dt, dt, res
 
 
