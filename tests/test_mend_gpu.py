@@ -263,9 +263,9 @@ def test_mend_training_steps(gold_dir, in_gold_dir, mode):
         assert float((ed3.opt["m"]["(40, 80).mlp.layers.0.v"].cpu() - st["m"]["(40, 80).mlp.layers.0.v"].cpu()).abs().max()) == 0.0
         gold = ref["train_modules"]["aux_models"]["(40, 80).mlp.layers.1.u"]
         assert float((ed3.aux["(40, 80).mlp.layers.1.u"].cpu() - gold).abs().max()) == 0.0
+        ed3.data_generator.close()      # stop the prefetch thread first: it shares the (not thread-safe) HF tokenizer with this thread
         loss3, _ = ed3.train_a_batch(ed3.organize_batch_data([deepcopy(rec[2])]))
         assert np.isfinite(loss3) and ed3.opt["t"] == 3
-        ed3.data_generator.close()
 
 
 def test_mend_train_from_scratch_then_edit(gold_dir, in_gold_dir, tmp_path):
