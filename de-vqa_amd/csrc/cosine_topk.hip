@@ -10,6 +10,7 @@
 // Exactness: the fp32 scan only has to place the true top-k inside the top-(k+8); the final order
 // and the reported scores come from the fp64 re-score, so indices match a float64 brute force.
 #include <stdlib.h>
+#include <atomic>
 #include "common.h"
 #include <rocprim/warp/warp_reduce.hpp>
 
@@ -585,6 +586,228 @@ __global__ __launch_bounds__(256) void merge_final_kernel(const float* __restric
     }
 }
 
+
+// ---- few queries (Q <= 4: finds_sim, IKE_VL, LTE_VL retrieval), ONE launch -------------------------------------------------------
+// Phase A: every workgroup scores 32 corpus rows (a wave: 8 rows with all their loads in flight) for all Q queries, fp32, the corpus
+// norm either from the caller's cache (corpus_inv_norm) or accumulated in the same pass, and publishes the scores.
+// Phase B: the workgroup whose arrival on a counter came LAST selects per query the k + 8 best fp32 scores -- an exact radix select
+// on the order-preserving integer image of the scores (4 passes of 8 bits over register-resident keys, ties to the lowest ids) --
+// re-scores those candidates in fp64 and emits them by (score desc, id asc): the same contract as the tiled path.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility: hand-offs measured with sc1 accesses in place of release / acquire,
+// first row): the scores are written with agent-scope (sc1) stores, every storing wave drains them (s_waitcnt vmcnt(0)), the
+// workgroup's barrier, ONE lane's agent-scope atomic add on ONE counter; the workgroup whose add returned the last ticket reads the
+// scores with agent-scope (sc1) loads only, after a barrier behind that add.  The last workgroup resets the counter for the next call.
+#define CT_COUNTERS 64
+__device__ unsigned g_ct_counter[CT_COUNTERS];
+
+__device__ __forceinline__ unsigned ct_key(float f) {       // larger float <-> larger unsigned; -0 < +0 is harmless (fp64 re-score decides)
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int QMAX>
+__global__ __launch_bounds__(256) void cosine_fused_kernel(const float* __restrict__ corpus, const float* __restrict__ inv_cached,
+                                                           const float* __restrict__ queries, int N, int Q, int D, int norm_c, int norm_q,
+                                                           int k, int nc, float* scores, unsigned* counter,
+                                                           int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    extern __shared__ unsigned lkeys[];                    // phase B: the N keys of one query (dynamic LDS, 4 N bytes)
+    __shared__ ct_wr_storage wr_st[4];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_remaining, s_last, s_ngt, s_ntie, s_cnt[4];
+    __shared__ int cand_i[CT_MAXK + CT_MARGIN];
+    __shared__ double cand_s[CT_MAXK + CT_MARGIN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ct_wr_storage& wst = wr_st[wave];
+    // ---------------- phase A ----------------
+    {
+        constexpr int RG = 8;
+        const int row0 = blockIdx.x * 32 + wave * RG;
+        const int nrows = min(RG, N - row0);
+        if (nrows > 0) {
+            const int nv = D >> 2;
+            float nrm[RG], acc[RG][QMAX];
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                nrm[g] = 0.f;
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q) acc[g][q] = 0.f;
+            }
+            const bool need_norm = norm_c && inv_cached == nullptr;
+            for (int c = lane; c < nv; c += 64) {
+                float4 v[RG];
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+                    v[g] = reinterpret_cast<const float4*>(corpus + (int64_t)(row0 + min(g, nrows - 1)) * D)[c];
+                float4 u[QMAX];
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q)
+                    u[q] = q < Q ? reinterpret_cast<const float4*>(queries + (int64_t)q * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int g = 0; g < RG; ++g) {
+                    if (need_norm) nrm[g] += (v[g].x * v[g].x + v[g].y * v[g].y) + (v[g].z * v[g].z + v[g].w * v[g].w);
+#pragma unroll
+                    for (int q = 0; q < QMAX; ++q)
+                        acc[g][q] += (v[g].x * u[q].x + v[g].y * u[q].y) + (v[g].z * u[q].z + v[g].w * u[q].w);
+                }
+            }
+            float mine[QMAX];
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) mine[q] = 0.f;
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                float ic = 1.f;
+                if (need_norm) {
+                    float n2;
+                    ct_wr_f().reduce(nrm[g], n2, wst.f, rocprim::plus<float>());
+                    ic = n2 > 0.f ? 1.f / sqrtf(n2) : 0.f;
+                } else if (norm_c) {
+                    ic = inv_cached[row0 + min(g, nrows - 1)];
+                }
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q)
+                    if (q < Q) {
+                        float sc;
+                        ct_wr_f().reduce(acc[g][q], sc, wst.f, rocprim::plus<float>());
+                        if (lane == g) mine[q] = sc * ic;
+                    }
+            }
+            if (lane < nrows) {
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q)
+                    if (q < Q) __hip_atomic_store(scores + (int64_t)q * N + row0 + lane, mine[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores ...
+        __syncthreads();                                        // ... before the ONE lane that signals for the workgroup
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (t == gridDim.x - 1) ? 1 : 0;
+            if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+        }
+        __syncthreads();                                        // every wave of the last workgroup loads behind the add's return
+        if (!s_last) return;
+    }
+    // ---------------- phase B: the last workgroup ----------------
+    for (int qi = 0; qi < Q; ++qi) {
+        for (int id = tid; id < N; id += 256)
+            lkeys[id] = ct_key(__hip_atomic_load(scores + (int64_t)qi * N + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        unsigned prefix = 0u, mask = 0u;
+        int remaining = nc;                                     // nc <= N
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0u;
+            __syncthreads();                                    // (pass 0: also publishes lkeys)
+            for (int id = tid; id < N; id += 256) {
+                const unsigned key = lkeys[id];
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {                                    // lane l owns bins 4l .. 4l + 3; suffix sums over the lanes above
+                unsigned h[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) h[t] = hist[4 * lane + t];
+                const unsigned s = (h[0] + h[1]) + (h[2] + h[3]);
+                unsigned x = s;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned y = __shfl_down(x, off, 64);
+                    if (lane + off < 64) x += y;
+                }
+                unsigned gt = x - s;                            // keys in bins above this lane's
+#pragma unroll
+                for (int t = 3; t >= 0; --t) {
+                    if ((int)gt < remaining && remaining <= (int)(gt + h[t])) {
+                        s_prefix = prefix | ((unsigned)(4 * lane + t) << shift);
+                        s_remaining = remaining - (int)gt;
+                    }
+                    gt += h[t];
+                }
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            remaining = s_remaining;
+            mask |= 0xffu << shift;
+        }
+        // prefix = the nc-th largest key; every key above it is a candidate, `remaining` of the keys equal to it (lowest ids first)
+        if (tid == 0) { s_ngt = 0; s_ntie = 0; }
+        __syncthreads();
+        int my_ties = 0;
+        for (int id = tid; id < N; id += 256) {
+            const unsigned key = lkeys[id];
+            if (key > prefix) cand_i[atomicAdd(&s_ngt, 1)] = id;
+            else if (key == prefix) ++my_ties;
+        }
+        if (my_ties) atomicAdd(&s_ntie, my_ties);
+        __syncthreads();
+        int id_cap = N - 1;                                     // ties with id <= id_cap are taken
+        if (s_ntie > remaining) {                               // more equal keys than places: the `remaining` lowest ids (rare)
+            int lo = 0, hi = N - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                int c = 0;
+                for (int id = tid; id <= mid; id += 256) c += lkeys[id] == prefix ? 1 : 0;
+                int cs;
+                ct_wr_i().reduce(c, cs, wst.i, rocprim::plus<int>());
+                __syncthreads();
+                if (lane == 0) s_cnt[wave] = cs;
+                __syncthreads();
+                const int tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+                if (tot >= remaining) hi = mid; else lo = mid + 1;
+            }
+            id_cap = lo;
+        }
+        const int base = s_ngt;
+        __syncthreads();
+        if (tid == 0) s_ntie = 0;
+        __syncthreads();
+        for (int id = tid; id <= id_cap; id += 256)
+            if (lkeys[id] == prefix) cand_i[base + atomicAdd(&s_ntie, 1)] = id;
+        __syncthreads();
+        // fp64 re-score of the nc candidates, rank by (score desc, id asc), emit the first k
+        const float* qv = queries + (int64_t)qi * D;
+        double qn = 0.0;
+        if (norm_q) {
+            for (int c = lane; c < D; c += 64) qn += (double)qv[c] * (double)qv[c];
+            qn = wave_sum_d(qn);
+        }
+        for (int p = wave; p < nc; p += 4) {
+            const int ci = cand_i[p];
+            const float* cv = corpus + (int64_t)ci * D;
+            double dot = 0.0, cn = 0.0;
+            for (int c = lane; c < D; c += 64) {
+                const double xx = (double)cv[c];
+                dot += xx * (double)qv[c];
+                cn += xx * xx;
+            }
+            dot = wave_sum_d(dot);
+            cn = wave_sum_d(cn);
+            if (lane == 0) {
+                double sc = dot;
+                if (norm_c) sc = cn > 0.0 ? sc / sqrt(cn) : 0.0;
+                if (norm_q) sc = qn > 0.0 ? sc / sqrt(qn) : 0.0;
+                cand_s[p] = sc;
+            }
+        }
+        __syncthreads();
+        if (tid < nc) {
+            const double sc = cand_s[tid];
+            const int id = cand_i[tid];
+            int rank = 0;
+            for (int b = 0; b < nc; ++b) rank += (cand_s[b] > sc || (cand_s[b] == sc && cand_i[b] < id)) ? 1 : 0;
+            if (rank < k) {
+                out_idx[(int64_t)qi * k + rank] = (int64_t)id;
+                out_score[(int64_t)qi * k + rank] = (float)sc;
+            }
+        }
+        for (int a = nc + tid; a < k; a += 256) {               // a corpus smaller than k: pad (as the tiled path does)
+            out_idx[(int64_t)qi * k + a] = (int64_t)-1;
+            out_score[(int64_t)qi * k + a] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 extern "C" int64_t devqa_cosine_topk_workspace(int N, int Q, int k) {
@@ -595,8 +818,8 @@ extern "C" int64_t devqa_cosine_topk_workspace(int N, int Q, int k) {
     return align256((int64_t)Q * (N + 64) * 4) + align256((int64_t)N * 4) + align256((int64_t)Q * 4) + ids;
 }
 
-extern "C" int devqa_cosine_topk(const float* corpus, const float* queries, int N, int Q, int D, int k, int normalize_corpus,
-                                 int normalize_queries, int64_t* out_idx, float* out_score, void* workspace, void* stream) {
+static int cosine_topk_impl(const float* corpus, const float* corpus_inv_norm, const float* queries, int N, int Q, int D, int k,
+                            int normalize_corpus, int normalize_queries, int64_t* out_idx, float* out_score, void* workspace, void* stream) {
     DEVQA_CHECK_ARG(corpus && queries && out_idx && out_score && workspace, "cosine_topk: null pointer");
     if (Q == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(N > 0 && Q > 0 && D > 0 && D % 4 == 0 && D <= 4096, "cosine_topk: bad dims N=%d Q=%d D=%d", N, Q, D);
@@ -612,6 +835,22 @@ extern "C" int devqa_cosine_topk(const float* corpus, const float* queries, int 
         static const int fewq = getenv("DEVQA_COSINE_FEWQ") ? atoi(getenv("DEVQA_COSINE_FEWQ")) : 1;
         const int nc = min(k + CT_MARGIN, N);
         const int n_lists = (N + 63) / 64;                                  // one sorted candidate list of <= 64 entries per wave
+        if (fewq == 1 && Q <= 4 && N <= 256 * 80) {      // ONE launch: scores + last-workgroup selection (cosine_fused_kernel)
+            static std::atomic<unsigned> ticket{0};
+            unsigned* counter = nullptr;
+            if (hipGetSymbolAddress((void**)&counter, HIP_SYMBOL(g_ct_counter)) != hipSuccess)
+                return devqa_fail(DEVQA_E_HIP, "cosine_topk: counter symbol");
+            counter += ticket.fetch_add(1) % CT_COUNTERS;        // calls in flight on different streams do not share a counter
+            const dim3 grid((N + 31) / 32);
+            auto kern = cosine_fused_kernel<4>;
+            static std::atomic<unsigned> attr{0};
+            devqa_set_max_smem(kern, 96 * 1024, attr);          // dynamic LDS: the keys of one query, 4 N bytes (N <= 20480)
+            hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)N * 4, st, corpus, normalize_corpus ? corpus_inv_norm : nullptr, queries, N, Q, D,
+                               normalize_corpus, normalize_queries, k, nc, scores, counter, out_idx, out_score);
+            devqa_prof_end(ph, 4.0 * (double)N * D, st);
+            DEVQA_LAUNCH_CHECK("cosine_fused");
+            return DEVQA_OK;
+        }
         if (fewq && Q <= 4) {
             float* ls = scores;                                             // [Q][n_lists][64] scores, then ids: inside the Q * N floats
             int* li = (int*)(ws + align256((int64_t)Q * (N + 64) * 4));     // ids: behind the (padded) score region
@@ -625,7 +864,9 @@ extern "C" int devqa_cosine_topk(const float* corpus, const float* queries, int 
             return DEVQA_OK;
         }
     }
-    if (normalize_corpus) {
+    if (normalize_corpus && corpus_inv_norm) {
+        inv_c = const_cast<float*>(corpus_inv_norm);        // the caller's cache (computed once at load, as the reference normalises once)
+    } else if (normalize_corpus) {
         hipLaunchKernelGGL(row_inv_norm_kernel, dim3((N + 3) / 4), dim3(256), 0, st, corpus, N, D, inv_c);
         DEVQA_LAUNCH_CHECK("row_inv_norm(corpus)");
     }
@@ -647,5 +888,26 @@ extern "C" int devqa_cosine_topk(const float* corpus, const float* queries, int 
                            normalize_queries, out_idx, out_score);
     devqa_prof_end(ph, 4.0 * (double)N * D, st);
     DEVQA_LAUNCH_CHECK("topk_select");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_cosine_topk(const float* corpus, const float* queries, int N, int Q, int D, int k, int normalize_corpus,
+                                 int normalize_queries, int64_t* out_idx, float* out_score, void* workspace, void* stream) {
+    return cosine_topk_impl(corpus, nullptr, queries, N, Q, D, k, normalize_corpus, normalize_queries, out_idx, out_score, workspace, stream);
+}
+
+// The same search with the corpus' inverse row norms supplied by the caller (devqa_row_inv_norm, computed ONCE when the corpus is loaded --
+// the reference normalises its stored embeddings once at load, R/dataset/vllm.py:104,117): the per-call pass over the corpus then
+// accumulates dot products only.  corpus_inv_norm == NULL is devqa_cosine_topk(normalize_corpus = 1).
+extern "C" int devqa_cosine_topk_cached(const float* corpus, const float* corpus_inv_norm, const float* queries, int N, int Q, int D, int k,
+                                        int normalize_queries, int64_t* out_idx, float* out_score, void* workspace, void* stream) {
+    return cosine_topk_impl(corpus, corpus_inv_norm, queries, N, Q, D, k, 1, normalize_queries, out_idx, out_score, workspace, stream);
+}
+
+extern "C" int devqa_row_inv_norm(const float* rows, int R, int D, float* out, void* stream) {
+    DEVQA_CHECK_ARG(rows && out, "row_inv_norm: null pointer");
+    DEVQA_CHECK_SHAPE(R > 0 && D > 0 && D % 4 == 0, "row_inv_norm: bad dims R=%d D=%d", R, D);
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, R, D, out);
+    DEVQA_LAUNCH_CHECK("row_inv_norm");
     return DEVQA_OK;
 }

@@ -42,12 +42,15 @@ class EmbeddingRetriever:
         self.save_image_path = images
         self.device = device
         self.stored = torch.as_tensor(np.asarray(embeddings, np.float32)).to(device).contiguous()
+        # the corpus side of the cosine is normalised ONCE, at load (vllm.py:104,117: util.normalize_embeddings on the stored tensor)
+        from .. import lib
+        self.stored_inv_norm = lib.row_inv_norm(self.stored) if self.stored.is_cuda and self.stored.shape[0] else None
 
     def topk(self, queries: np.ndarray, tops=5):
         import torch
         from .. import lib
         q = torch.as_tensor(np.asarray(queries, np.float32)).to(self.device).contiguous()
-        idx, _ = lib.cosine_topk(self.stored, q, tops, True, True)
+        idx, _ = lib.cosine_topk(self.stored, q, tops, True, True, corpus_inv_norm=self.stored_inv_norm)
         return idx.cpu().numpy()
 
     def finds_sim_many(self, srcs: List[str], trgs: List[str], tops=5):

@@ -61,6 +61,8 @@ class IKEvl(VLLMBaseEditor):
         self.encode = encode
         self.stored_sentences = corpus["sentences"]
         self.stored = torch.as_tensor(np.asarray(corpus["embeddings"], np.float32)).to(self.device).contiguous()
+        # ike_main.py:185-194 normalises the stored embeddings once, when the corpus is loaded: the inverse norms are cached here
+        self.stored_inv_norm = lib.row_inv_norm(self.stored) if self.stored.shape[0] else None
         self._orig_embeds = None
         self.icl_examples: List[str] = []
         self.facts: List[Tuple[str, str]] = []
@@ -77,7 +79,7 @@ class IKEvl(VLLMBaseEditor):
         query = ike_sentence(new_fact, new_fact)                       # ike_main.py:196-198
         q = torch.as_tensor(np.asarray(self.encode([query]), np.float32)).to(self.device).contiguous()
         k = min(self.cfg.k, self.stored.shape[0])
-        idx, _ = lib.cosine_topk(self.stored, q, k, True, True)        # normalize_embeddings + semantic_search(dot)
+        idx, _ = lib.cosine_topk(self.stored, q, k, True, True, corpus_inv_norm=self.stored_inv_norm)   # normalize_embeddings + semantic_search(dot)
         icl = [self.stored_sentences[int(i)] for i in idx[0].tolist()]
         icl.append(query)                                              # ike_main.py:205-206
         return icl

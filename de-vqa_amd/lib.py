@@ -81,6 +81,8 @@ def load():
     _sig(L.devqa_ft_step_control, [P, P, I, I, I, I, F, P, P, P, P, P, P])
     _sig(L.devqa_cosine_topk_workspace, [I, I, I], c_int64)
     _sig(L.devqa_cosine_topk, [P, P, I, I, I, I, I, I, P, P, P, P])
+    _sig(L.devqa_cosine_topk_cached, [P, P, P, I, I, I, I, I, P, P, P, P])
+    _sig(L.devqa_row_inv_norm, [P, I, I, P, P])
     for fn in (L.devqa_attention_bwd, L.devqa_attention_bwd_f32):
         _sig(fn, [P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, P])
     _sig(L.devqa_relu_bwd, [P, P, P, I64, P])
@@ -137,7 +139,7 @@ EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "dev
            "devqa_mend_transform", "devqa_mend_apply_workspace", "devqa_mend_apply", "devqa_llm_head_workspace", "devqa_llm_head", "devqa_llm_forward_workspace",
            "devqa_llm_forward", "devqa_ft_edit_workspace", "devqa_ft_edit", "devqa_ctx_bind_edit_target", "devqa_apply_delta", "devqa_restore",
            "devqa_token_acc", "devqa_comm_unique_id", "devqa_comm_create", "devqa_comm_destroy", "devqa_gather_scores",
-           "devqa_profile", "devqa_profile_read", "devqa_profile_dropped", "devqa_attention_reload_env", "devqa_act_cast", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
+           "devqa_profile", "devqa_profile_read", "devqa_profile_dropped", "devqa_attention_reload_env", "devqa_act_cast", "devqa_row_inv_norm", "devqa_cosine_topk_cached", "devqa_rmsnorm", "devqa_rmsnorm_bwd_dx", "devqa_rope_bf16", "devqa_rope_f32", "devqa_swiglu_bf16", "devqa_swiglu_f32",
            "devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
@@ -589,7 +591,15 @@ def ft_step_control(nll, mask, step, max_steps, floor, active, do_update, n_step
          "devqa_ft_step_control")
 
 
-def cosine_topk(corpus, queries, k, normalize_corpus=True, normalize_queries=True):
+def row_inv_norm(rows):
+    """fp32 [R] = 1 / ||rows[r]|| (0 for a zero row): the corpus-side cache of cosine_topk(corpus_inv_norm=...)"""
+    _need(rows, torch.float32, "row_inv_norm rows")
+    out = torch.empty((rows.shape[0],), dtype=torch.float32, device=rows.device)
+    _chk(load().devqa_row_inv_norm(_p(rows), rows.shape[0], rows.shape[1], _p(out), _stream()), "devqa_row_inv_norm")
+    return out
+
+
+def cosine_topk(corpus, queries, k, normalize_corpus=True, normalize_queries=True, corpus_inv_norm=None):
     _need(corpus, torch.float32, "cosine_topk corpus")
     _need(queries, torch.float32, "cosine_topk queries")
     N, D = corpus.shape
@@ -599,6 +609,12 @@ def cosine_topk(corpus, queries, k, normalize_corpus=True, normalize_queries=Tru
     off = (-ws.data_ptr()) % 256
     idx = torch.empty((Q, k), dtype=torch.int64, device=corpus.device)
     sc = torch.empty((Q, k), dtype=torch.float32, device=corpus.device)
+    if corpus_inv_norm is not None and normalize_corpus:
+        _need(corpus_inv_norm, torch.float32, "cosine_topk corpus_inv_norm")
+        assert corpus_inv_norm.numel() == N
+        _chk(load().devqa_cosine_topk_cached(_p(corpus), _p(corpus_inv_norm), _p(queries), N, Q, D, int(k), int(normalize_queries),
+                                             _p(idx), _p(sc), c_void_p(ws.data_ptr() + off), _stream()), "devqa_cosine_topk_cached")
+        return idx, sc
     _chk(load().devqa_cosine_topk(_p(corpus), _p(queries), N, Q, D, int(k), int(normalize_corpus), int(normalize_queries),
                                   _p(idx), _p(sc), c_void_p(ws.data_ptr() + off), _stream()), "devqa_cosine_topk")
     return idx, sc

@@ -371,6 +371,15 @@ int devqa_ft_step_control(const float* nll, const float* mask, int E, int Lmax, 
 int64_t devqa_cosine_topk_workspace(int N, int Q, int k);
 int devqa_cosine_topk(const float* corpus, const float* queries, int N, int Q, int D, int k, int normalize_corpus,
                       int normalize_queries, int64_t* out_idx, float* out_score, void* workspace, void* stream);
+/* The reference normalises its stored embeddings ONCE, when the corpus is loaded (R/dataset/vllm.py:104,117:
+ * util.normalize_embeddings), and every search is a dot product against them.  Same division of work here: devqa_row_inv_norm fills
+ * out[r] = 1 / ||rows[r]|| (0 for a zero row) once per corpus, devqa_cosine_topk_cached is devqa_cosine_topk(normalize_corpus = 1)
+ * reading those inverse norms instead of accumulating them again (corpus_inv_norm == NULL: accumulate, as devqa_cosine_topk).  The
+ * fp64 re-score of the k + 8 candidates recomputes their norms in fp64 either way, so the reported order and scores do not change.
+ * Q <= 4 and N <= 20480 run as ONE launch (scores, then selection by the last-arriving workgroup). */
+int devqa_row_inv_norm(const float* rows, int R, int D, float* out, void* stream);
+int devqa_cosine_topk_cached(const float* corpus, const float* corpus_inv_norm, const float* queries, int N, int Q, int D, int k,
+                             int normalize_queries, int64_t* out_idx, float* out_score, void* workspace, void* stream);
 
 /* =====================================================================================================================
  * PATH LEVEL (csrc/path_ctx.hip): a model context and the launch schedules of the hot path over the kernels above -- the

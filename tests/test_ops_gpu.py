@@ -403,6 +403,51 @@ def test_cosine_topk_exact_indices(L, N, Q, D, k):
     np.testing.assert_array_equal(idx2.cpu().numpy(), ridx2)
 
 
+@pytest.mark.parametrize("N,Q,k", [(15000, 1, 5), (15000, 1, 32), (15000, 3, 5), (20480, 4, 32), (19035, 2, 5), (300, 1, 32), (20, 2, 32), (33, 1, 1)])
+def test_cosine_topk_few_queries_one_launch(L, N, Q, k):
+    """The Q <= 4 path (finds_sim / IKE_VL / LTE_VL retrieval; ONE launch: scores + radix select + fp64 re-score by the last-arriving
+    workgroup): exact indices vs the float64 brute force, with MASSIVE ties (blocks of identical rows -> the lowest ids must win, more
+    equal keys than places), with the corpus' inverse norms cached (the product call sites) and without, twice in a row (the counter
+    the workgroups meet on must come back to zero), and against the many-query tiled path on the same inputs."""
+    from oracle import devqa_oracle as O
+    D = 384
+    rng = np.random.default_rng(N * 7 + Q + k)
+    c = rng.standard_normal((N, D)).astype(np.float32)
+    q = rng.standard_normal((Q, D)).astype(np.float32)
+    if N >= 300:
+        q[0] = c[123] * 2.5
+        for j in range(124, 124 + 60):          # 61 identical best rows for query 0: ties far beyond k + 8
+            c[j] = c[123]
+        c[N - 1] = c[5]                         # a far-apart duplicate pair
+    def pad(idx_, sc_=None):       # a corpus smaller than k: the product pads the id row with -1
+        n = idx_.shape[1]
+        if n == k:
+            return idx_, sc_
+        return (np.concatenate([idx_, np.full((idx_.shape[0], k - n), -1, np.int64)], 1),
+                None if sc_ is None else np.concatenate([sc_, np.full((idx_.shape[0], k - n), -np.inf)], 1))
+    ridx, rsc = pad(*O.cosine_topk(c, q, k))
+    ct, qt = dev(torch.from_numpy(c)), dev(torch.from_numpy(q))
+    inv = L.row_inv_norm(ct)
+    np.testing.assert_allclose(inv.cpu().numpy(), 1.0 / np.linalg.norm(c.astype(np.float64), axis=1), rtol=2e-6)
+    for cached in (None, inv, None, inv):
+        idx, sc = L.cosine_topk(ct, qt, k, True, True, corpus_inv_norm=cached)
+        torch.cuda.synchronize()
+        got, gsc = idx.cpu().numpy(), sc.cpu().numpy()
+        valid = ridx >= 0
+        np.testing.assert_array_equal(got, ridx)
+        np.testing.assert_allclose(gsc[valid], rsc[valid], atol=1e-6)
+    if N >= 300:
+        assert got[0, :min(k, 61)].tolist() == list(range(123, 123 + min(k, 61)))
+    # the tiled many-query path (Q > 4) on the same queries, repeated
+    q5 = np.concatenate([q, q, q, q, q])[:max(5, Q)]
+    idx5, _ = L.cosine_topk(ct, dev(torch.from_numpy(q5)), k, True, True)
+    np.testing.assert_array_equal(idx5.cpu().numpy()[:Q], ridx)
+    # raw dot product (no normalisation on either side)
+    ridx2, _ = pad(O.cosine_topk(c, q, k, False, False)[0])
+    idx2, _ = L.cosine_topk(ct, qt, k, False, False)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), ridx2)
+
+
 def test_column_compaction(L):
     g = torch.Generator().manual_seed(21)
     E, Lr, Din, Dout = 3, 2, 10240, 24
