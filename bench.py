@@ -48,7 +48,11 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cycles-per-step", type=int, default=127,
                     help="cycles per batch; 127 -> 508 images through the vision encoder in one call (130556 rows = 510 row tiles of 256)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="which leg is the headline `value`; the other leg is reported beside it (`strong` / `weak` object)")
+    ap.add_argument("--strong-cycles", type=int, default=1000, help="length of the edit stream of the strong-scaling leg (north_star: -sen 1000)")
+    ap.add_argument("--no-second-leg", action="store_true", help="skip the leg that is not the headline")
+    ap.add_argument("--dump-rows", type=str, default=None, help="rank 0 writes the gathered [n, 16] score rows of the strong leg here (.npy)")
     ap.add_argument("--ffn", choices=["sparse", "dense", "both"], default="both")
     ap.add_argument("--dense-steps", type=int, default=0, help="steps of the dense leg under --ffn both (default max(3, steps // 3))")
     ap.add_argument("--seed", type=int, default=20251121)
@@ -110,6 +114,22 @@ def spawn_ranks(n, argv):
         sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
         return 1
     return 0
+
+
+def split_batches(n, E):
+    """Sizes of the batches a rank cuts its block of n cycles into: at most E cycles each, and AT LEAST TWO batches whenever n > 1, so
+    that the software pipeline (stage A of batch i + 1 queued under stage B of batch i, batched.py) has something to overlap even when
+    a rank's whole block (1000 cycles / 8 ranks = 125) would fit one batch; sizes differ by at most one."""
+    if n <= 0:
+        return []
+    nb = max(-(-n // E), 2 if n > 1 else 1)
+    return [n // nb + (1 if i < n % nb else 0) for i in range(nb)]
+
+
+def build_threads(world):
+    """Host threads of the synthetic-weight generator: 8 ranks x 16 threads on a 64-core host would oversubscribe it 2x during the
+    (untimed) model build; share the cores between the ranks of this node."""
+    return max(2, min(16, (os.cpu_count() or 16) // max(world, 1)))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -363,7 +383,8 @@ class Leg:
         from devqa_amd.synth import IdTokenizer, evqa_cycles, synth_image_u8
         self.args, self.rank, self.world, self.dev = args, rank, world, dev
         t0 = time.time()
-        self.model, self.cfg, self.host_arrays = build_full_model(dev, args.seed, layers, keep_host_copy=keep_host_copy, style=style)
+        self.model, self.cfg, self.host_arrays = build_full_model(dev, args.seed, layers, threads=build_threads(world),
+                                                                  keep_host_copy=keep_host_copy, style=style)
         vllm = BLIP2OPTForEdit(None, dev, model=self.model, tokenizer=IdTokenizer())
         ft_cfg = FTvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "ft_vl", "blip2-opt-2.7b.yaml"))
         ft_cfg.layers = [self.cfg["text_config"]["num_hidden_layers"] - 1]
@@ -376,12 +397,13 @@ class Leg:
         self._evqa_cycles, self._synth_image_u8 = evqa_cycles, synth_image_u8
         self._img_cache = {}
 
-    def make_batches(self, K, W):
+    def make_batches(self, K, W, scaling=None, total=None):
         """-> (warm-up batches, timed batches, global id of this rank's first timed cycle, cycles of the timed region on this rank).
-        weak: every rank draws its own (W + K) * E cycles.  strong: ONE stream of K * E cycles (the same on every rank), rank r takes
-        its contiguous block and cuts it into batches of E."""
+        weak: every rank draws its own (W + K) * E cycles.  strong: ONE stream of `total` cycles (the same on every rank), rank r takes
+        its contiguous block and cuts it into >= 2 batches of <= E cycles (split_batches)."""
         import torch
         a, E = self.args, self.args.cycles_per_step
+        scaling = scaling or a.scaling
         proc, size, vocab = self.vllm.image_processor, self.cfg["vision_config"]["image_size"], self.cfg["text_config"]["vocab_size"]
 
         def image_of_factory(offset):
@@ -391,12 +413,12 @@ class Leg:
                     self._img_cache[key] = torch.from_numpy(proc(self._synth_image_u8(offset + s, tag, size, a.seed))).to(self.dev)
                 return self._img_cache[key]
             return image_of
-        if a.scaling == "weak":
+        if scaling == "weak":
             n = (K + W) * E
             cyc = self._evqa_cycles(n, vocab, a.seed + 7919 * self.rank, image_of_factory(self.rank * n))
             warm, timed, first = cyc[:W * E], cyc[W * E:], self.rank * K * E
         else:
-            total = K * E
+            total = total or K * E
             lo, hi = self.shard_range(total, self.rank, self.world)
             stream = self._evqa_cycles(total, vocab, a.seed, None)       # ids only: images are materialised for this rank's block
             warm_src = self._evqa_cycles(W * E, vocab, a.seed + 104729 * (self.rank + 1), image_of_factory(10 ** 7 + self.rank * W * E))
@@ -410,10 +432,15 @@ class Leg:
             timed = [with_images(s, stream[s]) for s in range(lo, hi)]
             warm, first = warm_src, lo
 
-        def cut(cs):
-            return [([self.copy_sample(c) for c in cs[i:i + E]], cs[i:i + E]) for i in range(0, len(cs), E)]
+        def cut(cs, sizes=None):
+            sizes = sizes or [min(E, len(cs) - i) for i in range(0, len(cs), E)]
+            out, i = [], 0
+            for n_ in sizes:
+                out.append(([self.copy_sample(c) for c in cs[i:i + n_]], cs[i:i + n_]))
+                i += n_
+            return out
         torch.cuda.synchronize()
-        return cut(warm), cut(timed), first, timed
+        return cut(warm), cut(timed, split_batches(len(timed), E) if scaling == "strong" else None), first, timed
 
     def sample_cycles(self, n):
         """n cycles of this leg's workload (device pixel tensors), for the cpu_baseline leg."""
@@ -442,15 +469,23 @@ class Leg:
         torch.cuda.empty_cache()
 
 
-def timed_leg(leg, K, W, barrier, use_dist, rank, world, dev):
-    """W untimed warm-up steps, then the K-step timed region bracketed by barrier + synchronize; max over ranks."""
+def comm_device(dev):
+    """device of the small tensors the collectives move: the GPU under RCCL, the host under gloo (CPU rehearsals of N > 1)"""
+    import torch
+    import torch.distributed as dist
+    return torch.device("cpu") if (dist.is_initialized() and dist.get_backend() == "gloo") else torch.device(dev)
+
+
+def timed_leg(leg, K, W, barrier, use_dist, rank, world, dev, scaling=None, total=None):
+    """W untimed warm-up steps, then the timed region (K steps of E cycles per rank, or this rank's block of the `total`-cycle stream)
+    bracketed by barrier + synchronize; max over ranks.  -> (elapsed, n_local, n_total, ranks, gathered score rows on rank 0)"""
     import torch
     import torch.distributed as dist
     from devqa_amd import lib
     from devqa_amd.batched import BatchedEditEval
     from devqa_amd.dist import gather_score_rows
     a = leg.args
-    warm, timed, first, _ = leg.make_batches(K, W)
+    warm, timed, first, _ = leg.make_batches(K, W, scaling, total)
     if warm:
         leg.run(warm, not a.no_pipeline)
     leg.reset_stats()
@@ -463,19 +498,23 @@ def timed_leg(leg, K, W, barrier, use_dist, rank, world, dev):
     lib.profile(0)
     n_local = len(outs)
     n_total, ranks = n_local, 1
+    got = BatchedEditEval.score_rows(outs, metas, first)
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = comm_device(dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        nt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        nt = torch.tensor([n_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(nt)
         n_total = int(nt.item())
-        rows = BatchedEditEval.score_rows(outs, metas, first)
-        got = gather_score_rows(rows, n_total, rank, world, torch.device(dev))     # the single RCCL collective of the data path
+        if (scaling or a.scaling) == "weak":        # equal blocks: the gather's partition rule is shard_range(n_total)
+            assert n_total == n_local * world
+        got = gather_score_rows(got, n_total, rank, world, cdev)     # the single collective of the data path (RCCL on the GPU)
         ranks = dist.get_world_size()
         if rank == 0:
             assert got.shape == (n_total, 16) and [int(v) for v in got[:, 0]] == list(range(n_total))
-    return elapsed, n_local, n_total, ranks
+    leg.last_batch_sizes = [len(b[1]) for b in timed]
+    return elapsed, n_local, n_total, ranks, got
 
 
 def gemm_roofline(K_E_local, elapsed):
@@ -555,13 +594,22 @@ def selftest_cpu(args):
     E, K = args.cycles_per_step, args.steps
     if args.scaling == "weak":
         first, n_local = rank * K * E, K * E
+        sizes = [E] * K
     else:
-        lo, hi = shard_range(K * E, rank, world)
+        lo, hi = shard_range(args.strong_cycles, rank, world)
         first, n_local = lo, hi - lo
+        sizes = split_batches(n_local, E)          # the same cut the GPU path makes (Leg.make_batches)
+    assert sum(sizes) == n_local and (n_local <= 1 or args.scaling == "weak" or len(sizes) >= 2)
     dist.barrier()
     t0 = time.time()
     rows = np.zeros((n_local, 16), np.float32)
-    rows[:, 0] = np.arange(first, first + n_local)
+    i = 0
+    for n_ in sizes:                               # fake cycles: every score is a fixed function of the GLOBAL cycle id
+        ids = np.arange(first + i, first + i + n_)
+        rows[i:i + n_, 0] = ids
+        for c in range(1, 16):
+            rows[i:i + n_, c] = ((ids * 2654435761 + c * 40503) % 1000) / 1000.0
+        i += n_
     time.sleep(0.01 * K)
     dist.barrier()
     tt = torch.tensor([time.time() - t0], dtype=torch.float64)
@@ -569,6 +617,8 @@ def selftest_cpu(args):
     nt = torch.tensor([n_local], dtype=torch.int64)
     dist.all_reduce(nt)
     got = gather_score_rows(rows, int(nt.item()), rank, world, torch.device("cpu"))
+    if rank == 0 and args.dump_rows:
+        np.save(args.dump_rows, got)
     if rank == 0:
         assert [int(v) for v in got[:, 0]] == list(range(int(nt.item())))
         print(json.dumps({"metric": "selftest (not a benchmark)", "value": round(int(nt.item()) / float(tt.item()), 3), "unit": "cycles/s",
@@ -597,9 +647,14 @@ def main():
     from devqa_amd.dist import init_from_env
 
     # DEVQA_FORCE_DIST=1: build the process group (RCCL) even for one rank, so that a 1-GPU box walks the N > 1 branches below
-    rank, world = init_from_env(min_world=1 if os.environ.get("DEVQA_FORCE_DIST") else 2)
+    # DEVQA_DIST_BACKEND=gloo + DEVQA_BENCH_SHARE_GPU=1: an N-rank REHEARSAL on fewer GPUs than ranks (collectives over gloo on the host,
+    # ranks share the visible devices round-robin; RCCL refuses two ranks on one device) -- walks sharding, sub-batching, both legs and
+    # the gather with real cycles on a one-GPU box; not a measurement
+    rank, world = init_from_env(backend=os.environ.get("DEVQA_DIST_BACKEND"), min_world=1 if os.environ.get("DEVQA_FORCE_DIST") else 2)
     use_dist = dist.is_initialized()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DEVQA_BENCH_SHARE_GPU"):
+        local_rank %= max(torch.cuda.device_count(), 1)
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(dev)
     lib.load()
@@ -616,7 +671,9 @@ def main():
     want_parity = want_cpu and not args.no_parity and layers is None
     n_cmp = max(1, args.cpu_cycles)
     leg = Leg(args, rank, world, dev, head_style, layers, keep_host_copy=want_cpu)
-    elapsed, n_local, n_total, ranks = timed_leg(leg, K, W, barrier, use_dist, rank, world, dev)
+    head_total = args.strong_cycles if args.scaling == "strong" else None
+    elapsed, n_local, n_total, ranks, head_rows = timed_leg(leg, K, W, barrier, use_dist, rank, world, dev, args.scaling, head_total)
+    head_batches = list(leg.last_batch_sizes)
     out = None
     if rank == 0:
         value = n_total / elapsed
@@ -638,7 +695,7 @@ def main():
                                    "weights/activations, fp32 master + AdamW state for the edited fc2 matrix, early stop enabled; "
                                    "FFN recipe: %s" % (n_total if args.scaling == "strong" else K * E,
                                                        "in total, block-partitioned over the ranks" if args.scaling == "strong" else "per GPU",
-                                                       E, DENSE_RECIPE if head_style == "survey" else SPARSE_RECIPE),
+                                                       max(head_batches) if head_batches else E, DENSE_RECIPE if head_style == "survey" else SPARSE_RECIPE),
                        "ffn": "dense" if head_style == "survey" else "sparse", "cycles_per_step": E, "cycles_total": n_total,
                        "mean_ft_steps": round(steps_mean, 2), "ft_active_columns_mean": ft["npad_mean"], "ft_columns": d_in,
                        "layers": "39/12/32" if layers is None else args.layers, "sharding": "splits block-partitioned, 1 gather"},
@@ -650,6 +707,23 @@ def main():
         }
         if head_style == "survey":
             out["value_survey_recipe"] = out["value"]
+    # ---- the other scaling leg on the same model: both are printed at every N ------------------------------------------------------
+    strong_rows = head_rows if args.scaling == "strong" else None
+    if not args.no_second_leg:
+        other = "strong" if args.scaling == "weak" else "weak"
+        o_el, o_local, o_total, _, o_rows = timed_leg(leg, K, 1, barrier, use_dist, rank, world, dev, other,
+                                                      args.strong_cycles if other == "strong" else None)
+        if other == "strong":
+            strong_rows = o_rows
+        if rank == 0:
+            out[other] = {"scaling": other, "value": round(o_total / o_el, 3), "unit": "cycles/s", "cycles_total": o_total,
+                          "elapsed_s": round(o_el, 3), "batches_rank0": list(leg.last_batch_sizes),
+                          "note": ("north_star's edit stream: %d cycles block-partitioned over the ranks, every rank cutting its block into >= 2 "
+                                   "batches so that the two pipeline stages overlap" % o_total) if other == "strong"
+                                  else "every rank runs %d steps of %d cycles" % (K, E)}
+    if rank == 0 and args.dump_rows and strong_rows is not None:
+        import numpy as np
+        np.save(args.dump_rows, strong_rows)
     # the cycles the CPU leg will run (and the batch around them for the parity capture): the head of this rank's own stream
     cycles_for_cpu = leg.sample_cycles(E if want_parity else n_cmp) if want_cpu and rank == 0 else None
     caps = {}
@@ -668,7 +742,7 @@ def main():
         Kd = args.dense_steps or max(3, K // 3)
         torch.cuda.empty_cache()        # the 22 GB of per-edit AdamW state of this leg should not fight cached blocks of the legs before
         dleg = Leg(args, rank, world, dev, "survey", layers, keep_host_copy=want_parity)
-        d_elapsed, d_local, d_total, _ = timed_leg(dleg, Kd, 2, barrier, use_dist, rank, world, dev)
+        d_elapsed, d_local, d_total, _, _ = timed_leg(dleg, Kd, 2, barrier, use_dist, rank, world, dev, "weak")
         if rank == 0:
             _, _, dft = side_kernels(dleg.be, d_elapsed)
             out["dense_ffn"] = {"value": round(d_total / d_elapsed, 3), "unit": "cycles/s", "steps": Kd, "warmup": 2,

@@ -134,11 +134,31 @@ def test_bench_gpus_n_spawns_n_ranks_world2():
     rc, j, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--cycles-per-step", "5"])
     assert rc == 0, err[-1500:]
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["scaling"] == "weak" and j["config"]["cycles_total"] == 30 and j["steps"] == 3
-    rc, j, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "0", "--cycles-per-step", "5", "--scaling", "strong"])
+    rc, j, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "0", "--cycles-per-step", "5", "--scaling", "strong", "--strong-cycles", "15"])
     assert rc == 0, err[-1500:]
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["cycles_total"] == 15
     rc, j, err = _run_bench(["--gpus", "1", "--steps", "2", "--cycles-per-step", "4"])
     assert rc == 0 and j["n_gpus"] == 1 and j["config"]["cycles_total"] == 8
+
+
+def test_bench_strong_stream_is_rank_count_invariant(tmp_path):
+    """`bench.py --gpus 2 --scaling strong` end to end (launcher, gloo group, block partition, every rank's block cut into >= 2
+    sub-batches, the single gather): rank-order concatenation of the gathered score rows == the rows of the 1-rank run of the same
+    stream, bit for bit -- also for a stream length that does not divide by the rank count or the batch size."""
+    import numpy as np
+    from bench import split_batches
+    assert split_batches(125, 127) == [63, 62] and split_batches(1000, 127) == [125] * 8 and split_batches(1, 127) == [1]
+    assert split_batches(0, 127) == [] and sum(split_batches(255, 127)) == 255 and max(split_batches(255, 127)) <= 127
+    for total in (1000, 37):
+        dumps = []
+        for n in (1, 2, 3):
+            f = str(tmp_path / ("rows_%d_%d.npy" % (total, n)))
+            rc, j, err = _run_bench(["--gpus", str(n), "--steps", "1", "--warmup", "0", "--cycles-per-step", "127", "--scaling", "strong",
+                                     "--strong-cycles", str(total), "--dump-rows", f])
+            assert rc == 0 and j["config"]["cycles_total"] == total and j["n_gpus"] == n, err[-1500:]
+            dumps.append(np.load(f))
+        assert dumps[0].shape == (total, 16) and [int(v) for v in dumps[0][:, 0]] == list(range(total))
+        assert dumps[0].tobytes() == dumps[1].tobytes() == dumps[2].tobytes()
 
 
 def test_bench_launcher_failure_modes():
