@@ -588,16 +588,27 @@ __global__ __launch_bounds__(256) void merge_final_kernel(const float* __restric
 
 
 // ---- few queries (Q <= 4: finds_sim, IKE_VL, LTE_VL retrieval), ONE launch -------------------------------------------------------
-// Phase A: every workgroup scores 32 corpus rows (a wave: 8 rows with all their loads in flight) for all Q queries, fp32, the corpus
-// norm either from the caller's cache (corpus_inv_norm) or accumulated in the same pass, and publishes the scores.
-// Phase B: the workgroup whose arrival on a counter came LAST selects per query the k + 8 best fp32 scores -- an exact radix select
-// on the order-preserving integer image of the scores (4 passes of 8 bits over register-resident keys, ties to the lowest ids) --
-// re-scores those candidates in fp64 and emits them by (score desc, id asc): the same contract as the tiled path.
+// Phase A: every workgroup (16 waves) scores 128 corpus rows (a wave: 8 rows with all their loads in flight) for all Q queries, fp32,
+// the corpus norm either from the caller's cache (corpus_inv_norm) or accumulated in the same pass, and publishes the scores.
+// Phase B: the workgroup whose arrival on a counter came LAST selects per query the nc = k + 8 best fp32 scores, re-scores those
+// candidates in fp64 and emits them by (score desc, id asc): the same contract as the tiled path.  Selection on the order-preserving
+// integer image of the scores, <= 20 keys per thread in registers:
+//   * the nc-th largest of the 64 group maxima (a group = the keys of 16 lanes) is a LOWER BOUND T0 of the nc-th largest key: at least
+//     nc keys (those maxima) reach it, so {key >= T0} contains the nc best; it is typically 1.1-2.5 nc keys;
+//   * if that set fits the candidate buffer (256) it is ranked by (key desc, id asc) and the first nc are kept;
+//   * else (thousands of equal scores: degenerate corpora) the exact nc-th key is found by bisection over the 32 key bits with
+//     workgroup-wide counts, and the ties at that key are admitted by ascending id (bisection over the id).
+// (A 256-bin LDS histogram radix select was measured first: the top byte of a cosine score takes 2-4 values, so its 15000 LDS
+// atomics serialise on a handful of addresses -- 55-70 us per query.)
 // Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility: hand-offs measured with sc1 accesses in place of release / acquire,
 // first row): the scores are written with agent-scope (sc1) stores, every storing wave drains them (s_waitcnt vmcnt(0)), the
 // workgroup's barrier, ONE lane's agent-scope atomic add on ONE counter; the workgroup whose add returned the last ticket reads the
 // scores with agent-scope (sc1) loads only, after a barrier behind that add.  The last workgroup resets the counter for the next call.
 #define CT_COUNTERS 64
+#define CT_FB 1024            // threads of a cosine_fused workgroup
+#define CT_FW (CT_FB / 64)
+#define CT_NPT 20             // keys per thread in phase B: N <= 20480
+#define CT_CCAP 256           // candidate buffer of the fast selection
 __device__ unsigned g_ct_counter[CT_COUNTERS];
 
 __device__ __forceinline__ unsigned ct_key(float f) {       // larger float <-> larger unsigned; -0 < +0 is harmless (fp64 re-score decides)
@@ -605,16 +616,28 @@ __device__ __forceinline__ unsigned ct_key(float f) {       // larger float <-> 
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// workgroup-wide sum of a per-thread count (two barriers; every thread gets the total)
+__device__ __forceinline__ int ct_block_sum(int c, ct_wr_storage& wst, int* s_part, int lane, int wave) {
+    int cs;
+    ct_wr_i().reduce(c, cs, wst.i, rocprim::plus<int>());
+    __syncthreads();
+    if (lane == 0) s_part[wave] = cs;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < CT_FW; ++w) tot += s_part[w];
+    return tot;
+}
+
 template <int QMAX>
-__global__ __launch_bounds__(256) void cosine_fused_kernel(const float* __restrict__ corpus, const float* __restrict__ inv_cached,
-                                                           const float* __restrict__ queries, int N, int Q, int D, int norm_c, int norm_q,
-                                                           int k, int nc, float* scores, unsigned* counter,
-                                                           int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
-    extern __shared__ unsigned lkeys[];                    // phase B: the N keys of one query (dynamic LDS, 4 N bytes)
-    __shared__ ct_wr_storage wr_st[4];
-    __shared__ unsigned hist[256];
-    __shared__ unsigned s_prefix;
-    __shared__ int s_remaining, s_last, s_ngt, s_ntie, s_cnt[4];
+__global__ __launch_bounds__(CT_FB) void cosine_fused_kernel(const float* __restrict__ corpus, const float* __restrict__ inv_cached,
+                                                             const float* __restrict__ queries, int N, int Q, int D, int norm_c, int norm_q,
+                                                             int k, int nc, float* scores, unsigned* counter,
+                                                             int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    __shared__ ct_wr_storage wr_st[CT_FW];
+    __shared__ unsigned s_gmax[64], s_ckey[CT_CCAP];
+    __shared__ unsigned s_T;
+    __shared__ int s_last, s_n, s_part[CT_FW], s_cid[CT_CCAP];
     __shared__ int cand_i[CT_MAXK + CT_MARGIN];
     __shared__ double cand_s[CT_MAXK + CT_MARGIN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -622,7 +645,7 @@ __global__ __launch_bounds__(256) void cosine_fused_kernel(const float* __restri
     // ---------------- phase A ----------------
     {
         constexpr int RG = 8;
-        const int row0 = blockIdx.x * 32 + wave * RG;
+        const int row0 = blockIdx.x * (CT_FW * RG) + wave * RG;
         const int nrows = min(RG, N - row0);
         if (nrows > 0) {
             const int nv = D >> 2;
@@ -690,94 +713,108 @@ __global__ __launch_bounds__(256) void cosine_fused_kernel(const float* __restri
     }
     // ---------------- phase B: the last workgroup ----------------
     for (int qi = 0; qi < Q; ++qi) {
-        for (int id = tid; id < N; id += 256)
-            lkeys[id] = ct_key(__hip_atomic_load(scores + (int64_t)qi * N + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        unsigned prefix = 0u, mask = 0u;
-        int remaining = nc;                                     // nc <= N
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            hist[tid] = 0u;
-            __syncthreads();                                    // (pass 0: also publishes lkeys)
-            for (int id = tid; id < N; id += 256) {
-                const unsigned key = lkeys[id];
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        unsigned keys[CT_NPT];
+        unsigned mx = 0u;
+#pragma unroll
+        for (int j = 0; j < CT_NPT; ++j) {
+            const int id = j * CT_FB + tid;
+            keys[j] = id < N ? ct_key(__hip_atomic_load(scores + (int64_t)qi * N + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
+            mx = max(mx, keys[j]);
+        }
+        // 64 group maxima (16 lanes each) -> T0 = the nc-th largest of them (nc <= 40 <= 64)
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+        if ((lane & 15) == 0) s_gmax[wave * 4 + (lane >> 4)] = mx;
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned g = s_gmax[tid];
+            int rank = 0;
+            for (int j = 0; j < 64; ++j) {
+                const unsigned o = s_gmax[j];
+                rank += (o > g || (o == g && j < tid)) ? 1 : 0;
             }
-            __syncthreads();
-            if (wave == 0) {                                    // lane l owns bins 4l .. 4l + 3; suffix sums over the lanes above
-                unsigned h[4];
+            if (rank == nc - 1) s_T = g;
+        }
+        __syncthreads();
+        const unsigned T0 = s_T;
+        int c = 0;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) h[t] = hist[4 * lane + t];
-                const unsigned s = (h[0] + h[1]) + (h[2] + h[3]);
-                unsigned x = s;
+        for (int j = 0; j < CT_NPT; ++j) c += keys[j] >= T0 ? 1 : 0;        // (empty slots hold key 0: counted only if T0 == 0)
+        const int C = ct_block_sum(c, wst, s_part, lane, wave);
+        if (C <= CT_CCAP && T0 != 0u) {
+            // fast path: the candidate set fits; rank it by (key desc, id asc), keep the first nc
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const unsigned y = __shfl_down(x, off, 64);
-                    if (lane + off < 64) x += y;
+            for (int j = 0; j < CT_NPT; ++j)
+                if (keys[j] >= T0) {
+                    const int p = atomicAdd(&s_n, 1);
+                    s_ckey[p] = keys[j];
+                    s_cid[p] = j * CT_FB + tid;
                 }
-                unsigned gt = x - s;                            // keys in bins above this lane's
+            __syncthreads();
+            if (tid < C) {
+                const unsigned key = s_ckey[tid];
+                const int id = s_cid[tid];
+                int rank = 0;
+                for (int j = 0; j < C; ++j) rank += (s_ckey[j] > key || (s_ckey[j] == key && s_cid[j] < id)) ? 1 : 0;
+                if (rank < nc) cand_i[rank] = id;
+            }
+        } else {
+            // exact path: the nc-th largest key by bisection over its bits, ties at it by ascending id
+            unsigned T = 0u;
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned cand = T | (1u << bit);
+                int cc = 0;
 #pragma unroll
-                for (int t = 3; t >= 0; --t) {
-                    if ((int)gt < remaining && remaining <= (int)(gt + h[t])) {
-                        s_prefix = prefix | ((unsigned)(4 * lane + t) << shift);
-                        s_remaining = remaining - (int)gt;
+                for (int j = 0; j < CT_NPT; ++j) cc += (j * CT_FB + tid < N && keys[j] >= cand) ? 1 : 0;
+                if (ct_block_sum(cc, wst, s_part, lane, wave) >= nc) T = cand;      // largest T with count(key >= T) >= nc
+            }
+            int cg = 0, ce = 0;
+#pragma unroll
+            for (int j = 0; j < CT_NPT; ++j) {
+                const bool ok = j * CT_FB + tid < N;
+                cg += (ok && keys[j] > T) ? 1 : 0;
+                ce += (ok && keys[j] == T) ? 1 : 0;
+            }
+            const int n_gt = ct_block_sum(cg, wst, s_part, lane, wave);
+            const int n_eq = ct_block_sum(ce, wst, s_part, lane, wave);
+            const int need = nc - n_gt;                                            // 1 <= need <= n_eq
+            int id_cap = N - 1;
+            if (n_eq > need) {
+                int lo = 0, hi = N - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    int cc = 0;
+#pragma unroll
+                    for (int j = 0; j < CT_NPT; ++j) {
+                        const int id = j * CT_FB + tid;
+                        cc += (id < N && id <= mid && keys[j] == T) ? 1 : 0;
                     }
-                    gt += h[t];
+                    if (ct_block_sum(cc, wst, s_part, lane, wave) >= need) hi = mid; else lo = mid + 1;
                 }
+                id_cap = lo;
             }
-            __syncthreads();
-            prefix = s_prefix;
-            remaining = s_remaining;
-            mask |= 0xffu << shift;
-        }
-        // prefix = the nc-th largest key; every key above it is a candidate, `remaining` of the keys equal to it (lowest ids first)
-        if (tid == 0) { s_ngt = 0; s_ntie = 0; }
-        __syncthreads();
-        int my_ties = 0;
-        for (int id = tid; id < N; id += 256) {
-            const unsigned key = lkeys[id];
-            if (key > prefix) cand_i[atomicAdd(&s_ngt, 1)] = id;
-            else if (key == prefix) ++my_ties;
-        }
-        if (my_ties) atomicAdd(&s_ntie, my_ties);
-        __syncthreads();
-        int id_cap = N - 1;                                     // ties with id <= id_cap are taken
-        if (s_ntie > remaining) {                               // more equal keys than places: the `remaining` lowest ids (rare)
-            int lo = 0, hi = N - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                int c = 0;
-                for (int id = tid; id <= mid; id += 256) c += lkeys[id] == prefix ? 1 : 0;
-                int cs;
-                ct_wr_i().reduce(c, cs, wst.i, rocprim::plus<int>());
-                __syncthreads();
-                if (lane == 0) s_cnt[wave] = cs;
-                __syncthreads();
-                const int tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
-                if (tot >= remaining) hi = mid; else lo = mid + 1;
+#pragma unroll
+            for (int j = 0; j < CT_NPT; ++j) {
+                const int id = j * CT_FB + tid;
+                if (id < N && (keys[j] > T || (keys[j] == T && id <= id_cap))) cand_i[atomicAdd(&s_n, 1)] = id;
             }
-            id_cap = lo;
         }
-        const int base = s_ngt;
-        __syncthreads();
-        if (tid == 0) s_ntie = 0;
-        __syncthreads();
-        for (int id = tid; id <= id_cap; id += 256)
-            if (lkeys[id] == prefix) cand_i[base + atomicAdd(&s_ntie, 1)] = id;
         __syncthreads();
         // fp64 re-score of the nc candidates, rank by (score desc, id asc), emit the first k
         const float* qv = queries + (int64_t)qi * D;
         double qn = 0.0;
         if (norm_q) {
-            for (int c = lane; c < D; c += 64) qn += (double)qv[c] * (double)qv[c];
+            for (int cc = lane; cc < D; cc += 64) qn += (double)qv[cc] * (double)qv[cc];
             qn = wave_sum_d(qn);
         }
-        for (int p = wave; p < nc; p += 4) {
+        for (int p = wave; p < nc; p += CT_FW) {
             const int ci = cand_i[p];
             const float* cv = corpus + (int64_t)ci * D;
             double dot = 0.0, cn = 0.0;
-            for (int c = lane; c < D; c += 64) {
-                const double xx = (double)cv[c];
-                dot += xx * (double)qv[c];
+            for (int cc = lane; cc < D; cc += 64) {
+                const double xx = (double)cv[cc];
+                dot += xx * (double)qv[cc];
                 cn += xx * xx;
             }
             dot = wave_sum_d(dot);
@@ -800,7 +837,7 @@ __global__ __launch_bounds__(256) void cosine_fused_kernel(const float* __restri
                 out_score[(int64_t)qi * k + rank] = (float)sc;
             }
         }
-        for (int a = nc + tid; a < k; a += 256) {               // a corpus smaller than k: pad (as the tiled path does)
+        for (int a = nc + tid; a < k; a += CT_FB) {             // a corpus smaller than k: pad (as the tiled path does)
             out_idx[(int64_t)qi * k + a] = (int64_t)-1;
             out_score[(int64_t)qi * k + a] = -INFINITY;
         }
@@ -835,18 +872,23 @@ static int cosine_topk_impl(const float* corpus, const float* corpus_inv_norm, c
         static const int fewq = getenv("DEVQA_COSINE_FEWQ") ? atoi(getenv("DEVQA_COSINE_FEWQ")) : 1;
         const int nc = min(k + CT_MARGIN, N);
         const int n_lists = (N + 63) / 64;                                  // one sorted candidate list of <= 64 entries per wave
-        if (fewq == 1 && Q <= 4 && N <= 256 * 80) {      // ONE launch: scores + last-workgroup selection (cosine_fused_kernel)
+        if (fewq == 1 && Q <= 4 && N <= CT_FB * CT_NPT) {      // ONE launch: scores + last-workgroup selection (cosine_fused_kernel)
             static std::atomic<unsigned> ticket{0};
             unsigned* counter = nullptr;
             if (hipGetSymbolAddress((void**)&counter, HIP_SYMBOL(g_ct_counter)) != hipSuccess)
                 return devqa_fail(DEVQA_E_HIP, "cosine_topk: counter symbol");
             counter += ticket.fetch_add(1) % CT_COUNTERS;        // calls in flight on different streams do not share a counter
-            const dim3 grid((N + 31) / 32);
-            auto kern = cosine_fused_kernel<4>;
-            static std::atomic<unsigned> attr{0};
-            devqa_set_max_smem(kern, 96 * 1024, attr);          // dynamic LDS: the keys of one query, 4 N bytes (N <= 20480)
-            hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)N * 4, st, corpus, normalize_corpus ? corpus_inv_norm : nullptr, queries, N, Q, D,
-                               normalize_corpus, normalize_queries, k, nc, scores, counter, out_idx, out_score);
+            const dim3 grid((N + CT_FW * 8 - 1) / (CT_FW * 8));
+            const float* inv = normalize_corpus ? corpus_inv_norm : nullptr;
+            if (Q == 1)
+                hipLaunchKernelGGL(cosine_fused_kernel<1>, grid, dim3(CT_FB), 0, st, corpus, inv, queries, N, Q, D, normalize_corpus, normalize_queries,
+                                   k, nc, scores, counter, out_idx, out_score);
+            else if (Q == 2)
+                hipLaunchKernelGGL(cosine_fused_kernel<2>, grid, dim3(CT_FB), 0, st, corpus, inv, queries, N, Q, D, normalize_corpus, normalize_queries,
+                                   k, nc, scores, counter, out_idx, out_score);
+            else
+                hipLaunchKernelGGL(cosine_fused_kernel<4>, grid, dim3(CT_FB), 0, st, corpus, inv, queries, N, Q, D, normalize_corpus, normalize_queries,
+                                   k, nc, scores, counter, out_idx, out_score);
             devqa_prof_end(ph, 4.0 * (double)N * D, st);
             DEVQA_LAUNCH_CHECK("cosine_fused");
             return DEVQA_OK;

@@ -31,7 +31,19 @@ def main():
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / n
-        out.append({"N": N, "Q": Q, "D": D, "k": k, "ms_per_batch": round(ms, 4), "queries_per_s": round(Q / ms * 1e3),
+        # GPU time of the call alone (HIP events around the launches, the library's slot profiler), raw and with the corpus' inverse
+        # norms cached as the product call sites do -- the back-to-back figure above includes the host's per-call work
+        gpu_us = {}
+        inv = lib.row_inv_norm(corpus)
+        for name, kw in (("gpu_us", {}), ("gpu_us_cached_norms", {"corpus_inv_norm": inv})):
+            torch.cuda.synchronize()
+            lib.profile(1)
+            for _ in range(n):
+                lib.cosine_topk(corpus, q, k, True, True, **kw)
+            lib.profile(0)
+            pms, _, pn = lib.profile_read(lib.PROF_COSINE)
+            gpu_us[name] = round(1e3 * pms / max(pn, 1), 1)
+        out.append({"N": N, "Q": Q, "D": D, "k": k, **gpu_us, "ms_per_batch": round(ms, 4), "queries_per_s": round(Q / ms * 1e3),
                     "algorithmic_GBps": round(N * D * 4 / ms / 1e6, 1), "frac_of_8TBps": round(N * D * 4 / ms / 1e6 / 8000, 4),
                     "gflops": round(2.0 * N * D * Q / ms / 1e6, 1)})
     print(json.dumps(out, indent=1))
