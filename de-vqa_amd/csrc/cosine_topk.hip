@@ -588,12 +588,12 @@ __global__ __launch_bounds__(256) void merge_final_kernel(const float* __restric
 
 
 // ---- few queries (Q <= 4: finds_sim, IKE_VL, LTE_VL retrieval), ONE launch -------------------------------------------------------
-// Phase A: every workgroup (16 waves) scores 128 corpus rows (a wave: 8 rows with all their loads in flight) for all Q queries, fp32,
+// Phase A: every workgroup (8 waves) scores 64 corpus rows (a wave: 8 rows with all their loads in flight) for all Q queries, fp32,
 // the corpus norm either from the caller's cache (corpus_inv_norm) or accumulated in the same pass, and publishes the scores.
 // Phase B: the workgroup whose arrival on a counter came LAST selects per query the nc = k + 8 best fp32 scores, re-scores those
 // candidates in fp64 and emits them by (score desc, id asc): the same contract as the tiled path.  Selection on the order-preserving
-// integer image of the scores, <= 20 keys per thread in registers:
-//   * the nc-th largest of the 64 group maxima (a group = the keys of 16 lanes) is a LOWER BOUND T0 of the nc-th largest key: at least
+// integer image of the scores, held in LDS:
+//   * the nc-th largest of the 64 group maxima (a group = the keys of 8 lanes) is a LOWER BOUND T0 of the nc-th largest key: at least
 //     nc keys (those maxima) reach it, so {key >= T0} contains the nc best; it is typically 1.1-2.5 nc keys;
 //   * if that set fits the candidate buffer (256) it is ranked by (key desc, id asc) and the first nc are kept;
 //   * else (thousands of equal scores: degenerate corpora) the exact nc-th key is found by bisection over the 32 key bits with
@@ -605,11 +605,16 @@ __global__ __launch_bounds__(256) void merge_final_kernel(const float* __restric
 // workgroup's barrier, ONE lane's agent-scope atomic add on ONE counter; the workgroup whose add returned the last ticket reads the
 // scores with agent-scope (sc1) loads only, after a barrier behind that add.  The last workgroup resets the counter for the next call.
 #define CT_COUNTERS 64
-#define CT_FB 1024            // threads of a cosine_fused workgroup
+#define CT_FB 512             // threads of a cosine_fused workgroup (8 waves: 256 VGPRs per lane, no spills; 1024 threads spilled)
 #define CT_FW (CT_FB / 64)
-#define CT_NPT 20             // keys per thread in phase B: N <= 20480
+#define CT_NPT 40             // keys per thread in phase B: N <= 20480 (10 x 16-byte loads)
 #define CT_CCAP 256           // candidate buffer of the fast selection
 __device__ unsigned g_ct_counter[CT_COUNTERS];
+#ifdef CT_TIMING      /* tools/debug/cosine_phase_timing.sh: wall-clock stamps of the last workgroup's thread 0 (debug builds only) */
+#define CT_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(scores + (((int64_t)Q * (N + 4) + 63) / 64 + 1) * 64)[i] = wall_clock64(); } while (0)
+#else
+#define CT_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned ct_key(float f) {       // larger float <-> larger unsigned; -0 < +0 is harmless (fp64 re-score decides)
     const unsigned u = __float_as_uint(f);
@@ -634,15 +639,19 @@ __global__ __launch_bounds__(CT_FB) void cosine_fused_kernel(const float* __rest
                                                              const float* __restrict__ queries, int N, int Q, int D, int norm_c, int norm_q,
                                                              int k, int nc, float* scores, unsigned* counter,
                                                              int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    extern __shared__ unsigned lkeys[];                    // phase B: the keys of one query (dynamic LDS, 4 * roundup(N, 4) bytes)
     __shared__ ct_wr_storage wr_st[CT_FW];
-    __shared__ unsigned s_gmax[64], s_ckey[CT_CCAP];
+    __shared__ unsigned s_gmax[64];
+    __shared__ unsigned long long s_c64[CT_CCAP + 4];
     __shared__ unsigned s_T;
-    __shared__ int s_last, s_n, s_part[CT_FW], s_cid[CT_CCAP];
+    __shared__ int s_last, s_n, s_part[CT_FW];
     __shared__ int cand_i[CT_MAXK + CT_MARGIN];
     __shared__ double cand_s[CT_MAXK + CT_MARGIN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     ct_wr_storage& wst = wr_st[wave];
+    const int Np = (N + 3) & ~3;           // row stride of the score buffer: 16-byte aligned rows for phase B's loads
     // ---------------- phase A ----------------
+    CT_STAMP(0);
     {
         constexpr int RG = 8;
         const int row0 = blockIdx.x * (CT_FW * RG) + wave * RG;
@@ -657,22 +666,34 @@ __global__ __launch_bounds__(CT_FB) void cosine_fused_kernel(const float* __rest
                 for (int q = 0; q < QMAX; ++q) acc[g][q] = 0.f;
             }
             const bool need_norm = norm_c && inv_cached == nullptr;
-            for (int c = lane; c < nv; c += 64) {
-                float4 v[RG];
+            constexpr int CH = 1;                       // 16-byte pieces per row and lane in flight
+            for (int c0 = lane; c0 < nv; c0 += 64 * CH) {
+                float4 v[RG][CH];
 #pragma unroll
                 for (int g = 0; g < RG; ++g)
-                    v[g] = reinterpret_cast<const float4*>(corpus + (int64_t)(row0 + min(g, nrows - 1)) * D)[c];
-                float4 u[QMAX];
+#pragma unroll
+                    for (int h = 0; h < CH; ++h)
+                        v[g][h] = c0 + 64 * h < nv ? reinterpret_cast<const float4*>(corpus + (int64_t)(row0 + min(g, nrows - 1)) * D)[c0 + 64 * h]
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 u[QMAX][CH];
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q)
-                    u[q] = q < Q ? reinterpret_cast<const float4*>(queries + (int64_t)q * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int g = 0; g < RG; ++g) {
-                    if (need_norm) nrm[g] += (v[g].x * v[g].x + v[g].y * v[g].y) + (v[g].z * v[g].z + v[g].w * v[g].w);
+                    for (int h = 0; h < CH; ++h)
+                        u[q][h] = (q < Q && c0 + 64 * h < nv) ? reinterpret_cast<const float4*>(queries + (int64_t)q * D)[c0 + 64 * h]
+                                                               : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int q = 0; q < QMAX; ++q)
-                        acc[g][q] += (v[g].x * u[q].x + v[g].y * u[q].y) + (v[g].z * u[q].z + v[g].w * u[q].w);
-                }
+                for (int g = 0; g < RG; ++g)
+#pragma unroll
+                    for (int h = 0; h < CH; ++h) {
+                        const float4 x = v[g][h];
+                        // explicit fma chains: every row goes through the SAME instruction sequence whatever slot g it sits in, so identical
+                        // rows get identical fp32 scores (ties are then broken by id, as the contract says)
+                        if (need_norm) nrm[g] = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, nrm[g]))));
+#pragma unroll
+                        for (int q = 0; q < QMAX; ++q)
+                            acc[g][q] = fmaf(x.x, u[q][h].x, fmaf(x.y, u[q][h].y, fmaf(x.z, u[q][h].z, fmaf(x.w, u[q][h].w, acc[g][q]))));
+                    }
             }
             float mine[QMAX];
 #pragma unroll
@@ -698,11 +719,12 @@ __global__ __launch_bounds__(CT_FB) void cosine_fused_kernel(const float* __rest
             if (lane < nrows) {
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q)
-                    if (q < Q) __hip_atomic_store(scores + (int64_t)q * N + row0 + lane, mine[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (q < Q) __hip_atomic_store(scores + (int64_t)q * Np + row0 + lane, mine[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores ...
         __syncthreads();                                        // ... before the ONE lane that signals for the workgroup
+        CT_STAMP(1);
         if (tid == 0) {
             const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (t == gridDim.x - 1) ? 1 : 0;
@@ -711,70 +733,97 @@ __global__ __launch_bounds__(CT_FB) void cosine_fused_kernel(const float* __rest
         __syncthreads();                                        // every wave of the last workgroup loads behind the add's return
         if (!s_last) return;
     }
+    CT_STAMP(2);
     // ---------------- phase B: the last workgroup ----------------
     for (int qi = 0; qi < Q; ++qi) {
-        unsigned keys[CT_NPT];
+        // keys -> LDS: 10 x 16-byte agent-scope (sc1) loads per thread, all in flight (thread t, piece j: ids 4 (512 j + t) .. + 3); every
+        // later step walks the LDS copy in ROLLED loops -- this code runs once per launch on one workgroup, straight from a cold
+        // instruction cache: a fully unrolled register-resident version of it measured slower
         unsigned mx = 0u;
+        {
+            const float* srow = scores + (int64_t)qi * Np;
+            const float* pp[10];
 #pragma unroll
-        for (int j = 0; j < CT_NPT; ++j) {
-            const int id = j * CT_FB + tid;
-            keys[j] = id < N ? ct_key(__hip_atomic_load(scores + (int64_t)qi * N + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
-            mx = max(mx, keys[j]);
+            for (int j = 0; j < 10; ++j) pp[j] = srow + 4 * min(j * CT_FB + tid, (Np >> 2) - 1);
+            float4_t r0, r1, r2, r3, r4, r5, r6, r7, r8, r9;
+            asm volatile("global_load_dwordx4 %0, %10, off sc1\n\tglobal_load_dwordx4 %1, %11, off sc1\n\tglobal_load_dwordx4 %2, %12, off sc1\n\t"
+                         "global_load_dwordx4 %3, %13, off sc1\n\tglobal_load_dwordx4 %4, %14, off sc1\n\tglobal_load_dwordx4 %5, %15, off sc1\n\t"
+                         "global_load_dwordx4 %6, %16, off sc1\n\tglobal_load_dwordx4 %7, %17, off sc1\n\tglobal_load_dwordx4 %8, %18, off sc1\n\t"
+                         "global_load_dwordx4 %9, %19, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9)
+                         : "v"(pp[0]), "v"(pp[1]), "v"(pp[2]), "v"(pp[3]), "v"(pp[4]), "v"(pp[5]), "v"(pp[6]), "v"(pp[7]), "v"(pp[8]), "v"(pp[9])
+                         : "memory");
+            const float4_t rr[10] = {r0, r1, r2, r3, r4, r5, r6, r7, r8, r9};
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int i4 = j * CT_FB + tid;
+                if (4 * i4 < Np) {
+                    uint4 kv;
+                    kv.x = 4 * i4 + 0 < N ? ct_key(rr[j][0]) : 0u;
+                    kv.y = 4 * i4 + 1 < N ? ct_key(rr[j][1]) : 0u;
+                    kv.z = 4 * i4 + 2 < N ? ct_key(rr[j][2]) : 0u;
+                    kv.w = 4 * i4 + 3 < N ? ct_key(rr[j][3]) : 0u;
+                    reinterpret_cast<uint4*>(lkeys)[i4] = kv;
+                    mx = max(max(mx, max(kv.x, kv.y)), max(kv.z, kv.w));
+                }
+            }
         }
-        // 64 group maxima (16 lanes each) -> T0 = the nc-th largest of them (nc <= 40 <= 64)
+        CT_STAMP(3);
+        // 64 group maxima (8 waves x 8 groups of 8 lanes) -> T0 = the nc-th largest of them (nc <= 40 <= 64), found by wave 0 in registers
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
-        if ((lane & 15) == 0) s_gmax[wave * 4 + (lane >> 4)] = mx;
+        for (int off = 1; off < 8; off <<= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+        if ((lane & 7) == 0) s_gmax[wave * 8 + (lane >> 3)] = mx;
         if (tid == 0) s_n = 0;
-        __syncthreads();
-        if (tid < 64) {
-            const unsigned g = s_gmax[tid];
+        if (tid < CT_CCAP + 4) s_c64[tid] = 0ull;
+        __syncthreads();                                        // (also publishes lkeys)
+        if (wave == 0) {
+            const unsigned g = s_gmax[lane];
             int rank = 0;
             for (int j = 0; j < 64; ++j) {
                 const unsigned o = s_gmax[j];
-                rank += (o > g || (o == g && j < tid)) ? 1 : 0;
+                rank += (o > g || (o == g && j < lane)) ? 1 : 0;
             }
             if (rank == nc - 1) s_T = g;
         }
         __syncthreads();
         const unsigned T0 = s_T;
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < CT_NPT; ++j) c += keys[j] >= T0 ? 1 : 0;        // (empty slots hold key 0: counted only if T0 == 0)
-        const int C = ct_block_sum(c, wst, s_part, lane, wave);
-        if (C <= CT_CCAP && T0 != 0u) {
-            // fast path: the candidate set fits; rank it by (key desc, id asc), keep the first nc
-#pragma unroll
-            for (int j = 0; j < CT_NPT; ++j)
-                if (keys[j] >= T0) {
-                    const int p = atomicAdd(&s_n, 1);
-                    s_ckey[p] = keys[j];
-                    s_cid[p] = j * CT_FB + tid;
-                }
-            __syncthreads();
+        // candidates {key >= T0} straight into the buffer (a 64-bit image: key, then the complemented id, so that ONE comparison orders
+        // by key desc, id asc); the count decides afterwards whether the buffer held them all
+        for (int id = tid; id < N; id += CT_FB) {
+            const unsigned key = lkeys[id];
+            if (key >= T0) {
+                const int p = atomicAdd(&s_n, 1);
+                if (p < CT_CCAP) s_c64[p] = ((unsigned long long)key << 32) | (unsigned)(0x7fffffff - id);
+            }
+        }
+        __syncthreads();
+        const int C = s_n;
+        CT_STAMP(4);
+        if (C <= CT_CCAP) {
+            // fast path: rank the candidates, keep the first nc (entries past C are 0: never above a real one)
             if (tid < C) {
-                const unsigned key = s_ckey[tid];
-                const int id = s_cid[tid];
+                const unsigned long long mine = s_c64[tid];
                 int rank = 0;
-                for (int j = 0; j < C; ++j) rank += (s_ckey[j] > key || (s_ckey[j] == key && s_cid[j] < id)) ? 1 : 0;
-                if (rank < nc) cand_i[rank] = id;
+                for (int j = 0; j < C; j += 4)
+                    rank += (s_c64[j] > mine ? 1 : 0) + (s_c64[j + 1] > mine ? 1 : 0) + (s_c64[j + 2] > mine ? 1 : 0) + (s_c64[j + 3] > mine ? 1 : 0);
+                if (rank < nc) cand_i[rank] = 0x7fffffff - (int)(unsigned)(mine & 0xffffffffull);
             }
         } else {
             // exact path: the nc-th largest key by bisection over its bits, ties at it by ascending id
+            __syncthreads();
+            if (tid == 0) s_n = 0;
             unsigned T = 0u;
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned cand = T | (1u << bit);
                 int cc = 0;
-#pragma unroll
-                for (int j = 0; j < CT_NPT; ++j) cc += (j * CT_FB + tid < N && keys[j] >= cand) ? 1 : 0;
+                for (int id = tid; id < N; id += CT_FB) cc += lkeys[id] >= cand ? 1 : 0;
                 if (ct_block_sum(cc, wst, s_part, lane, wave) >= nc) T = cand;      // largest T with count(key >= T) >= nc
             }
             int cg = 0, ce = 0;
-#pragma unroll
-            for (int j = 0; j < CT_NPT; ++j) {
-                const bool ok = j * CT_FB + tid < N;
-                cg += (ok && keys[j] > T) ? 1 : 0;
-                ce += (ok && keys[j] == T) ? 1 : 0;
+            for (int id = tid; id < N; id += CT_FB) {
+                const unsigned key = lkeys[id];
+                cg += key > T ? 1 : 0;
+                ce += key == T ? 1 : 0;
             }
             const int n_gt = ct_block_sum(cg, wst, s_part, lane, wave);
             const int n_eq = ct_block_sum(ce, wst, s_part, lane, wave);
@@ -785,48 +834,70 @@ __global__ __launch_bounds__(CT_FB) void cosine_fused_kernel(const float* __rest
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     int cc = 0;
-#pragma unroll
-                    for (int j = 0; j < CT_NPT; ++j) {
-                        const int id = j * CT_FB + tid;
-                        cc += (id < N && id <= mid && keys[j] == T) ? 1 : 0;
-                    }
+                    for (int id = tid; id <= mid; id += CT_FB) cc += lkeys[id] == T ? 1 : 0;
                     if (ct_block_sum(cc, wst, s_part, lane, wave) >= need) hi = mid; else lo = mid + 1;
                 }
                 id_cap = lo;
             }
+            for (int id = tid; id < N; id += CT_FB) {
+                const unsigned key = lkeys[id];
+                if (key > T || (key == T && id <= id_cap)) cand_i[atomicAdd(&s_n, 1)] = id;
+            }
+        }
+        __syncthreads();
+        CT_STAMP(5);
+        // fp64 re-score of the nc candidates, rank by (score desc, id asc), emit the first k.  One wave per candidate; the row and the
+        // query come in 16-byte pieces, FOUR pieces per lane issued before the first use (a scalar loop over D was a chain of D / 64
+        // dependent memory round trips: ~5 us per candidate round)
+        const float4* qv4 = reinterpret_cast<const float4*>(queries + (int64_t)qi * D);
+        const int nv = D >> 2;
+        constexpr int PC = 3;                // candidates of a wave in flight (8 waves x 3 per round)
+        for (int p0 = wave; p0 < nc; p0 += CT_FW * PC) {
+            double dot[PC], cn[PC], qn = 0.0;
+            const float4* cv4[PC];
 #pragma unroll
-            for (int j = 0; j < CT_NPT; ++j) {
-                const int id = j * CT_FB + tid;
-                if (id < N && (keys[j] > T || (keys[j] == T && id <= id_cap))) cand_i[atomicAdd(&s_n, 1)] = id;
+            for (int u = 0; u < PC; ++u) {
+                dot[u] = 0.0;
+                cn[u] = 0.0;
+                cv4[u] = reinterpret_cast<const float4*>(corpus + (int64_t)cand_i[min(p0 + u * CT_FW, nc - 1)] * D);
             }
-        }
-        __syncthreads();
-        // fp64 re-score of the nc candidates, rank by (score desc, id asc), emit the first k
-        const float* qv = queries + (int64_t)qi * D;
-        double qn = 0.0;
-        if (norm_q) {
-            for (int cc = lane; cc < D; cc += 64) qn += (double)qv[cc] * (double)qv[cc];
+            for (int c0 = lane; c0 < nv; c0 += 128) {
+                float4 xv[PC][2], yv[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int cc = c0 + 64 * h;
+                    yv[h] = cc < nv ? qv4[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < PC; ++u) xv[u][h] = cc < nv ? cv4[u][cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double y0 = yv[h].x, y1 = yv[h].y, y2 = yv[h].z, y3 = yv[h].w;
+                    qn += (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3);
+#pragma unroll
+                    for (int u = 0; u < PC; ++u) {
+                        const double x0 = xv[u][h].x, x1 = xv[u][h].y, x2 = xv[u][h].z, x3 = xv[u][h].w;
+                        dot[u] += (x0 * y0 + x1 * y1) + (x2 * y2 + x3 * y3);
+                        cn[u] += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+                    }
+                }
+            }
             qn = wave_sum_d(qn);
-        }
-        for (int p = wave; p < nc; p += CT_FW) {
-            const int ci = cand_i[p];
-            const float* cv = corpus + (int64_t)ci * D;
-            double dot = 0.0, cn = 0.0;
-            for (int cc = lane; cc < D; cc += 64) {
-                const double xx = (double)cv[cc];
-                dot += xx * (double)qv[cc];
-                cn += xx * xx;
-            }
-            dot = wave_sum_d(dot);
-            cn = wave_sum_d(cn);
-            if (lane == 0) {
-                double sc = dot;
-                if (norm_c) sc = cn > 0.0 ? sc / sqrt(cn) : 0.0;
-                if (norm_q) sc = qn > 0.0 ? sc / sqrt(qn) : 0.0;
-                cand_s[p] = sc;
+#pragma unroll
+            for (int u = 0; u < PC; ++u) {
+                const int p = p0 + u * CT_FW;
+                if (p >= nc) break;
+                const double d_ = wave_sum_d(dot[u]), c_ = wave_sum_d(cn[u]);
+                if (lane == 0) {
+                    double sc = d_;
+                    if (norm_c) sc = c_ > 0.0 ? sc / sqrt(c_) : 0.0;
+                    if (norm_q) sc = qn > 0.0 ? sc / sqrt(qn) : 0.0;
+                    cand_s[p] = sc;
+                }
             }
         }
         __syncthreads();
+        CT_STAMP(6);
         if (tid < nc) {
             const double sc = cand_s[tid];
             const int id = cand_i[tid];
@@ -837,6 +908,7 @@ __global__ __launch_bounds__(CT_FB) void cosine_fused_kernel(const float* __rest
                 out_score[(int64_t)qi * k + rank] = (float)sc;
             }
         }
+        CT_STAMP(7);
         for (int a = nc + tid; a < k; a += CT_FB) {             // a corpus smaller than k: pad (as the tiled path does)
             out_idx[(int64_t)qi * k + a] = (int64_t)-1;
             out_score[(int64_t)qi * k + a] = -INFINITY;
@@ -880,15 +952,21 @@ static int cosine_topk_impl(const float* corpus, const float* corpus_inv_norm, c
             counter += ticket.fetch_add(1) % CT_COUNTERS;        // calls in flight on different streams do not share a counter
             const dim3 grid((N + CT_FW * 8 - 1) / (CT_FW * 8));
             const float* inv = normalize_corpus ? corpus_inv_norm : nullptr;
-            if (Q == 1)
-                hipLaunchKernelGGL(cosine_fused_kernel<1>, grid, dim3(CT_FB), 0, st, corpus, inv, queries, N, Q, D, normalize_corpus, normalize_queries,
+            const size_t lds = (size_t)((N + 3) & ~3) * 4;       // the keys of one query (<= 80 KiB)
+            static std::atomic<unsigned> a1{0}, a2{0}, a4{0};
+            if (Q == 1) {
+                devqa_set_max_smem(cosine_fused_kernel<1>, 96 * 1024, a1);
+                hipLaunchKernelGGL(cosine_fused_kernel<1>, grid, dim3(CT_FB), lds, st, corpus, inv, queries, N, Q, D, normalize_corpus, normalize_queries,
                                    k, nc, scores, counter, out_idx, out_score);
-            else if (Q == 2)
-                hipLaunchKernelGGL(cosine_fused_kernel<2>, grid, dim3(CT_FB), 0, st, corpus, inv, queries, N, Q, D, normalize_corpus, normalize_queries,
+            } else if (Q == 2) {
+                devqa_set_max_smem(cosine_fused_kernel<2>, 96 * 1024, a2);
+                hipLaunchKernelGGL(cosine_fused_kernel<2>, grid, dim3(CT_FB), lds, st, corpus, inv, queries, N, Q, D, normalize_corpus, normalize_queries,
                                    k, nc, scores, counter, out_idx, out_score);
-            else
-                hipLaunchKernelGGL(cosine_fused_kernel<4>, grid, dim3(CT_FB), 0, st, corpus, inv, queries, N, Q, D, normalize_corpus, normalize_queries,
+            } else {
+                devqa_set_max_smem(cosine_fused_kernel<4>, 96 * 1024, a4);
+                hipLaunchKernelGGL(cosine_fused_kernel<4>, grid, dim3(CT_FB), lds, st, corpus, inv, queries, N, Q, D, normalize_corpus, normalize_queries,
                                    k, nc, scores, counter, out_idx, out_score);
+            }
             devqa_prof_end(ph, 4.0 * (double)N * D, st);
             DEVQA_LAUNCH_CHECK("cosine_fused");
             return DEVQA_OK;
@@ -953,3 +1031,44 @@ extern "C" int devqa_row_inv_norm(const float* rows, int R, int D, float* out, v
     DEVQA_LAUNCH_CHECK("row_inv_norm");
     return DEVQA_OK;
 }
+
+#ifdef CT_TIMING
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCT_TIMING cosine_topk.hip -o build/ct_timing   (stand-alone phase timing of cosine_fused_kernel)
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+// stand-alone: the three library hooks this file uses (linking libdevqa_hip.so would interpose ITS copy of the kernels)
+int devqa_fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); return code; }
+int devqa_prof_begin(int, hipStream_t) { return -1; }
+void devqa_prof_end(int, double, hipStream_t) {}
+int main() {
+    const int N = 15000, D = 384;
+    std::vector<float> hc((size_t)N * D), hq(4 * D);
+    unsigned x = 12345u;
+    auto rnd = [&]() { x = x * 1664525u + 1013904223u; return ((x >> 8) & 0xffff) / 65536.f - 0.5f; };
+    for (auto& v : hc) v = rnd();
+    for (auto& v : hq) v = rnd();
+    float *dc, *dq, *dsc;
+    int64_t* di;
+    void* ws;
+    hipMalloc(&dc, hc.size() * 4); hipMalloc(&dq, hq.size() * 4); hipMalloc(&dsc, 4 * 32 * 4); hipMalloc(&di, 4 * 32 * 8);
+    hipMalloc(&ws, devqa_cosine_topk_workspace(N, 4, 32));
+    hipMemcpy(dc, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dq, hq.data(), hq.size() * 4, hipMemcpyHostToDevice);
+    for (int k : {5, 32}) {
+        for (int rep = 0; rep < 4; ++rep) {
+            const int rc = devqa_cosine_topk(dc, dq, N, 1, D, k, 1, 1, di, dsc, ws, nullptr);
+            const hipError_t e = hipDeviceSynchronize();
+            if (rc != 0 || e != hipSuccess) printf("rc %d hip %s\n", rc, hipGetErrorString(e));
+        }
+        unsigned long long st[16];
+        hipMemcpy(st, (float*)ws + (((int64_t)1 * (N + 4) + 63) / 64 + 1) * 64, sizeof(st), hipMemcpyDeviceToHost);
+        int64_t hi[4]; hipMemcpy(hi, di, sizeof(hi), hipMemcpyDeviceToHost);
+        printf("idx %ld %ld %ld  stamp0 %llu\n", (long)hi[0], (long)hi[1], (long)hi[2], st[0]);
+        printf("k=%d (100 MHz ticks -> us): phaseA %.2f  arrive->B %.2f  keys %.2f  T0+count %.2f  candidates %.2f  rescore %.2f  emit %.2f  (last block total %.2f)\n", k,
+               (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0, (st[4] - st[3]) / 100.0, (st[5] - st[4]) / 100.0,
+               (st[6] - st[5]) / 100.0, (st[7] - st[6]) / 100.0, (st[7] - st[0]) / 100.0);
+    }
+    return 0;
+}
+#endif
