@@ -299,10 +299,13 @@ def minigpt4_ike(n=4):
     ed = IKEvl(vllm, cfg, DEV, corpus, _hash_encode)
     build_s = time.time() - t0
     cps, dt, res = run_eval(ed, n, None, distinct_image_size=224)
-    # the in-context prefix (k = 32 retrieved demonstrations + the new fact) is part of every probe's input: the decoder term of
-    # A_min counts it once per cycle (shared by the 21 probes) on top of the image prefixes and probe texts
+    # the in-context prefix (k = 32 retrieved demonstrations + the new fact, `demo_rows` token rows) stands BEHIND the image rows of a probe
+    # ('<ImageHere>\n' + context + prompt, minigpt4.py:71-72 + ike_vl.with_context), so under causal attention its hidden states depend on
+    # the image: the deduplicated minimum holds it once per DISTINCT (image | no image) context of the 12 post-edit probes = 4 images + 1
+    # text-only = 5 copies (pre-edit probes carry no context)
     demo_rows = len(tok("".join(ed.retrieve("fact 1 is", "7")))["input_ids"])
-    a_min = a_min_tflop("minigpt4") + (32 * 2.0 * (4 * 4096 ** 2 + 3 * 4096 * 11008)) * demo_rows / 1e12
+    per_row = 32 * 2.0 * (4 * 4096 ** 2 + 3 * 4096 * 11008) + 32 * 4.0 * 4096 * (demo_rows / 2.0 + 32)
+    a_min = a_min_tflop("minigpt4") + 5 * demo_rows * per_row / 1e12
     return config_line("BASELINE config #5 (one GPU's shard): MiniGPT-4 (Vicuna-7B dims) + IKE_VL, cosine top-k k=%d over a 15000 x 384 corpus, "
                        "%d distinct synthetic cycles, bf16, generic evaluator with shared-prefix probe packing" % (cfg.k, n), n, dt,
                        run_eval.last_profile, a_min, {"build_s": round(build_s, 1), "icl_prefix_rows": demo_rows})
