@@ -125,6 +125,17 @@ int layernorm(const Ctx& c, const float* x, const float* add, const std::string&
     return devqa_layernorm(x, add, (const float*)g->ptr, (const float*)b->ptr, M, D, eps, nullptr, o, st);
 }
 
+inline bool llama_dec(const Ctx& c) { return c.d.family != DEVQA_FAMILY_BLIP2_OPT; }
+
+int rmsnorm(const Ctx& c, const float* x, const float* add, const std::string& wname, int M, int D, float eps, void* out_act, float* out_f32,
+            hipStream_t st) {
+    const Weight* g = nullptr;
+    RC(need(c, wname, &g, DEVQA_DTYPE_F32));
+    if (c.bf16) return devqa_rmsnorm(x, add, (const float*)g->ptr, M, D, eps, (devqa_bf16*)out_act, out_f32, st);
+    float* o = out_f32 ? out_f32 : (float*)out_act;
+    return devqa_rmsnorm(x, add, (const float*)g->ptr, M, D, eps, nullptr, o, st);
+}
+
 int attention(const Ctx& c, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo,
               const int32_t* desc, int n_seq, int max_q, int H, int dh, int causal, hipStream_t st) {
     const float scale = (float)pow((double)dh, -0.5);   // dh ** -0.5 evaluated in double, then rounded: what the Python host passes
@@ -165,11 +176,19 @@ unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 2
 // =================================================================================================================================
 extern "C" int devqa_ctx_create(int device, const devqa_model_desc* desc, const devqa_weight* table, int n_weights, devqa_ctx_t* out) {
     DEVQA_CHECK_ARG(desc && table && out && n_weights > 0, "ctx_create: null argument");
-    DEVQA_CHECK_ARG(desc->family == DEVQA_FAMILY_BLIP2_OPT, "ctx_create: unknown model family %d", desc->family);
+    DEVQA_CHECK_ARG(desc->family == DEVQA_FAMILY_BLIP2_OPT || desc->family == DEVQA_FAMILY_LLAVA || desc->family == DEVQA_FAMILY_MINIGPT4,
+                    "ctx_create: unknown model family %d", desc->family);
     DEVQA_CHECK_ARG(desc->compute_dtype == DEVQA_DTYPE_BF16 || desc->compute_dtype == DEVQA_DTYPE_F32, "ctx_create: bad compute dtype");
-    DEVQA_CHECK_SHAPE(desc->v_hidden % desc->v_heads == 0 && desc->q_hidden % desc->q_heads == 0 && desc->t_hidden % desc->t_heads == 0,
+    DEVQA_CHECK_SHAPE(desc->v_heads > 0 && desc->t_heads > 0 && desc->v_hidden % desc->v_heads == 0 && desc->t_hidden % desc->t_heads == 0,
                       "ctx_create: hidden sizes must be multiples of the head counts");
-    DEVQA_CHECK_SHAPE(desc->image_size % desc->patch_size == 0 && desc->q_cross_freq >= 1, "ctx_create: bad vision / Q-Former geometry");
+    DEVQA_CHECK_SHAPE(desc->patch_size > 0 && desc->image_size % desc->patch_size == 0, "ctx_create: bad vision geometry");
+    if (desc->family != DEVQA_FAMILY_LLAVA)     /* a Q-Former sits between the ViT and the decoder */
+        DEVQA_CHECK_SHAPE(desc->q_heads > 0 && desc->q_hidden % desc->q_heads == 0 && desc->q_cross_freq >= 1, "ctx_create: bad Q-Former geometry");
+    if (desc->family != DEVQA_FAMILY_BLIP2_OPT) /* LLaMA decoder */
+        DEVQA_CHECK_SHAPE(desc->t_rms_eps > 0.f && desc->t_rope_theta > 0.f && (desc->t_hidden / desc->t_heads) % 2 == 0,
+                          "ctx_create: the LLaMA decoder needs t_rms_eps, t_rope_theta and an even head size");
+    if (desc->family == DEVQA_FAMILY_LLAVA)
+        DEVQA_CHECK_SHAPE(desc->v_run_layers >= 1 && desc->v_run_layers <= desc->v_layers, "ctx_create: v_run_layers=%d", desc->v_run_layers);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return devqa_fail(DEVQA_E_ARG, "ctx_create: no device %d", device);
     Ctx* c = new (std::nothrow) Ctx();
@@ -272,10 +291,101 @@ int bert_attention(const Ctx& c, const std::string& p, float* h32_in, float* h32
 }
 }  // namespace
 
+// ---- LLaVA-1.5 (R/editor/vllms_for_edit/llava/llava.py:25-51): CLIP ViT hidden state of layer v_run_layers (HF hidden_states[-2]) without
+// the CLS row -> multi_modal_projector (Linear, GELU, Linear) -> [B, NP, t_hidden] ------------------------------------------------------
+namespace {
+struct ClipPlan {
+    void *cols, *h, *qkv, *att, *f, *g, *p1;
+    float *patches, *x0, *x, *rows;
+    int32_t *d_vit, *idx;
+};
+int64_t plan_clip(const Ctx& c, int B, Arena& a, ClipPlan& p) {
+    const auto& d = c.d;
+    const int G = d.image_size / d.patch_size, NP = G * G, N = NP + 1, D = d.v_hidden, F = d.v_ffn;
+    const int kpad = (3 * d.patch_size * d.patch_size + 63) / 64 * 64;
+    const int64_t e = esz(c), R = (int64_t)B * N, RP = (int64_t)B * NP;
+    p.cols = a.take(RP * kpad * e);
+    p.patches = (float*)a.take(RP * D * 4);
+    p.x0 = (float*)a.take(R * D * 4);
+    p.x = (float*)a.take(R * D * 4);
+    p.h = a.take(R * D * e);
+    p.qkv = a.take(R * 3 * D * e);
+    p.att = a.take(R * D * e);
+    p.f = a.take(R * F * e);
+    p.rows = (float*)a.take(RP * D * 4);
+    p.g = a.take(RP * D * e);
+    p.p1 = a.take(RP * d.t_hidden * e);
+    p.d_vit = (int32_t*)a.take((int64_t)B * 24);
+    p.idx = (int32_t*)a.take(RP * 4);
+    return al256(a.off);
+}
+__global__ void drop_cls_idx_kernel(int32_t* idx, int B, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * (N - 1)) return;
+    idx[i] = (i / (N - 1)) * N + 1 + i % (N - 1);
+}
+int clip_vision_encode(const Ctx& c, const float* pixel_values, int B, float* out_embeds, void* workspace, int64_t ws_bytes, hipStream_t st) {
+    const auto& d = c.d;
+    const int P = d.patch_size, G = d.image_size / P, NP = G * G, N = NP + 1, D = d.v_hidden, F = d.v_ffn, H = d.v_heads, dh = D / H;
+    const int R = B * N, RP = B * NP;
+    const int kpad = (3 * P * P + 63) / 64 * 64;
+    Arena a(workspace, ws_bytes);
+    ClipPlan w;
+    plan_clip(c, B, a, w);
+    if (a.overflow) return devqa_fail(DEVQA_E_SHAPE, "vision_encode: workspace of %lld bytes is too small (need %lld)", (long long)ws_bytes, (long long)al256(a.off));
+    const std::string pre = "vision_tower.vision_model.";
+    if (c.bf16) RC(devqa_im2col_patches(pixel_values, B, d.image_size, P, kpad, (devqa_bf16*)w.cols, st));
+    else RC(devqa_im2col_patches_f32(pixel_values, B, d.image_size, P, kpad, (float*)w.cols, st));
+    RC(gemm(c, w.cols, kpad, "derived.patch_w_gemm", nullptr, RP, D, kpad, 1.f, DEVQA_ACT_NONE, nullptr, nullptr, w.patches, st));     // CLIP: no conv bias
+    const Weight *cls = nullptr, *pos = nullptr;
+    RC(need(c, pre + "embeddings.class_embedding", &cls, DEVQA_DTYPE_F32));
+    RC(need(c, pre + "embeddings.position_embedding.weight", &pos, DEVQA_DTYPE_F32));
+    RC(devqa_vit_assemble(w.patches, (const float*)cls->ptr, (const float*)pos->ptr, B, NP, D, w.x0, st));
+    {
+        const bool keep = c.bf16;      // (the fp32 LayerNorm wrapper writes to out_f32 either way)
+        (void)keep;
+        const Weight *g = nullptr, *b = nullptr;
+        RC(need(c, pre + "pre_layrnorm.weight", &g, DEVQA_DTYPE_F32));
+        RC(need(c, pre + "pre_layrnorm.bias", &b, DEVQA_DTYPE_F32));
+        RC(devqa_layernorm(w.x0, nullptr, (const float*)g->ptr, (const float*)b->ptr, R, D, d.v_ln_eps, nullptr, w.x, st));
+    }
+    hipLaunchKernelGGL(full_desc_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.d_vit, B, N, N, 0);    // keys = a visible range (the own rows)
+    hipLaunchKernelGGL(drop_cls_idx_kernel, dim3((RP + 255) / 256), dim3(256), 0, st, w.idx, B, N);
+    DEVQA_LAUNCH_CHECK("clip descriptors");
+    char buf[200];
+    const int64_t e = esz(c);
+    for (int i = 0; i < d.v_run_layers; ++i) {
+        snprintf(buf, sizeof(buf), "%sencoder.layers.%d.", pre.c_str(), i);
+        const std::string p(buf);
+        snprintf(buf, sizeof(buf), "derived.clip_qkv.%d", i);
+        const std::string fq(buf);
+        RC(layernorm(c, w.x, nullptr, p + "layer_norm1", R, D, d.v_ln_eps, w.h, nullptr, st));
+        RC(gemm(c, w.h, D, fq + ".weight", (fq + ".bias").c_str(), R, 3 * D, D, 1.f, DEVQA_ACT_NONE, nullptr, w.qkv, nullptr, st));
+        const char* qkv = (const char*)w.qkv;
+        RC(attention(c, qkv, 3 * D, qkv + (int64_t)D * e, 3 * D, qkv + (int64_t)2 * D * e, 3 * D, w.att, D, w.d_vit, B, N, H, dh, 0, st));
+        RC(gemm(c, w.att, D, p + "self_attn.out_proj.weight", (p + "self_attn.out_proj.bias").c_str(), R, D, D, 1.f, DEVQA_ACT_NONE, w.x, nullptr, w.x, st));
+        RC(layernorm(c, w.x, nullptr, p + "layer_norm2", R, D, d.v_ln_eps, w.h, nullptr, st));
+        RC(gemm(c, w.h, D, p + "mlp.fc1.weight", (p + "mlp.fc1.bias").c_str(), R, F, D, 1.f, DEVQA_ACT_QUICK_GELU, nullptr, w.f, nullptr, st));
+        RC(gemm(c, w.f, F, p + "mlp.fc2.weight", (p + "mlp.fc2.bias").c_str(), R, D, F, 1.f, DEVQA_ACT_NONE, w.x, nullptr, w.x, st));
+    }
+    RC(devqa_gather_rows(w.x, w.idx, RP, D, 4, w.rows, st));
+    const void* g = nullptr;
+    RC(to_act(c, w.rows, w.g, (int64_t)RP * D, &g, st));
+    RC(gemm(c, g, D, "multi_modal_projector.linear_1.weight", "multi_modal_projector.linear_1.bias", RP, d.t_hidden, D, 1.f, DEVQA_ACT_GELU, nullptr, w.p1,
+            nullptr, st));
+    return gemm(c, w.p1, d.t_hidden, "multi_modal_projector.linear_2.weight", "multi_modal_projector.linear_2.bias", RP, d.t_hidden, d.t_hidden, 1.f,
+                DEVQA_ACT_NONE, nullptr, nullptr, out_embeds, st);
+}
+}  // namespace
+
 extern "C" int64_t devqa_vision_encode_workspace(devqa_ctx_t h, int B) {
     Ctx* c = ctx_of(h);
     if (!c || B <= 0) return -1;
     Arena a(nullptr, 0);
+    if (c->d.family == DEVQA_FAMILY_LLAVA) {
+        ClipPlan p;
+        return plan_clip(*c, B, a, p);
+    }
     VisionPlan p;
     return plan_vision(*c, B, a, p);
 }
@@ -288,6 +398,7 @@ extern "C" int devqa_vision_encode(devqa_ctx_t h, const float* pixel_values, int
     DEVQA_CHECK_SHAPE(B > 0, "vision_encode: B=%d", B);
     DEVQA_CHECK_ARG((((uintptr_t)workspace) & 255) == 0, "vision_encode: workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (c.d.family == DEVQA_FAMILY_LLAVA) return clip_vision_encode(c, pixel_values, B, out_embeds, workspace, ws_bytes, st);
     const auto& d = c.d;
     const int P = d.patch_size, G = d.image_size / P, NP = G * G, N = NP + 1, D = d.v_hidden, F = d.v_ffn, H = d.v_heads, dh = D / H;
     const int Q = d.num_query_tokens, dq = d.q_hidden, R = B * N, RQ = B * Q;
@@ -362,7 +473,7 @@ extern "C" int devqa_vision_encode(devqa_ctx_t h, const float* pixel_values, int
 // =================================================================================================================================
 namespace {
 struct LlmPlan {
-    void *h, *qkv, *att, *a;
+    void *h, *qkv, *att, *a, *gu;
 };
 int64_t plan_llm(const Ctx& c, int R, bool own_a, Arena& ar, LlmPlan& p) {
     const int64_t e = esz(c), d = c.d.t_hidden;
@@ -370,15 +481,50 @@ int64_t plan_llm(const Ctx& c, int R, bool own_a, Arena& ar, LlmPlan& p) {
     p.qkv = ar.take((int64_t)R * 3 * d * e);
     p.att = ar.take((int64_t)R * d * e);
     p.a = own_a ? ar.take((int64_t)R * c.d.t_ffn * e) : nullptr;
+    p.gu = llama_dec(c) ? ar.take((int64_t)R * 2 * c.d.t_ffn * e) : nullptr;     // fused [gate | up] projection output
     return al256(ar.off);
 }
-int llm_layers(const Ctx& c, float* x, const int32_t* desc, int n_seq, int max_len, int R, int dense, int n_layers, int stop_before_fc2,
-               void* a_out, LlmPlan& w, hipStream_t st) {
+// LLaMA / Vicuna decoder layers [first, first + n_layers) (HF LlamaDecoderLayer: RMSNorm, rotary q / k, causal attention, SwiGLU FFN; no
+// biases) in place on x; positions: int32 [R] rotary position of every row.  R/editor/vllms_for_edit/llava/llava.py:63-68,
+// .../minigpt4/minigpt4.py:63-68.
+int llama_layers(const Ctx& c, float* x, const int32_t* pos, const int32_t* desc, int n_seq, int max_len, int R, int dense, int first, int n_layers,
+                 int stop_before_fc2, void* a_out, LlmPlan& w, hipStream_t st) {
     const auto& d = c.d;
     const int D = d.t_hidden, H = d.t_heads, dh = D / H, F = d.t_ffn;
     const int64_t e = esz(c);
     char buf[160];
-    for (int i = 0; i < n_layers; ++i) {
+    for (int i = first; i < first + n_layers; ++i) {
+        snprintf(buf, sizeof(buf), "language_model.model.layers.%d.", i);
+        const std::string p(buf);
+        RC(rmsnorm(c, x, nullptr, p + "input_layernorm.weight", R, D, d.t_rms_eps, w.h, nullptr, st));
+        snprintf(buf, sizeof(buf), "derived.llama_qkv.%d.weight", i);
+        RC(gemm(c, w.h, D, buf, nullptr, R, 3 * D, D, 1.f, DEVQA_ACT_NONE, nullptr, w.qkv, nullptr, st));
+        if (c.bf16) RC(devqa_rope_bf16((devqa_bf16*)w.qkv, 3 * D, R, pos, 2 * H, dh, d.t_rope_theta, st));    // q heads then k heads
+        else RC(devqa_rope_f32((float*)w.qkv, 3 * D, R, pos, 2 * H, dh, d.t_rope_theta, st));
+        if (!dense && hipMemsetAsync(w.att, 0, (size_t)R * D * e, st) != hipSuccess) return devqa_fail(DEVQA_E_HIP, "llm_layers: memset failed");
+        const char* qkv = (const char*)w.qkv;
+        RC(attention(c, qkv, 3 * D, qkv + (int64_t)D * e, 3 * D, qkv + (int64_t)2 * D * e, 3 * D, w.att, D, desc, n_seq, max_len, H, dh, 1, st));
+        RC(gemm(c, w.att, D, p + "self_attn.o_proj.weight", nullptr, R, D, D, 1.f, DEVQA_ACT_NONE, x, nullptr, x, st));
+        RC(rmsnorm(c, x, nullptr, p + "post_attention_layernorm.weight", R, D, d.t_rms_eps, w.h, nullptr, st));
+        snprintf(buf, sizeof(buf), "derived.llama_gu.%d.weight", i);
+        RC(gemm(c, w.h, D, buf, nullptr, R, 2 * F, D, 1.f, DEVQA_ACT_NONE, nullptr, w.gu, nullptr, st));
+        const bool last_stop = stop_before_fc2 && i == first + n_layers - 1;
+        void* a = last_stop ? a_out : w.a;
+        if (c.bf16) RC(devqa_swiglu_bf16((const devqa_bf16*)w.gu, R, F, (devqa_bf16*)a, st));
+        else RC(devqa_swiglu_f32((const float*)w.gu, R, F, (float*)a, st));
+        if (last_stop) return DEVQA_OK;
+        RC(gemm(c, a, F, p + "mlp.down_proj.weight", nullptr, R, D, F, 1.f, DEVQA_ACT_NONE, x, nullptr, x, st));
+    }
+    return DEVQA_OK;
+}
+int llm_layers(const Ctx& c, float* x, const int32_t* pos, const int32_t* desc, int n_seq, int max_len, int R, int dense, int first, int n_layers,
+               int stop_before_fc2, void* a_out, LlmPlan& w, hipStream_t st) {
+    if (llama_dec(c)) return llama_layers(c, x, pos, desc, n_seq, max_len, R, dense, first, n_layers, stop_before_fc2, a_out, w, st);
+    const auto& d = c.d;
+    const int D = d.t_hidden, H = d.t_heads, dh = D / H, F = d.t_ffn;
+    const int64_t e = esz(c);
+    char buf[160];
+    for (int i = first; i < first + n_layers; ++i) {
         snprintf(buf, sizeof(buf), "language_model.model.decoder.layers.%d.", i);
         const std::string p(buf);
         RC(layernorm(c, x, nullptr, p + "self_attn_layer_norm", R, D, d.t_ln_eps, w.h, nullptr, st));
@@ -390,7 +536,7 @@ int llm_layers(const Ctx& c, float* x, const int32_t* desc, int n_seq, int max_l
         RC(attention(c, qkv, 3 * D, qkv + (int64_t)D * e, 3 * D, qkv + (int64_t)2 * D * e, 3 * D, w.att, D, desc, n_seq, max_len, H, dh, 1, st));
         RC(gemm(c, w.att, D, p + "self_attn.out_proj.weight", (p + "self_attn.out_proj.bias").c_str(), R, D, D, 1.f, DEVQA_ACT_NONE, x, nullptr, x, st));
         RC(layernorm(c, x, nullptr, p + "final_layer_norm", R, D, d.t_ln_eps, w.h, nullptr, st));
-        const bool last_stop = stop_before_fc2 && i == n_layers - 1;
+        const bool last_stop = stop_before_fc2 && i == first + n_layers - 1;
         void* a = last_stop ? a_out : w.a;
         RC(gemm(c, w.h, D, p + "fc1.weight", (p + "fc1.bias").c_str(), R, F, D, 1.f, DEVQA_ACT_RELU, nullptr, a, nullptr, st));
         if (last_stop) return DEVQA_OK;
@@ -399,6 +545,11 @@ int llm_layers(const Ctx& c, float* x, const int32_t* desc, int n_seq, int max_l
     return DEVQA_OK;
 }
 int llm_head(const Ctx& c, const float* rows, const float* add, int R, float* logits, void* h_ws, hipStream_t st) {
+    if (llama_dec(c)) {      // RMSNorm + the (untied) lm_head
+        RC(rmsnorm(c, rows, add, "language_model.model.norm.weight", R, c.d.t_hidden, c.d.t_rms_eps, h_ws, nullptr, st));
+        return gemm(c, h_ws, c.d.t_hidden, "language_model.lm_head.weight", nullptr, R, c.d.t_vocab, c.d.t_hidden, 1.f, DEVQA_ACT_NONE, nullptr, nullptr,
+                    logits, st);
+    }
     RC(layernorm(c, rows, add, "language_model.model.decoder.final_layer_norm", R, c.d.t_hidden, c.d.t_ln_eps, h_ws, nullptr, st));
     return gemm(c, h_ws, c.d.t_hidden, "language_model.model.decoder.embed_tokens.weight", nullptr, R, c.d.t_vocab, c.d.t_hidden, 1.f, DEVQA_ACT_NONE,
                 nullptr, nullptr, logits, st);
@@ -415,20 +566,27 @@ extern "C" int64_t devqa_llm_layers_workspace(devqa_ctx_t h, int R, int stop_bef
     return plan_llm(*c, R, true, a, p);
 }
 
-extern "C" int devqa_llm_layers(devqa_ctx_t h, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense, int n_layers,
-                                int stop_before_fc2, void* out_fc2_in, void* workspace, int64_t ws_bytes, void* stream) {
+extern "C" int devqa_llm_layers_ex(devqa_ctx_t h, float* x, const int32_t* positions, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense,
+                                   int first_layer, int n_layers, int stop_before_fc2, void* out_fc2_in, void* workspace, int64_t ws_bytes, void* stream) {
     CTX_OR_FAIL(h);
     DEVQA_CHECK_ARG(x && seq_desc && workspace, "llm_layers: null pointer");
     DEVQA_CHECK_ARG(!stop_before_fc2 || out_fc2_in, "llm_layers: stop_before_fc2 needs out_fc2_in");
+    DEVQA_CHECK_ARG(!llama_dec(c) || positions, "llm_layers: the LLaMA decoder needs the rotary positions of the rows (devqa_llm_layers_ex)");
     if (R == 0 || n_seq == 0) return DEVQA_OK;
-    if (n_layers < 0) n_layers = c.d.t_layers;
-    DEVQA_CHECK_SHAPE(R > 0 && n_seq > 0 && max_len > 0 && n_layers >= 1 && n_layers <= c.d.t_layers, "llm_layers: bad dims R=%d n_seq=%d layers=%d", R, n_seq, n_layers);
+    if (n_layers < 0) n_layers = c.d.t_layers - first_layer;
+    DEVQA_CHECK_SHAPE(R > 0 && n_seq > 0 && max_len > 0 && first_layer >= 0 && n_layers >= 1 && first_layer + n_layers <= c.d.t_layers,
+                      "llm_layers: bad dims R=%d n_seq=%d first=%d layers=%d", R, n_seq, first_layer, n_layers);
     DEVQA_CHECK_ARG((((uintptr_t)workspace) & 255) == 0, "llm_layers: workspace must be 256-byte aligned");
     Arena a(workspace, ws_bytes);
     LlmPlan w;
     plan_llm(c, R, true, a, w);
     if (a.overflow) return devqa_fail(DEVQA_E_SHAPE, "llm_layers: workspace of %lld bytes is too small (need %lld)", (long long)ws_bytes, (long long)al256(a.off));
-    return llm_layers(c, x, seq_desc, n_seq, max_len, R, dense, n_layers, stop_before_fc2, out_fc2_in, w, (hipStream_t)stream);
+    return llm_layers(c, x, positions, seq_desc, n_seq, max_len, R, dense, first_layer, n_layers, stop_before_fc2, out_fc2_in, w, (hipStream_t)stream);
+}
+
+extern "C" int devqa_llm_layers(devqa_ctx_t h, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense, int n_layers,
+                                int stop_before_fc2, void* out_fc2_in, void* workspace, int64_t ws_bytes, void* stream) {
+    return devqa_llm_layers_ex(h, x, nullptr, seq_desc, n_seq, max_len, R, dense, 0, n_layers, stop_before_fc2, out_fc2_in, workspace, ws_bytes, stream);
 }
 
 // SURVEY.md 8(b)'s name for the frozen prefix of FT_VL: all layers, the last one stopping at its fc2 input
@@ -467,8 +625,14 @@ extern "C" int64_t devqa_llm_forward_workspace(devqa_ctx_t h, int R, int R_want)
 
 extern "C" int devqa_llm_forward(devqa_ctx_t h, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense,
                                  const int32_t* want_rows, int R_want, float* out_logits, void* workspace, int64_t ws_bytes, void* stream) {
+    return devqa_llm_forward_ex(h, x, nullptr, seq_desc, n_seq, max_len, R, dense, want_rows, R_want, out_logits, workspace, ws_bytes, stream);
+}
+
+extern "C" int devqa_llm_forward_ex(devqa_ctx_t h, float* x, const int32_t* positions, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense,
+                                    const int32_t* want_rows, int R_want, float* out_logits, void* workspace, int64_t ws_bytes, void* stream) {
     CTX_OR_FAIL(h);
     DEVQA_CHECK_ARG(x && seq_desc && want_rows && out_logits && workspace, "llm_forward: null pointer");
+    DEVQA_CHECK_ARG(!llama_dec(c) || positions, "llm_forward: the LLaMA decoder needs the rotary positions of the rows (devqa_llm_forward_ex)");
     if (R == 0 || R_want == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(R > 0 && R_want > 0 && n_seq > 0 && max_len > 0, "llm_forward: bad dims");
     DEVQA_CHECK_ARG((((uintptr_t)workspace) & 255) == 0, "llm_forward: workspace must be 256-byte aligned");
@@ -479,7 +643,7 @@ extern "C" int devqa_llm_forward(devqa_ctx_t h, float* x, const int32_t* seq_des
     float* rows = (float*)a.take((int64_t)R_want * c.d.t_hidden * 4);
     void* hws = a.take((int64_t)R_want * c.d.t_hidden * esz(c));
     if (a.overflow) return devqa_fail(DEVQA_E_SHAPE, "llm_forward: workspace of %lld bytes is too small (need %lld)", (long long)ws_bytes, (long long)al256(a.off));
-    RC(llm_layers(c, x, seq_desc, n_seq, max_len, R, dense, c.d.t_layers, 0, nullptr, w, st));
+    RC(llm_layers(c, x, positions, seq_desc, n_seq, max_len, R, dense, 0, c.d.t_layers, 0, nullptr, w, st));
     RC(devqa_gather_rows(x, want_rows, R_want, c.d.t_hidden, 4, rows, st));
     return llm_head(c, rows, nullptr, R_want, out_logits, hws, st);
 }
@@ -576,7 +740,7 @@ extern "C" int devqa_ft_edit(devqa_ctx_t h, const float* w0, int64_t w0_stride_e
     plan_ft(c, E, kmax, npad, ar, p);
     if (ar.overflow) return devqa_fail(DEVQA_E_SHAPE, "ft_edit: workspace of %lld bytes is too small (need %lld)", (long long)ws_bytes, (long long)al256(ar.off));
     const Weight *fg = nullptr, *et = nullptr;
-    RC(need(c, "language_model.model.decoder.final_layer_norm.weight", &fg, DEVQA_DTYPE_F32));
+    RC(need(c, llama_dec(c) ? "language_model.model.norm.weight" : "language_model.model.decoder.final_layer_norm.weight", &fg, DEVQA_DTYPE_F32));
     if (c.bf16) RC(need(c, "derived.embed_T", &et, DEVQA_DTYPE_BF16));
     float* mom = out_delta;      // the first-moment buffer becomes the delta at the end (same shape)
     hipLaunchKernelGGL(ft_init_kernel, dim3((E + 63) / 64), dim3(64), 0, st, mask, E, kmax, cfg->num_steps, p.coef, p.active, p.do_update, out_steps,
@@ -598,7 +762,8 @@ extern "C" int devqa_ft_edit(devqa_ctx_t h, const float* w0, int64_t w0_stride_e
         } else {
             RC(gemm(c, p.dlog, V, "derived.embed_T", nullptr, R, Dout, V, 1.f, DEVQA_ACT_NONE, nullptr, nullptr, p.dH, st));
         }
-        RC(devqa_layernorm_bwd_dx(p.y, resid_rows, (const float*)fg->ptr, p.dH, R, Dout, c.d.t_ln_eps, p.dy, st));
+        if (llama_dec(c)) RC(devqa_rmsnorm_bwd_dx(p.y, resid_rows, (const float*)fg->ptr, p.dH, R, Dout, c.d.t_rms_eps, p.dy, st));
+        else RC(devqa_layernorm_bwd_dx(p.y, resid_rows, (const float*)fg->ptr, p.dH, R, Dout, c.d.t_ln_eps, p.dy, st));
         RC(devqa_ft_adamw_step(p.w, mom, p.var, w0, a_rows, p.dy, p.y, p.do_update, out_updates, E, kmax, Dout, npad, cfg->lr, cfg->beta1, cfg->beta2,
                                cfg->eps, cfg->weight_decay, cfg->clamp_eps, w0_stride_e, st));
     }

@@ -56,8 +56,33 @@ class LlavaNative(Blip2Native):
             return
         self.patch_w_gemm.zero_()
         self.patch_w_gemm[:, :self.patch_kreal] = pw.reshape(pw.shape[0], -1).to(self.wdtype)
-        self.embed_T = head.t().contiguous()
+        if self.embed_T is None:
+            self.embed_T = head.t().contiguous()
+        else:
+            self.embed_T.copy_(head.t())      # in place: the path-level context holds this buffer's address
         self._derived_version = ver
+
+    def weight_table(self):
+        """{canonical name: device tensor} for lib.PathContext (include/devqa.h, DEVQA_FAMILY_LLAVA): every parameter that is not a row
+        block of a fused operand under its own name, the fused operands as derived.clip_qkv.<i>.{weight,bias} / derived.llama_qkv.<i>.weight /
+        derived.llama_gu.<i>.weight, the patch-embedding GEMM operand and lm_head^T."""
+        from collections import OrderedDict
+        self.refresh_derived()
+        t = OrderedDict()
+        for name, p_ in self.named_parameters():
+            if self._fused_slot(name) is not None:
+                continue
+            t[name] = p_.data
+            ent = self._fp32_masters.get(name)
+            if ent is not None and self.wdtype != torch.float32:
+                t[name + "#shadow"] = ent[1]
+        for key, w in self.fused_w.items():
+            t["derived.%s.weight" % key] = w
+        for key, b in self.fused_b.items():
+            t["derived.%s.bias" % key] = b
+        t["derived.patch_w_gemm"] = self.patch_w_gemm
+        t["derived.embed_T"] = self.embed_T
+        return t
 
     @classmethod
     def from_pretrained_dir(cls, path, device="cuda", dtype="bf16"):

@@ -65,13 +65,45 @@ class MiniGPT4Native(Blip2Native):
             return
         self.patch_w_gemm.zero_()
         self.patch_w_gemm[:, :self.patch_kreal] = pw.reshape(pw.shape[0], -1).to(self.wdtype)
-        self.embed_T = head.t().contiguous()
+        if self.embed_T is None:
+            self.embed_T = head.t().contiguous()
+        else:
+            self.embed_T.copy_(head.t())      # in place: the path-level context holds this buffer's address
         D = self.cfg["vision_config"]["hidden_size"]
         for i, buf in enumerate(self.vit_qkv_bias):
             buf.zero_()
             buf[:D] = self.get("visual_encoder.blocks.%d.attn.q_bias" % i)
             buf[2 * D:] = self.get("visual_encoder.blocks.%d.attn.v_bias" % i)
         self._derived_version = ver
+
+    def weight_table(self):
+        """{canonical name: device tensor} for lib.PathContext (include/devqa.h, DEVQA_FAMILY_MINIGPT4): the vision side under the BLIP-2
+        names, the decoder under the LLaVA names (minigpt4_spec.canonical_name), the ViT's fused qkv bias cat(q_bias, 0, v_bias)
+        (eva_vit.py:193-197) as vision_model.encoder.layers.<i>.self_attn.qkv.bias, the fused LLaMA operands as derived.llama_*."""
+        from collections import OrderedDict
+        from ....minigpt4_spec import canonical_name
+        self.refresh_derived()
+        t = OrderedDict()
+        for name, p_ in self.named_parameters():
+            if self._fused_slot(name) is not None:
+                continue
+            cn = canonical_name(name)
+            if cn is None:
+                continue
+            t[cn] = p_.data
+            ent = self._fp32_masters.get(name)
+            if ent is not None and self.wdtype != torch.float32:
+                t[cn + "#shadow"] = ent[1]
+        for i, b in enumerate(self.vit_qkv_bias):
+            t["vision_model.encoder.layers.%d.self_attn.qkv.bias" % i] = b
+        for key, w in self.fused_w.items():
+            t["derived.%s.weight" % key] = w
+        t["derived.patch_w_gemm"] = self.patch_w_gemm
+        t["derived.embed_T"] = self.embed_T
+        return t
+
+    def storage_fingerprint(self):
+        return hash((super().storage_fingerprint(), tuple(b.data_ptr() for b in self.vit_qkv_bias)))
 
     @classmethod
     def from_pretrained_dir(cls, path, device="cuda", dtype="bf16"):

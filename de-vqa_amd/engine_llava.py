@@ -27,6 +27,41 @@ class LlavaEngine:
         self.theta = float(self.t.get("rope_theta", 10000.0))
         self._desc_cache = {}
 
+    # ---- path-level context (include/devqa.h "PATH LEVEL", DEVQA_FAMILY_LLAVA / _MINIGPT4): the schedules below live behind the C ABI ----
+    FAMILY = lib.FAMILY_LLAVA
+
+    def _model_desc(self):
+        v, t = self.v, self.t
+        return lib.ModelDesc(family=self.FAMILY, compute_dtype=lib.DTYPE_BF16 if self.adt == torch.bfloat16 else lib.DTYPE_F32,
+                             image_size=v["image_size"], patch_size=v["patch_size"], v_hidden=v["hidden_size"], v_layers=v["num_hidden_layers"],
+                             v_heads=v["num_attention_heads"], v_ffn=v["intermediate_size"], num_query_tokens=self.n_img,
+                             t_hidden=t["hidden_size"], t_layers=t["num_hidden_layers"], t_heads=t["num_attention_heads"],
+                             t_ffn=t["intermediate_size"], t_vocab=self._p(self.lm + "lm_head.weight").shape[0],
+                             t_max_pos=t.get("max_position_embeddings", 0), v_ln_eps=v["layer_norm_eps"], t_rms_eps=self.eps,
+                             t_rope_theta=self.theta, v_run_layers=v["num_hidden_layers"] - 1)
+
+    def path_ctx(self):
+        """lib.PathContext over this model's weight table (rebuilt when any of its buffers has moved: storage fingerprint), or None
+        when the schedule must stay in Python: editor hooks registered on the engine are handled by decoder_layers itself, and
+        DEVQA_PATH_ABI=0 keeps the Python-ordered launches (A/B tests of the two drivers of the same kernels)."""
+        import os
+        if not hasattr(self.m, "weight_table") or os.environ.get("DEVQA_PATH_ABI", "1") == "0":
+            return None
+        self.m.refresh_derived()
+        fp = self.m.storage_fingerprint()
+        if self.__dict__.get("_ctx") is None or self._ctx_fp != fp:
+            old = self.__dict__.get("_ctx")
+            if old is not None:
+                torch.cuda.current_stream(self.dev).synchronize()
+                old.close()
+            self._ctx = lib.PathContext(self.dev.index or 0, self._model_desc(), self.m.weight_table())
+            self._ctx_fp = fp
+        self.m.refresh_shadows()
+        return self._ctx
+
+    def _hooks_active(self):
+        return bool(getattr(self, "module_deltas", None)) or bool(getattr(self, "extra_neurons", None))
+
     def _w(self, name):
         return self.m.weight_for_gemm(name)
 
@@ -54,6 +89,9 @@ class LlavaEngine:
 
     @torch.no_grad()
     def encode_images(self, pixels):
+        ctx = self.path_ctx()
+        if ctx is not None:
+            return ctx.vision_encode(pixels.contiguous())
         m, v = self.m, self.v
         m.refresh_derived()
         B = pixels.shape[0]
@@ -198,6 +236,11 @@ class LlavaEngine:
         n_seq = ps.desc.shape[0]
         last = t["num_hidden_layers"] - 1 if upto_layer is None else upto_layer
         deltas = getattr(self, "module_deltas", None) or {}
+        ctx = self.path_ctx() if (save is None and not return_h and not self._hooks_active() and last >= first_layer) else None
+        if ctx is not None:     # plain frozen layers: one path-level call (devqa_llm_layers_ex) instead of ~10 Python-ordered launches per layer
+            a = ctx.llm_layers(x, ps.desc, n_seq, ps.max_len, getattr(ps, "dense", False), last + 1 - first_layer, stop_before_fc2,
+                               positions=ps.pos, first_layer=first_layer)
+            return x, a
         for i in range(first_layer, last + 1):
             p = self.lm + "model.layers.%d." % i
             rec = None
@@ -364,6 +407,9 @@ class LlavaEngine:
 
     @torch.no_grad()
     def lm_head(self, x_rows, add=None):
+        ctx = self.path_ctx()
+        if ctx is not None:
+            return ctx.llm_head(x_rows.contiguous(), add)
         h = lib.rmsnorm(x_rows, self._p(self.lm + "model.norm.weight"), self.eps, add=add, want=self.want)
         return lib.gemm(h, self._w(self.lm + "lm_head.weight"), want="f32")
 

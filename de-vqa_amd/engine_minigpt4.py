@@ -5,6 +5,7 @@ unchanged.  Replaces R/editor/vllms_for_edit/minigpt4/modules/minigpt4.py:214-24
 """
 import torch
 
+from . import lib
 from .engine import Blip2Engine
 from .engine_llava import LlavaEngine
 from .minigpt4_spec import blip2_alias
@@ -40,9 +41,22 @@ class MiniGPT4Engine(LlavaEngine):
         self._desc_cache = {}
         self.vision = _VisionPart(model)
 
+    FAMILY = lib.FAMILY_MINIGPT4
+
+    def _model_desc(self):
+        d = super()._model_desc()
+        q = self.m.cfg["qformer_config"]
+        d.v_run_layers = self.v["num_hidden_layers"]
+        d.q_hidden, d.q_layers, d.q_heads, d.q_ffn = q["hidden_size"], q["num_hidden_layers"], q["num_attention_heads"], q["intermediate_size"]
+        d.q_cross_freq, d.q_ln_eps = q["cross_attention_frequency"], q["layer_norm_eps"]
+        return d
+
     def image_chunks(self, n, max_chunk=128):
         return self.vision.image_chunks(n, max_chunk)
 
     def encode_images(self, pixels):
         """pixel_values fp32 [B,3,S,S] -> llama_proj(Q-Former(ln_vision(ViT))) fp32 [B, 32, d_llm]"""
+        ctx = self.path_ctx()
+        if ctx is not None:
+            return ctx.vision_encode(pixels.contiguous())
         return self.vision.encode_images(pixels)

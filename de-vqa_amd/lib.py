@@ -110,6 +110,7 @@ def load():
     _sig(L.devqa_vision_encode, [U64, P, I, P, P, I64, P])
     _sig(L.devqa_llm_layers_workspace, [U64, I, I], c_int64)
     _sig(L.devqa_llm_layers, [U64, P, P, I, I, I, I, I, I, P, P, I64, P])
+    _sig(L.devqa_llm_layers_ex, [U64, P, P, P, I, I, I, I, I, I, I, P, P, I64, P])
     _sig(L.devqa_llm_prefix_workspace, [U64, I], c_int64)
     _sig(L.devqa_llm_prefix, [U64, P, P, I, I, I, I, P, P, I64, P])
     _sig(L.devqa_mend_transform_workspace, [I, I, I, I], c_int64)
@@ -120,6 +121,7 @@ def load():
     _sig(L.devqa_llm_head, [U64, P, P, I, P, P, I64, P])
     _sig(L.devqa_llm_forward_workspace, [U64, I, I], c_int64)
     _sig(L.devqa_llm_forward, [U64, P, P, I, I, I, I, P, I, P, P, I64, P])
+    _sig(L.devqa_llm_forward_ex, [U64, P, P, P, I, I, I, I, P, I, P, P, I64, P])
     _sig(L.devqa_ft_edit_workspace, [U64, I, I, I], c_int64)
     _sig(L.devqa_ft_edit, [U64, P, I64, P, P, P, P, I, I, I, P, P, P, P, P, P, I64, P])
     _sig(L.devqa_ctx_bind_edit_target, [U64, ctypes.c_char_p, P])
@@ -135,7 +137,7 @@ def load():
 
 
 EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "devqa_vision_encode_workspace", "devqa_vision_encode",
-           "devqa_llm_layers_workspace", "devqa_llm_layers", "devqa_llm_prefix_workspace", "devqa_llm_prefix", "devqa_mend_transform_workspace",
+           "devqa_llm_layers_workspace", "devqa_llm_layers", "devqa_llm_layers_ex", "devqa_llm_forward_ex", "devqa_llm_prefix_workspace", "devqa_llm_prefix", "devqa_mend_transform_workspace",
            "devqa_mend_transform", "devqa_mend_apply_workspace", "devqa_mend_apply", "devqa_llm_head_workspace", "devqa_llm_head", "devqa_llm_forward_workspace",
            "devqa_llm_forward", "devqa_ft_edit_workspace", "devqa_ft_edit", "devqa_ctx_bind_edit_target", "devqa_apply_delta", "devqa_restore",
            "devqa_token_acc", "devqa_comm_unique_id", "devqa_comm_create", "devqa_comm_destroy", "devqa_gather_scores",
@@ -787,13 +789,15 @@ def swiglu_bwd(gu, da):
 # path level: model context + the launch schedules behind the ABI (include/devqa.h "PATH LEVEL")
 # ---------------------------------------------------------------------------------------------
 DTYPE_BF16, DTYPE_F32, FAMILY_BLIP2_OPT, SCORE_COLS = 1, 2, 1, 16
+FAMILY_LLAVA, FAMILY_MINIGPT4 = 2, 3
 
 
 class ModelDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("family", "compute_dtype", "image_size", "patch_size", "v_hidden", "v_layers", "v_heads", "v_ffn",
                                              "q_hidden", "q_layers", "q_heads", "q_ffn", "q_cross_freq", "num_query_tokens",
                                              "t_hidden", "t_layers", "t_heads", "t_ffn", "t_vocab", "t_max_pos")] + \
-               [(n, ctypes.c_float) for n in ("v_ln_eps", "q_ln_eps", "t_ln_eps")]
+               [(n, ctypes.c_float) for n in ("v_ln_eps", "q_ln_eps", "t_ln_eps", "t_rms_eps", "t_rope_theta")] + \
+               [(n, ctypes.c_int32) for n in ("v_run_layers", "reserved")]
 
 
 class WeightEntry(ctypes.Structure):
@@ -917,21 +921,26 @@ class PathContext:
     def vision_encode(self, pixels):
         _need(pixels, torch.float32, "vision_encode pixels")
         B, d = pixels.shape[0], self.desc
-        out = torch.empty((B, d.num_query_tokens, d.t_hidden), dtype=torch.float32, device=pixels.device)
+        n_tok = (d.image_size // d.patch_size) ** 2 if d.family == FAMILY_LLAVA else d.num_query_tokens
+        out = torch.empty((B, n_tok, d.t_hidden), dtype=torch.float32, device=pixels.device)
         n = load().devqa_vision_encode_workspace(self.h, B)
         keep, ws = _ws(n, pixels.device)
         _chk(load().devqa_vision_encode(self.h, _p(pixels), B, _p(out), ws, n, _stream()), "devqa_vision_encode")
         return out
 
-    def llm_layers(self, x, seq_desc, n_seq, max_len, dense, n_layers=-1, stop_before_fc2=False):
-        """In place on x fp32 [R, d].  -> fc2 input [R, ffn] (compute dtype) when stop_before_fc2, else None"""
+    def llm_layers(self, x, seq_desc, n_seq, max_len, dense, n_layers=-1, stop_before_fc2=False, positions=None, first_layer=0):
+        """Layers [first_layer, first_layer + n_layers) in place on x fp32 [R, d] (devqa_llm_layers_ex; `positions` int32 [R]: the rows'
+        rotary positions, required by the LLaMA-family decoders).  -> fc2 / down_proj input [R, ffn] (compute dtype) when
+        stop_before_fc2, else None"""
         _need(x, torch.float32, "llm_layers x")
         R = x.shape[0]
+        if positions is not None:
+            assert positions.dtype == torch.int32 and positions.is_cuda and positions.is_contiguous() and positions.numel() == R
         a = torch.empty((R, self.desc.t_ffn), dtype=self.adt, device=x.device) if stop_before_fc2 else None
         n = load().devqa_llm_layers_workspace(self.h, R, int(stop_before_fc2))
         keep, ws = _ws(n, x.device)
-        _chk(load().devqa_llm_layers(self.h, _p(x), _p(seq_desc), int(n_seq), int(max_len), R, int(bool(dense)), int(n_layers),
-                                     int(bool(stop_before_fc2)), _p(a), ws, n, _stream()), "devqa_llm_layers")
+        _chk(load().devqa_llm_layers_ex(self.h, _p(x), _p(positions), _p(seq_desc), int(n_seq), int(max_len), R, int(bool(dense)), int(first_layer),
+                                        int(n_layers), int(bool(stop_before_fc2)), _p(a), ws, n, _stream()), "devqa_llm_layers_ex")
         return a
 
     def llm_prefix(self, x, seq_desc, n_seq, max_len, dense):
@@ -957,15 +966,15 @@ class PathContext:
         _chk(load().devqa_llm_head(self.h, _p(rows), _p(add), R, _p(out), ws, n, _stream()), "devqa_llm_head")
         return out
 
-    def llm_forward(self, x, seq_desc, n_seq, max_len, dense, want_rows):
+    def llm_forward(self, x, seq_desc, n_seq, max_len, dense, want_rows, positions=None):
         _need(x, torch.float32, "llm_forward x")
         assert want_rows.dtype == torch.int32 and want_rows.is_cuda
         R, Rw = x.shape[0], want_rows.numel()
         out = torch.empty((Rw, self.desc.t_vocab), dtype=torch.float32, device=x.device)
         n = load().devqa_llm_forward_workspace(self.h, R, Rw)
         keep, ws = _ws(n, x.device)
-        _chk(load().devqa_llm_forward(self.h, _p(x), _p(seq_desc), int(n_seq), int(max_len), R, int(bool(dense)), _p(want_rows), Rw, _p(out),
-                                      ws, n, _stream()), "devqa_llm_forward")
+        _chk(load().devqa_llm_forward_ex(self.h, _p(x), _p(positions), _p(seq_desc), int(n_seq), int(max_len), R, int(bool(dense)), _p(want_rows), Rw,
+                                         _p(out), ws, n, _stream()), "devqa_llm_forward_ex")
         return out
 
     def ft_edit(self, w0, a_rows, resid_rows, labels, mask, num_steps, lr, weight_decay, clamp_eps, beta1=0.9, beta2=0.999, eps=1e-8,

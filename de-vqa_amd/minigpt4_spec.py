@@ -133,3 +133,37 @@ def blip2_alias(name: str) -> str:
     if name.startswith("qformer.encoder.layer."):
         return "Qformer.bert." + name[len("qformer."):].replace("attention.attention.", "attention.self.")
     raise KeyError(name)
+
+
+_MG4_BLOCK = re.compile(r"^visual_encoder\.blocks\.(\d+)\.(.*)$")
+
+
+def canonical_name(name: str):
+    """MiniGPT-4 state-dict name -> the canonical name of the path-level weight table (include/devqa.h, DEVQA_FAMILY_MINIGPT4: the vision
+    side under the BLIP-2 names, the decoder under the LLaVA names), or None for parameters the table carries in a derived form only
+    (the ViT's q_bias / v_bias: the fused qkv bias).  Inverse of blip2_alias on the vision side."""
+    if name.startswith("llama_model."):
+        return "language_model." + name[len("llama_model."):]
+    m = _MG4_BLOCK.match(name)
+    if m:
+        i, rest = int(m.group(1)), m.group(2)
+        if rest in ("attn.q_bias", "attn.v_bias"):
+            return None
+        for k, v in _VIT_SUB.items():
+            if rest.startswith(v):
+                return "vision_model.encoder.layers.%d.%s%s" % (i, k, rest[len(v):])
+        raise KeyError(name)
+    fixed = {"visual_encoder.cls_token": "vision_model.embeddings.class_embedding",
+             "visual_encoder.pos_embed": "vision_model.embeddings.position_embedding",
+             "visual_encoder.patch_embed.proj.weight": "vision_model.embeddings.patch_embedding.weight",
+             "visual_encoder.patch_embed.proj.bias": "vision_model.embeddings.patch_embedding.bias",
+             "ln_vision.weight": "vision_model.post_layernorm.weight", "ln_vision.bias": "vision_model.post_layernorm.bias",
+             "Qformer.bert.embeddings.LayerNorm.weight": "qformer.layernorm.weight",
+             "Qformer.bert.embeddings.LayerNorm.bias": "qformer.layernorm.bias",
+             "llama_proj.weight": "language_projection.weight", "llama_proj.bias": "language_projection.bias",
+             "query_tokens": "query_tokens"}
+    if name in fixed:
+        return fixed[name]
+    if name.startswith("Qformer.bert.encoder.layer."):
+        return "qformer." + name[len("Qformer.bert."):].replace("attention.self.", "attention.attention.")
+    raise KeyError(name)

@@ -401,7 +401,9 @@ int devqa_cosine_topk_cached(const float* corpus, const float* corpus_inv_norm, 
  * ===================================================================================================================== */
 typedef uint64_t devqa_ctx_t;
 typedef uint64_t devqa_comm_t;
-#define DEVQA_FAMILY_BLIP2_OPT 1
+#define DEVQA_FAMILY_BLIP2_OPT 1 /* ViT-g + Q-Former + projection, OPT decoder (R/editor/vllms_for_edit/blip2/blip2.py) */
+#define DEVQA_FAMILY_LLAVA 2     /* CLIP ViT (hidden state -2, CLS dropped) + 2-layer GELU projector, LLaMA decoder (.../llava/llava.py:25-68) */
+#define DEVQA_FAMILY_MINIGPT4 3  /* EVA ViT-g + Q-Former + llama_proj, LLaMA decoder (.../minigpt4/minigpt4.py:33-69) */
 #define DEVQA_DTYPE_BF16 1
 #define DEVQA_DTYPE_F32 2
 #define DEVQA_SCORE_COLS 16   /* [sample_id, reliability, text_rephrase, image_rephrase, 9 locality accs, edit_time, steps, final_loss] */
@@ -411,9 +413,28 @@ typedef struct devqa_model_desc {
     int32_t compute_dtype; /* DEVQA_DTYPE_BF16 (bf16 operands, fp32 accumulate / residual stream) or DEVQA_DTYPE_F32 ("faithful") */
     int32_t image_size, patch_size, v_hidden, v_layers, v_heads, v_ffn;             /* ViT (HF Blip2VisionConfig) */
     int32_t q_hidden, q_layers, q_heads, q_ffn, q_cross_freq, num_query_tokens;     /* Q-Former */
-    int32_t t_hidden, t_layers, t_heads, t_ffn, t_vocab, t_max_pos;                 /* OPT decoder */
+    int32_t t_hidden, t_layers, t_heads, t_ffn, t_vocab, t_max_pos;                 /* decoder (t_max_pos: OPT's learned positions) */
     float v_ln_eps, q_ln_eps, t_ln_eps;
+    /* LLaMA-family decoders (DEVQA_FAMILY_LLAVA / _MINIGPT4): RMSNorm epsilon, rotary base; LLAVA: number of CLIP encoder layers that
+     * run (HF vision_feature_layer = -2 -> v_layers - 1).  Ignored by DEVQA_FAMILY_BLIP2_OPT. */
+    float t_rms_eps, t_rope_theta;
+    int32_t v_run_layers, reserved;
 } devqa_model_desc;
+
+/* Weight-table names per family.  The table carries ONE canonical naming; a host whose checkpoint names differ registers its tensors
+ * under these (the Python host does: MiniGPT4Native.weight_table).
+ *   BLIP2_OPT : the HF Blip2ForConditionalGeneration parameter names + derived.dec_qkv.<i>.{weight,bias} (fused
+ *               q|k|v rows), derived.patch_w_gemm [v_hidden, Kpad], derived.embed_T [t_hidden, vocab]; an fp32 edit target additionally
+ *               as "<name>#shadow" (its compute-dtype copy).
+ *   LLAVA     : vision_tower.vision_model.{embeddings.{class_embedding, position_embedding.weight}, pre_layrnorm.*, encoder.layers.<i>.
+ *               {layer_norm1, layer_norm2, self_attn.out_proj, mlp.fc1, mlp.fc2}.*}, derived.clip_qkv.<i>.{weight,bias},
+ *               multi_modal_projector.linear_{1,2}.*, language_model.model.{embed_tokens.weight, norm.weight, layers.<i>.{input_layernorm,
+ *               post_attention_layernorm}.weight, layers.<i>.self_attn.o_proj.weight, layers.<i>.mlp.down_proj.weight},
+ *               language_model.lm_head.weight, derived.llama_qkv.<i>.weight [3d, d], derived.llama_gu.<i>.weight [2F, d] (gate rows, then
+ *               up rows), derived.patch_w_gemm, derived.embed_T (= lm_head^T).
+ *   MINIGPT4  : the vision side under the BLIP2_OPT names (visual_encoder.* -> vision_model.*, ln_vision -> vision_model.post_layernorm,
+ *               Qformer.bert.* -> qformer.*, llama_proj -> language_projection), the decoder under the LLAVA names (llama_model.* ->
+ *               language_model.*). */
 
 typedef struct devqa_weight {
     const char* name;   /* HF parameter name or "derived.*" */
@@ -444,6 +465,14 @@ int devqa_vision_encode(devqa_ctx_t ctx, const float* pixel_values, int B, float
 int64_t devqa_llm_layers_workspace(devqa_ctx_t ctx, int R, int stop_before_fc2);
 int devqa_llm_layers(devqa_ctx_t ctx, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense, int n_layers,
                      int stop_before_fc2, void* out_fc2_in, void* workspace, int64_t ws_bytes, void* stream);
+/* The general form: layers [first_layer, first_layer + n_layers) (n_layers = -1: up to the last), and `positions` = int32 [R] rotary
+ * position of every packed row -- REQUIRED by the LLaMA-family decoders (RoPE is applied per layer; OPT's learned positions are already
+ * in x, so it takes NULL).  LLaMA layers: RMSNorm -> fused q|k|v GEMM -> rotary q, k -> causal attention -> o_proj (+ residual) -> RMSNorm
+ * -> fused gate|up GEMM -> SiLU(gate) * up -> down_proj (+ residual); stop_before_fc2 stops the last layer at its down_proj INPUT
+ * (out_fc2_in [R, t_ffn]).  first_layer > 0 continues a forward whose earlier layers already ran on x (e.g. the layers an editor
+ * modifies, after the frozen ones). */
+int devqa_llm_layers_ex(devqa_ctx_t ctx, float* x, const int32_t* positions, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense,
+                        int first_layer, int n_layers, int stop_before_fc2, void* out_fc2_in, void* workspace, int64_t ws_bytes, void* stream);
 /* devqa_llm_prefix (SURVEY.md 8(b)'s name): devqa_llm_layers over ALL layers with stop_before_fc2 = 1 */
 int64_t devqa_llm_prefix_workspace(devqa_ctx_t ctx, int R);
 int devqa_llm_prefix(devqa_ctx_t ctx, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense, void* out_fc2_in,
@@ -456,6 +485,9 @@ int devqa_llm_head(devqa_ctx_t ctx, const float* rows, const float* add, int R, 
 int64_t devqa_llm_forward_workspace(devqa_ctx_t ctx, int R, int R_want);
 int devqa_llm_forward(devqa_ctx_t ctx, float* x, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense,
                       const int32_t* want_rows, int R_want, float* out_logits, void* workspace, int64_t ws_bytes, void* stream);
+/* the same with the rows' rotary positions (LLaMA-family decoders) */
+int devqa_llm_forward_ex(devqa_ctx_t ctx, float* x, const int32_t* positions, const int32_t* seq_desc, int n_seq, int max_len, int R, int dense,
+                         const int32_t* want_rows, int R_want, float* out_logits, void* workspace, int64_t ws_bytes, void* stream);
 
 /* K9-K13 (R/editor/vllm_editors/ft_vl/ft_vl.py:111-158): the FT_VL inner loop for E concurrent edits of the last decoder
  * layer's fc2 matrix, control flow on the device (no host sync): per step  final LN + lm_head on the loss rows -> masked NLL +
