@@ -81,13 +81,19 @@ class BatchedEditEval:
             return False
         if not (isinstance(editor, FTvl) and hasattr(editor.vllm, "engine") and hasattr(editor.vllm.engine, "pack_from_tokens")):
             return False
-        if edit_n != 1 or editor.cfg.batch_size != 1:
+        if editor.cfg.batch_size != 1:
             return False
         try:
             editor._edit_target()
         except NotImplementedError:
             return False
-        return all(len(split) == 1 and len(split[0]["requests"]) == 1 for split in eval_data)
+        if not all(len(s["requests"]) == 1 for split in eval_data for s in split):
+            return False
+        if all(len(split) == 1 for split in eval_data):
+            return True
+        # edit_n > 1 (`-sen N`): the chained form (run -> _run_sequential) needs the device-side FT loop of the path-level context
+        eng = editor.vllm.engine
+        return hasattr(eng, "path_ctx") and eng.path_ctx() is not None
 
     # ------------------------------------------------------------------------------------------
     def run(self, result_data, eval_data, gather=True):
@@ -99,6 +105,8 @@ class BatchedEditEval:
         n = len(eval_data)
         lo, hi = shard_range(n, rank, world)
         self.editor.restore_to_original_model()
+        if any(len(split) != 1 for split in eval_data):       # `-sen N` with N > 1: chained edits inside a split
+            return self._run_sequential(result_data, eval_data, lo, hi, rank, world, gather)
         local, meta = [], []
         batches = []
         for b0 in range(lo, hi, self.E):
@@ -114,6 +122,85 @@ class BatchedEditEval:
         from .dist import gather_results
         allres = gather_results(local, self.last_scores, n, rank, world, self.eng.dev)
         return None if allres is None else [[r] for r in allres]
+
+    # ------------------------------------------------------------------------------------------
+    # `-sen N`, N > 1 (R/evaluation/vllm_editor_eval.py:100-123): a split's N edits are applied CUMULATIVELY (ft_vl.py:56-61: every
+    # delta is added to the same matrix), then all its samples are probed on the final weights.  Only the edited matrix changes, so
+    # the frozen work is the same as for N independent cycles and runs batched (stage A: vision encoder, decoder up to the edited
+    # layer's fc2 input, once per unique image / sequence); the chain itself is serial by definition: edit i starts from
+    # W0 + sum_{j<i} delta_j -- one device-side FT loop per edit (devqa_ft_edit, E = 1) on its active columns gathered from the RUNNING
+    # matrix, its delta scattered back into it, no host synchronisation inside the chain.  Pre-edit probes use the pristine matrix,
+    # post-edit probes the final one: two GEMMs over the cached fc2-input rows per chunk.
+    # ------------------------------------------------------------------------------------------
+    def _run_sequential(self, result_data, eval_data, lo, hi, rank, world, gather):
+        local = [self._run_split_chained(result_data[i], eval_data[i]) for i in range(lo, hi)]
+        self.last_meta = [mt for _, metas in local for mt in metas]
+        local = [res for res, _ in local]
+        if world == 1 or not gather:
+            return local
+        from .dist import gather_split_results
+        sizes = [len(sp) for sp in eval_data]
+        return gather_split_results(local, sizes, lo, rank, world, self.eng.dev)
+
+    @torch.no_grad()
+    def _run_split_chained(self, rds, eds):
+        eng, cfg, dev = self.eng, self.editor.cfg, self.eng.dev
+        ctx = eng.path_ctx()
+        if ctx is None:
+            raise RuntimeError("chained FT_VL edits on the batched engine need the path-level context (DEVQA_PATH_ABI)")
+        n = len(eds)
+        chunks = [self._stage_a(rds[i:i + self.E], eds[i:i + self.E]) for i in range(0, n, self.E)]
+        wname = self.editor._edit_target()
+        w0 = self.vllm.model.get(wname)                          # fp32 master [d, ffn], never written here
+        Wc = w0.clone()                                          # the running matrix of the chain
+        Din = w0.shape[1]
+        clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else -1.0
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        per_edit = []
+        for c in chunks:
+            E, kmax, a_ft, resid_ft = c["E"], c["kmax"], c["a_ft"], c["resid_ft"]
+            t_lab = lib.h2d(c["labels"].reshape(-1), torch.int32, dev)
+            t_mask = lib.h2d(c["mask"], torch.float32, dev)
+            if c.get("act") is not None:
+                idx, cnt, mx, act_ev = c["act"]
+                act_ev.synchronize()
+                npad = max(8, (int(mx[0]) + 7) // 8 * 8)
+            else:                                                # weight decay: every column moves
+                idx = torch.arange(Din, dtype=torch.int32, device=dev).repeat(E, 1).contiguous()
+                cnt = torch.full((E,), Din, dtype=torch.int32, device=dev)
+                npad = Din
+            for e in range(E):
+                ie, ce = idx[e:e + 1], cnt[e:e + 1]
+                w_e = lib.gather_cols(Wc, ie, ce, npad, per_edit=False)                     # [1, d, npad] from the RUNNING matrix
+                a_e = lib.gather_cols(a_ft[e:e + 1].contiguous(), ie, ce, npad, per_edit=True)
+                delta, losses, n_steps, _ = ctx.ft_edit(w_e, a_e, resid_ft[e * kmax:(e + 1) * kmax], t_lab[e * kmax:(e + 1) * kmax],
+                                                        t_mask[e:e + 1], cfg.num_steps, cfg.lr, cfg.weight_decay, clamp)
+                lib.scatter_cols_add(delta[0], idx[e], ce, Wc)                               # Wc[:, J_e] += delta_e  (ft_vl.py:56-61)
+                per_edit.append((n_steps, losses))
+        ev1.record()
+        w0_op = self.vllm.model.weight_for_gemm(wname)
+        wc_op = Wc if eng.adt == torch.float32 else lib.cast_f32_bf16(Wc)
+        outs = []
+        for c in chunks:
+            y_pre = lib.gemm(c["a_tail"], w0_op, c["b2"], residual=c["resid_tail"], want="f32")
+            pre_argmax = self._argmax_from_y(y_pre)
+            y_post = lib.gemm(c["a_tail"], wc_op, c["b2"], residual=c["resid_tail"], want="f32")
+            outs.append((pre_argmax, self._argmax_from_y(y_post)))
+        steps_h = torch.cat([s_ for s_, _ in per_edit]).cpu().numpy()
+        loss_h = torch.cat([l_ for _, l_ in per_edit]).cpu().numpy()
+        torch.cuda.current_stream(dev).synchronize()
+        edit_time = ev0.elapsed_time(ev1) * 1e-3 / max(n, 1)
+        results = []
+        for c, (pre, post) in zip(chunks, outs):
+            results += self._fill_results(c["rds"], c["probes"], pre.cpu().numpy(), post.cpu().numpy(), edit_time)
+        metas = [(int(steps_h[i]), float(loss_h[i, max(int(steps_h[i]) - 1, 0)])) for i in range(n)]
+        self.stats["cycles"] += n
+        self.stats["steps"] += int(steps_h.sum())
+        self.last_losses, self.last_steps = loss_h, steps_h
+        if self.keep_debug:
+            self.__dict__.setdefault("debug", {})["chain_weight"] = Wc
+        return results, metas
 
     @staticmethod
     def score_rows(results, meta, first_id):

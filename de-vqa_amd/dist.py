@@ -120,3 +120,22 @@ def gather_results_ragged(local_results, local_rows, rank, world, device):
     for i, r in enumerate(allres):
         assert int(rows[i, 0]) == i and abs(float(rows[i, 1]) - r["reliability"][0]["acc"]) < 1e-6
     return allres
+
+
+def gather_split_results(local_splits, sizes, lo, rank, world, device):
+    """Rank r evaluated the contiguous block of SPLITS starting at split `lo` (each a list of sample results; `sizes` = samples per
+    split of the whole run); rank 0 gets all splits in order (the collective of fixed-width score rows + the host gather of the
+    dicts, per SAMPLE, regrouped), the others None."""
+    from .batched import BatchedEditEval
+    first = sum(sizes[:lo])
+    flat = [r for sp in local_splits for r in sp]
+    rows = BatchedEditEval.score_rows(flat, [(0, 0.0)] * len(flat), first)
+    dev = torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+    allres = gather_results_ragged(flat, rows, rank, world, dev)
+    if allres is None:
+        return None
+    out, i = [], 0
+    for sz in sizes:
+        out.append(allres[i:i + sz])
+        i += sz
+    return out

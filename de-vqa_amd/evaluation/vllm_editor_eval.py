@@ -331,21 +331,9 @@ class VLLMEditorEvaluation:
         if world == 1:
             return local
         # the gather helpers move one row / one dict per SAMPLE: flatten the splits, regroup on rank 0
-        sizes = [len(sp) for sp in result_data]
-        first = sum(sizes[:lo])
-        flat = [r for sp in local for r in sp]
-        rows = BatchedEditEval.score_rows(flat, [(0, 0.0)] * len(flat), first)
-        from ..dist import gather_results_ragged
-        dev = torch.device(editor.device if isinstance(editor.device, str) else "cuda:%d" % editor.device) \
-            if dist.get_backend() == "nccl" else torch.device("cpu")
-        allres = gather_results_ragged(flat, rows, rank, world, dev)
-        if allres is None:
-            return None
-        out, i = [], 0
-        for sz in sizes:
-            out.append(allres[i:i + sz])
-            i += sz
-        return out
+        from ..dist import gather_split_results
+        dev = editor.device if isinstance(editor.device, str) else "cuda:%d" % editor.device
+        return gather_split_results(local, [len(sp) for sp in result_data], lo, rank, world, dev)
 
     def _run_splits(self, editor, result_data, eval_data):
         """prepare -> edit -> test -> restore per split (vllm_editor_eval.py:94-123).  Every split starts from the restored

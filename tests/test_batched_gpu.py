@@ -161,3 +161,49 @@ def test_pipelined_batches_equal_sequential(gold_dir, in_gold_dir, dtype):
                         a, b = r1[sec][sub][0], r2[sec][sub][0]
                         assert a["acc"] == b["acc"] and a["predict_after_edit"] == b["predict_after_edit"]
                 assert r1["reliability"][0]["acc"] == r2["reliability"][0]["acc"]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_batched_chained_edits_match_reference_and_generic(gold_dir, in_gold_dir, tmp_path, dtype):
+    """`-sen N` with N > 1 (R/evaluation/vllm_editor_eval.py:114-122: a split's edits accumulate on the same matrix, then every sample of
+    the split is probed on the final weights) on the batched engine: frozen work batched, the chain as one device-side FT loop per edit
+    on the running matrix.  Against the reference's results.json for edit_n = 3 (tiny_goldens g5_results_sen3: 8 samples -> two splits
+    of 3, the incomplete tail dropped) and against the generic per-sample path, incl. the final edited matrix."""
+    from devqa_amd.batched import BatchedEditEval
+    from devqa_amd.evaluation.vllm_editor_eval import VLLMEditorEvaluation
+    vllm, ed, data = _setup(gold_dir, dtype)
+    j = json.load(open(os.path.join(gold_dir, "tiny_goldens.json")))
+    ev = VLLMEditorEvaluation(ed, data, "EVQA", str(tmp_path / "b"))
+    res_b = ev.evaluate_sequential_edit(3, False, None)            # auto-selected
+    assert ev.last_mode == "BatchedEditEval"
+    ev2 = VLLMEditorEvaluation(ed, data, "EVQA", str(tmp_path / "g"))
+    res_g = ev2.evaluate_sequential_edit(3, False, None, batched=False)
+    assert ev2.last_mode == "generic"
+    assert [len(s) for s in res_b] == [len(s) for s in res_g] == [3, 3]
+    fb, fg = _flat(res_b), _flat(res_g)
+    gold = _flat(j["g5_results_sen3"])
+    assert len(fb) == len(fg) == len(gold) == 72
+    same_generic = sum(a == b for a, b in zip(fb, fg))
+    same_gold = sum((a[0], round(a[1], 4), a[2], a[3]) == b for a, b in zip(fb, gold))
+    print(dtype, "chained: batched==generic %d/72, batched==reference %d/72" % (same_generic, same_gold))
+    if dtype == "fp32":
+        assert same_generic == 72 and same_gold == 72
+    else:
+        assert same_generic >= 66 and same_gold >= 54
+    # the running matrix after a split's three edits == the generic path's edited weight
+    wname = ed._edit_target()
+    be = BatchedEditEval(ed, cycles_per_batch=2)                   # chunks of 2: the chain crosses a chunk boundary
+    be.keep_debug = True
+    recs = [deepcopy(r) for r in data.data_with_img[:3]]
+    res, _ = be._run_split_chained([deepcopy(r) for r in recs], recs)
+    Wc = be.debug["chain_weight"].clone()
+    ed.restore_to_original_model()
+    for r in data.data_with_img[:3]:
+        ed.edit_one_piece(deepcopy(r["requests"][0]))
+    Wg = vllm.model.get(wname).clone()
+    ed.restore_to_original_model()
+    W0 = vllm.model.get(wname)
+    rel = float((Wc - Wg).norm() / (Wg - W0).norm())
+    print(dtype, "chained edits: |W_batched - W_generic| / |W_generic - W0| = %.2e" % rel)
+    assert rel < (1e-4 if dtype == "fp32" else 5e-2)
+    assert len(res) == 3
