@@ -92,13 +92,31 @@ __device__ __forceinline__ float am_sum4(float x) {
 // DEVQA_ATTENTION_QB=2): 128-query tiles -- every K / V fragment read from LDS feeds two MFMAs (half the LDS traffic per query) and
 // long sequences need fewer workgroups that each stream the whole K / V (ViT-g, 257 tokens: 3 instead of 5 per image and head);
 // measured slower, see launch_attention_mfma.
+// blockIdx -> (sequence, head, q tile).  The hardware deals workgroups round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  The q
+// tiles of one (sequence, head) GROUP share K / V, and the heads of one sequence share cache lines (adjacent column slices of the same rows),
+// so a UNIT of `unit` consecutive groups stays on one XCD and consecutive units go to consecutive XCDs: unit = H (a whole sequence) when there
+// are enough sequences to balance 8 XCDs with them, else one group.  (Round 2 gave every XCD one contiguous RANGE of groups: in a mixed pack
+// -- LLaVA's decoder: 64 prefix sequences of 577 rows first, 192 probe texts of ~20 rows after -- two XCDs then carried all the long
+// sequences: 2649 us against 886 us for the same work, tools/debug/att_llava_bench.py.)
+// The grid is 8 * ceil(units / 8) * unit * q_tiles workgroups; ids past the last group exit.
+__device__ __forceinline__ int am_unit(int n_seq, int H) { return n_seq >= 32 ? H : 1; }
+__device__ __forceinline__ bool am_remap(int b, int q_tiles, int n_seq, int H, int& bid) {
+    const int unit = am_unit(n_seq, H);
+    const int per = unit * q_tiles;                 // workgroups of a unit
+    const int xcd = b & 7, idx = b >> 3;
+    const int ul = idx / per, in_u = idx - ul * per;
+    const int g = (ul * 8 + xcd) * unit + in_u / q_tiles;
+    bid = g * q_tiles + in_u % q_tiles;
+    return g < n_seq * H;
+}
+
 template <int DHP, int QB, bool DBUF, int NW = 4, int EXP = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attention_mfma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                              const bf16_t* __restrict__ k, int64_t ldk,
                                                              const bf16_t* __restrict__ v, int64_t ldv,
                                                              bf16_t* __restrict__ out, int64_t ldo,
                                                              const int32_t* __restrict__ seq_desc, int H, int dh,
-                                                             float scale, int causal, int q_tiles) {
+                                                             float scale, int causal, int q_tiles, int n_seq) {
     // bytes per LDS row: the padding makes 8 consecutive rows start in 8 different 4-bank groups (ds_read_b128 K fragments,
     // ds_write_b128 staging) and 4 consecutive rows in 4 different 8-bank groups (ds_read_b64_tr_b16 V fragments); 16 bytes do
     // that for 192- and 128-byte rows (used by the double-buffered instantiation, which needs the capacity: 52 KiB per workgroup
@@ -119,12 +137,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_mfma_kernel(const bf16_t
     __shared__ __attribute__((aligned(16))) unsigned char Ks2[(DBUF ? 2 : 1) * BUF];
     __shared__ __attribute__((aligned(16))) unsigned char Vs2[(DBUF ? 2 : 1) * BUF];
 
-    int bid = blockIdx.x;
-    {   // workgroups that share an XCD (blockIdx % 8) take a contiguous range of ids: the q tiles of one (sequence, head)
-        // then read their K/V through ONE L2 instead of up to q_tiles different ones
-        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-    }
+    int bid;
+    if (!am_remap(blockIdx.x, q_tiles, n_seq, H, bid)) return;
     const int qt = bid % q_tiles;
     const int h = (bid / q_tiles) % H;
     const int s = bid / (q_tiles * H);
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(64 * NW, ((NW == 8 && DHP <= 96) || SB) ? 4 : 2) vo
                                                                  const bf16_t* __restrict__ v, int64_t ldv,
                                                                  bf16_t* __restrict__ out, int64_t ldo,
                                                                  const int32_t* __restrict__ seq_desc, int H, int dh,
-                                                                 float scale, int causal, int q_tiles) {
+                                                                 float scale, int causal, int q_tiles, int n_seq) {
     constexpr int ROWB = 2 * DHP;          // bytes per key row in LDS (unpadded)
     constexpr int KS = DHP / 32;
     constexpr int DT = DHP / 16;
@@ -421,11 +435,8 @@ __global__ __launch_bounds__(64 * NW, ((NW == 8 && DHP <= 96) || SB) ? 4 : 2) vo
     __shared__ __attribute__((aligned(1024))) unsigned char Ks2[(SB ? 1 : 2) * IMG];
     __shared__ __attribute__((aligned(1024))) unsigned char Vs2[(SB ? 1 : 2) * IMG];
 
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-    }
+    int bid;
+    if (!am_remap(blockIdx.x, q_tiles, n_seq, H, bid)) return;
     const int qt = bid % q_tiles;
     const int h = (bid / q_tiles) % H;
     const int s = bid / (q_tiles * H);
@@ -895,6 +906,10 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     // 128-query tiles (8 waves) halve the K / V staging per query, which is what bounds the kernel on long sequences (ViT-g, T = 256:
     // 133 -> 116 us); short sequences fill 64-query tiles better (T = 128: 43.6 vs 47.3 us)
     int dma_nw = max_q_len >= 224 ? 8 : 4;
+    // dh 128, causal (the LLaMA decoders of LLaVA / MiniGPT-4: 577-row image prefixes): 64-query tiles of 4 waves measured 565 us against 685 us for
+    // 128-query tiles of 8 on the prefix pack of a 16-cycle batch (tools/debug/att_llava_bench.py) -- a causal tile's K / V range ends at its last
+    // query, so the larger tile stages more keys per query than it saves
+    if (dhp == 128 && (causal & 1)) dma_nw = 4;
     if (env.nw == 8 || env.nw == 4) dma_nw = env.nw;
     // causal packs of short sequences (decoder probes): 32-query tiles of two waves on ONE LDS-DMA image (attention_mfma_dma_kernel<D, 2, true>);
     // non-causal short-query calls (Q-Former: 32 queries over 257 keys) keep the register-staged kernel
@@ -907,16 +922,17 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     const bool dma_short = causal && !dma && !dma_env && nw == 4 && qb == 1 && !dbuf && exp_id == 0 && !nw_env && max_q_len <= 64 && short_ok;
     const int qt = dma_short ? 32 : dma ? 16 * dma_nw : 16 * nw * qb;
     const int q_tiles = (max_q_len + qt - 1) / qt;
-    const long grid = (long)n_seq * H * q_tiles;
+    const long unit = n_seq >= 32 ? H : 1;                             // am_remap / am_unit: units padded to a multiple of the 8 XCDs
+    const long grid = ((((long)n_seq * H + unit - 1) / unit + 7) / 8) * 8 * unit * q_tiles;
     DEVQA_CHECK_SHAPE(grid < 2147483647L, "attention: grid too large");
     hipStream_t st = (hipStream_t)stream;
 #ifdef DEVQA_EXPERIMENTS
 #define LAUNCH_EXP()                                                                                                   \
     do {                                                                                                               \
-        if (exp_id == 1) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
-        if (exp_id == 2) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
-        if (exp_id == 3) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
-        if (exp_id == 4) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles); \
+        if (exp_id == 1) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq); \
+        if (exp_id == 2) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq); \
+        if (exp_id == 3) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq); \
+        if (exp_id == 4) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq); \
     } while (0)
 #else
 #define LAUNCH_EXP() do { } while (0)     /* exp_id is always 0 in a product build */
@@ -925,28 +941,28 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     do {                                                                                                               \
         if (qb == 2)                                                                                                   \
             hipLaunchKernelGGL((attention_mfma_kernel<D, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
-                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                     \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                     \
         else if (dbuf)                                                                                                 \
             hipLaunchKernelGGL((attention_mfma_kernel<(D <= 96 ? D : 96), 1, true>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, \
-                               k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                     \
+                               k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                     \
         else if (dma_short)                                                                                            \
             hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 2, true>), dim3((unsigned)grid), dim3(128), 0, st, q, ldq, k, ldk, v, ldv, \
-                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                     \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                     \
         else if (dma) {                                                                                                \
             if (dma_nw == 8)                                                                                           \
                 hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 8>), dim3((unsigned)grid), dim3(512), 0, st, q, ldq, k, ldk, v, ldv, \
-                                   out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                 \
+                                   out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                 \
             else                                                                                                       \
                 hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
-                                   out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                 \
+                                   out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                 \
         } else if (exp_id >= 1 && exp_id <= 4 && D == 96) {                                                              \
             LAUNCH_EXP();                                                                                              \
         } else if (nw == 6)                                                                                            \
             hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 6>), dim3((unsigned)grid), dim3(384), 0, st, q, ldq, k, ldk, v, ldv, \
-                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                     \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                     \
         else                                                                                                           \
             hipLaunchKernelGGL((attention_mfma_kernel<D, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
-                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles);                                     \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                     \
     } while (0)
     // FLOPs as launched (4 Tq Tk dh per head with Tq = Tk = max_q_len: an upper bound for ragged / causal batches, exact for ViT)
     const int ph = devqa_prof_begin(DEVQA_PROF_ATTENTION, st);
