@@ -94,13 +94,19 @@ __device__ __forceinline__ float am_sum4(float x) {
 // measured slower, see launch_attention_mfma.
 // blockIdx -> (sequence, head, q tile).  The hardware deals workgroups round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  The q
 // tiles of one (sequence, head) GROUP share K / V, and the heads of one sequence share cache lines (adjacent column slices of the same rows),
-// so a UNIT of `unit` consecutive groups stays on one XCD and consecutive units go to consecutive XCDs: unit = H (a whole sequence) when there
-// are enough sequences to balance 8 XCDs with them, else one group.  (Round 2 gave every XCD one contiguous RANGE of groups: in a mixed pack
+// so a UNIT of `unit` consecutive groups stays on one XCD and consecutive units go to consecutive XCDs: a unit is n_seq / 64 whole sequences
+// (~64 units per launch: enough to balance 8 XCDs, and the sequences of one edit+eval cycle -- an image prefix and the texts that read its K / V
+// -- stay together: dealing single sequences round-robin cost the BLIP-2 + MEND_VL config 13 %), one group when there are few sequences.  (Round 2 gave every XCD one contiguous RANGE of groups: in a mixed pack
 // -- LLaVA's decoder: 64 prefix sequences of 577 rows first, 192 probe texts of ~20 rows after -- two XCDs then carried all the long
 // sequences: 2649 us against 886 us for the same work, tools/debug/att_llava_bench.py.)
 // The grid is 8 * ceil(units / 8) * unit * q_tiles workgroups; ids past the last group exit.
-__device__ __forceinline__ int am_unit(int n_seq, int H) { return n_seq >= 32 ? H : 1; }
+__host__ __device__ __forceinline__ int am_unit(int n_seq, int H) { return n_seq >= 32 ? (n_seq >= 128 ? n_seq / 64 : 1) * H : 1; }
 __device__ __forceinline__ bool am_remap(int b, int q_tiles, int n_seq, int H, int& bid) {
+    if (n_seq < 0) {        // (-n_seq: the round-2 mapping, one contiguous range of ids per XCD; grid = groups * q_tiles exactly)
+        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = b & 7, idx = b >> 3;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+        return true;
+    }
     const int unit = am_unit(n_seq, H);
     const int per = unit * q_tiles;                 // workgroups of a unit
     const int xcd = b & 7, idx = b >> 3;
@@ -823,7 +829,7 @@ __global__ __launch_bounds__(512, 1) void attention_mfma_resident_kernel(const b
 // Variant switches (A/B measurements and the variant tests): read from the environment ONCE, and again only when the host asks
 // (devqa_attention_reload_env; lib.attention re-reads when it sees a DEVQA_ATTENTION_* variable change).  -1 = unset.
 namespace {
-struct AttnEnv { int resident = -1, qb = -1, dbuf = -1, nw = -1, exp = -1, dma = -1, shrt = -1; };
+struct AttnEnv { int resident = -1, qb = -1, dbuf = -1, nw = -1, exp = -1, dma = -1, shrt = -1, xcd = -1; };
 AttnEnv g_attn_env;
 std::atomic<int> g_attn_env_ready{0};
 std::mutex g_attn_env_mu;
@@ -837,6 +843,7 @@ void attn_env_load() {
     e.nw = env_int("DEVQA_ATTENTION_NW");
     e.dma = env_int("DEVQA_ATTENTION_DMA");
     e.shrt = env_int("DEVQA_ATTENTION_SHORT");
+    e.xcd = env_int("DEVQA_ATTENTION_XCD");
 #ifdef DEVQA_EXPERIMENTS
     e.exp = env_int("DEVQA_ATTENTION_EXP");      // timing experiments (WRONG results): compiled in only with -DDEVQA_EXPERIMENTS
 #endif
@@ -922,17 +929,24 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     const bool dma_short = causal && !dma && !dma_env && nw == 4 && qb == 1 && !dbuf && exp_id == 0 && !nw_env && max_q_len <= 64 && short_ok;
     const int qt = dma_short ? 32 : dma ? 16 * dma_nw : 16 * nw * qb;
     const int q_tiles = (max_q_len + qt - 1) / qt;
-    const long unit = n_seq >= 32 ? H : 1;                             // am_remap / am_unit: units padded to a multiple of the 8 XCDs
-    const long grid = ((((long)n_seq * H + unit - 1) / unit + 7) / 8) * 8 * unit * q_tiles;
+    // workgroup -> XCD mapping (am_remap): sequence units for CAUSAL packs with LONG sequences (balance: the LLaMA decoders' mixed packs of
+    // 577-row prefixes and 20-row texts), the contiguous ranges of round 2 otherwise -- uniform packs (ViT: every sequence costs the same, ranges
+    // keep neighbouring images' lines in one L2) and packs of short sequences (a cycle's texts read their image prefix's K / V through the same
+    // L2).  Measured in situ on one box: units everywhere cost the BLIP-2 + FT_VL bench 0.6 % and the MEND_VL config 8 %.
+    // DEVQA_ATTENTION_XCD=0 / 1 forces ranges / units.
+    const bool units = env.xcd == -1 ? ((causal & 1) && max_q_len >= 224) : env.xcd != 0;
+    const long unit = am_unit(n_seq, H);
+    const long grid = units ? ((((long)n_seq * H + unit - 1) / unit + 7) / 8) * 8 * unit * q_tiles : (long)n_seq * H * q_tiles;
+    const int n_seq_arg = units ? n_seq : -n_seq;
     DEVQA_CHECK_SHAPE(grid < 2147483647L, "attention: grid too large");
     hipStream_t st = (hipStream_t)stream;
 #ifdef DEVQA_EXPERIMENTS
 #define LAUNCH_EXP()                                                                                                   \
     do {                                                                                                               \
-        if (exp_id == 1) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq); \
-        if (exp_id == 2) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq); \
-        if (exp_id == 3) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq); \
-        if (exp_id == 4) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq); \
+        if (exp_id == 1) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg); \
+        if (exp_id == 2) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg); \
+        if (exp_id == 3) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg); \
+        if (exp_id == 4) hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg); \
     } while (0)
 #else
 #define LAUNCH_EXP() do { } while (0)     /* exp_id is always 0 in a product build */
@@ -941,28 +955,28 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     do {                                                                                                               \
         if (qb == 2)                                                                                                   \
             hipLaunchKernelGGL((attention_mfma_kernel<D, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
-                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                     \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg);                                     \
         else if (dbuf)                                                                                                 \
             hipLaunchKernelGGL((attention_mfma_kernel<(D <= 96 ? D : 96), 1, true>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, \
-                               k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                     \
+                               k, ldk, v, ldv, out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg);                     \
         else if (dma_short)                                                                                            \
             hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 2, true>), dim3((unsigned)grid), dim3(128), 0, st, q, ldq, k, ldk, v, ldv, \
-                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                     \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg);                                     \
         else if (dma) {                                                                                                \
             if (dma_nw == 8)                                                                                           \
                 hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 8>), dim3((unsigned)grid), dim3(512), 0, st, q, ldq, k, ldk, v, ldv, \
-                                   out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                 \
+                                   out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg);                                 \
             else                                                                                                       \
                 hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 4>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
-                                   out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                 \
+                                   out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg);                                 \
         } else if (exp_id >= 1 && exp_id <= 4 && D == 96) {                                                              \
             LAUNCH_EXP();                                                                                              \
         } else if (nw == 6)                                                                                            \
             hipLaunchKernelGGL((attention_mfma_kernel<96, 1, false, 6>), dim3((unsigned)grid), dim3(384), 0, st, q, ldq, k, ldk, v, ldv, \
-                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                     \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg);                                     \
         else                                                                                                           \
             hipLaunchKernelGGL((attention_mfma_kernel<D, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, \
-                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq);                                     \
+                               out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg);                                     \
     } while (0)
     // FLOPs as launched (4 Tq Tk dh per head with Tq = Tk = max_q_len: an upper bound for ragged / causal batches, exact for ViT)
     const int ph = devqa_prof_begin(DEVQA_PROF_ATTENTION, st);
