@@ -12,10 +12,18 @@ w - w0, model restored, delta then added in place).  What changes is how a step 
   * gradient + AdamW + the next forward's fc2 rows are ONE HBM sweep over the matrix
     (devqa_ft_adamw_step), the rank-L gradient is never materialised.
 
-Supported edit target on this path: the LAST decoder layer's FFN output matrix (`...decoder.layers.<last>.fc2.weight`
-for BLIP-2-OPT, `language_model.model.layers.<last>.mlp.down_proj.weight` for LLaVA -- what every shipped FT_VL
-config selects: R/configs/ft_vl/{blip2-opt-2.7b,llava-v1.5-7b}.yaml:2,8).  Other targets would need a full
-backward pass through the network and raise NotImplementedError.
+Two execution forms behind the same `execute_ft`:
+  * FAST (the benchmarked one): the edit target is the LAST decoder layer's FFN output matrix (`...decoder.layers.<last>.fc2.weight`
+    for BLIP-2-OPT, `language_model.model.layers.<last>.mlp.down_proj.weight` for LLaVA -- what every shipped FT_VL config
+    selects: R/configs/ft_vl/{blip2-opt-2.7b,llava-v1.5-7b}.yaml:2,8); BatchedEditEval builds on it.
+  * GENERAL (round 3): ANY set of decoder-layer parameters the reference's substring rule selects (ft_vl.py:31-36 -- several layers, fc1,
+    attention projections, LayerNorms, biases): the layers below the lowest selected one run once, every step then runs the remaining
+    layers with saved activations, the head on the label rows, the explicit backward of the engine with parameter gradients
+    (engine.decoder_backward(grads=...), the machinery of LTE_VL's training) and one Adam(W) step per selected tensor
+    (devqa_adam_step) on its fp32 master.  Pinned by the reference's own FTvl on three such selections
+    (tools/make_goldens_ft_general.py, tests/test_ft_general_gpu.py).
+Targets outside the language model's decoder layers (vision tower, Q-Former, embeddings, final norm) would need a backward pass
+through those parts and raise NotImplementedError.
 """
 from copy import deepcopy
 from dataclasses import dataclass
@@ -43,6 +51,12 @@ class FTvlConfig(BaseConfig):
 
 
 LOSS_FLOOR = 1e-2  # ft_vl.py:131,145
+
+
+def VLLM_HOST(t):
+    """host copy of a label tensor: the original the wrapper attached (no synchronisation), else a transfer"""
+    h = getattr(t, "_devqa_host", None)
+    return h if h is not None else t.cpu()
 
 
 class FTvl(VLLMBaseEditor):
@@ -78,8 +92,12 @@ class FTvl(VLLMBaseEditor):
         with torch.no_grad():
             for w_name, upd in deltas.items():
                 w = nethook.get_parameter(self.vllm.model, w_name)
-                lib.delta_op(1, w, None, upd)   # w[...] += upd_matrix (ft_vl.py:60-61)
+                if w.numel() % 4 == 0:
+                    lib.delta_op(1, w.data.reshape(-1), None, upd.contiguous().reshape(-1))   # w[...] += upd_matrix (ft_vl.py:60-61)
+                else:
+                    w.data.add_(upd)
                 self.vllm.model.mark_dirty(w_name)  # HIP wrote in place: the bf16 shadow is stale
+            self.vllm.model.refresh_shadows()       # (row blocks of fused operands are read through the fused buffer: refresh now)
 
     # ---------------------------------------------------------------------------------------
     def _edit_target(self):
@@ -113,11 +131,124 @@ class FTvl(VLLMBaseEditor):
             resid = resid + eng.edit_bias()
         return a_rows, resid.contiguous(), torch.tensor(labels, dtype=torch.int32, device=eng.dev)
 
+    # ---------------------------------------------------------------------------------------
+    # GENERAL form: any decoder-layer parameters (see the module docstring)
+    # ---------------------------------------------------------------------------------------
+    def _general_plan(self, names):
+        """-> (lowest selected layer, {selected name: (gradient key, row slice or None)}); raises NotImplementedError for a selection the
+        explicit backward does not reach."""
+        import re
+        eng, model = self.vllm.engine, self.vllm.model
+        if not hasattr(eng, "train_params") or not hasattr(eng, "decoder_backward"):
+            raise NotImplementedError("native FT_VL: this engine has no parameter-gradient backward")
+        keys = eng.train_params()
+        lm = eng.LM_MODULE + "."
+        plan, lo = {}, None
+        for n in names:
+            m = re.search(r"\.layers\.(\d+)\.", n)
+            if not n.startswith(lm) or m is None:
+                raise NotImplementedError("native FT_VL edits decoder-layer parameters of the language model; config selects %s" % n)
+            fs = model._fused_slot(n)
+            if fs is not None:          # a row block of a fused operand (q / k / v, gate / up)
+                group, slot, _n = fs
+                key = "derived.%s.%s" % (group, n.rsplit(".", 1)[1])
+                rows = model.get(n).shape[0]
+                plan[n] = (key, slice(slot * rows, (slot + 1) * rows))
+            else:
+                key = n
+                plan[n] = (key, None)
+            if key not in keys:
+                raise NotImplementedError("native FT_VL: no gradient path for %s" % n)
+            layer = int(m.group(1))
+            lo = layer if lo is None else min(lo, layer)
+        return lo, plan
+
+    def _execute_ft_general(self, requests, names):
+        vllm, eng, model, cfg = self.vllm, self.vllm.engine, self.vllm.model, self.cfg
+        dev = eng.dev
+        lo, plan = self._general_plan(names)
+        n_layers = eng.t["num_hidden_layers"]
+        params = {n: nethook.get_parameter(model, n) for n in names}          # fp32 masters (promote_to_fp32 in __init__)
+        w0 = {n: p_.detach().clone() for n, p_ in params.items()}
+        mom = {n: torch.zeros_like(p_.data) for n, p_ in params.items()}
+        var = {n: torch.zeros_like(p_.data) for n, p_ in params.items()}
+        tp = eng.train_params()
+        layer_of = lambda k: int(k.split(".")[2]) if k.startswith("derived.") else int(k.split(".layers.")[1].split(".")[0])   # noqa: E731
+        G = {k: torch.zeros(t_.shape, dtype=torch.float32, device=dev) for k, t_ in tp.items()
+             if (".layers." in k or k.startswith("derived.")) and layer_of(k) >= lo}
+        bs = cfg.batch_size
+        chunks = [requests[i:i + bs] for i in range(0, len(requests), bs)]
+        clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else None
+        t_adam = 0
+        self.last_losses = []
+        # the layers below the lowest selected one are frozen: their output rows are computed once per chunk
+        prepared = []
+        for c in chunks:
+            (x, vt), y, m = vllm.prompts_imgs_target_to_xym([r["prompt"] for r in c], [r["image"] for r in c], [r["target_new"] for r in c])
+            ps = eng.pack_from_embeds(x["inputs_embeds"], x["attention_mask"])
+            if lo > 0:
+                eng.decoder_layers(ps, upto_layer=lo - 1)
+            B, T = x["inputs_embeds"].shape[:2]
+            L = y.shape[1]
+            mh, yh = VLLM_HOST(m), VLLM_HOST(y)
+            rows = [b * T + (T - L) + j for b in range(B) for j in range(L) if int(mh[b, j]) != 0]
+            labels = [int(yh[b, j]) for b in range(B) for j in range(L) if int(mh[b, j]) != 0]
+            prepared.append((ps, ps.x.clone(), lib.h2d(rows, torch.int32, dev), lib.h2d(labels, torch.int32, dev), len(rows), len(c)))
+        for it in range(cfg.num_steps):
+            loss_sum, cnt = 0.0, 0
+            for ps, x_lo, idx, labels, k, n_items in prepared:
+                model.refresh_shadows()                              # compute-dtype copies of the masters (incl. row blocks of fused operands)
+                eng.__dict__.pop("_wt_cache", None)                  # transposed operands of the backward follow the weights
+                ps.x = x_lo.clone()
+                save = {"layers": set(range(lo, n_layers))}
+                x_fin, _ = eng.decoder_layers(ps, save=save, first_layer=lo)
+                pre_ln = lib.gather_rows(x_fin, idx)
+                logits = eng.lm_head(pre_ln)
+                coef = torch.full((k,), 1.0 / k, dtype=torch.float32, device=dev)
+                _, nll, dlog = lib.vocab_rows(logits, labels, coef, want_argmax=False, want_nll=True, want_dlogits=True, dlogits_dtype=eng.adt)
+                loss = float(nll.mean().item())                      # the reference syncs here too (ft_vl.py:129-131)
+                self.last_losses.append(loss)
+                loss_sum += loss * n_items
+                cnt += n_items
+                if loss >= LOSS_FLOOR:
+                    for g in G.values():
+                        g.zero_()
+                    dH = lib.gemm_rows_longk(dlog, model.embed_T)
+                    dxr = eng.final_norm_bwd(pre_ln, dH)
+                    dx = torch.zeros_like(x_fin)
+                    dx.index_copy_(0, idx.long(), dxr)
+                    eng.decoder_backward(ps, save, dx, set(), grads=G)
+                    t_adam += 1
+                    for n, p_ in params.items():
+                        key, sl = plan[n]
+                        g = G[key] if sl is None else G[key][sl]
+                        if cfg.weight_decay:
+                            p_.data.mul_(1.0 - cfg.lr * cfg.weight_decay)         # AdamW: decoupled decay (torch.optim.AdamW)
+                        lib.adam_step_(p_.data.reshape(-1), g.reshape(-1).contiguous(), mom[n].reshape(-1), var[n].reshape(-1), cfg.lr, t_adam)
+                        model.mark_dirty(n)
+                if clamp is not None:                                            # ft_vl.py:135-141
+                    for n, p_ in params.items():
+                        p_.data.copy_(torch.max(torch.min(p_.data, w0[n] + clamp), w0[n] - clamp))
+                        model.mark_dirty(n)
+            if loss_sum / cnt < LOSS_FLOOR:
+                break
+        deltas = {}
+        for n, p_ in params.items():
+            deltas[n] = (p_.data - w0[n])
+            p_.data.copy_(w0[n])                                                  # the model is restored; edit_batch adds the deltas
+            model.mark_dirty(n)
+        model.refresh_shadows()
+        eng.__dict__.pop("_wt_cache", None)
+        return deltas
+
     def execute_ft(self, requests: List[Dict]) -> Dict[str, torch.Tensor]:
         requests = deepcopy(requests)
         for r in requests:
             if r["target_new"][0] != " ":
                 r["target_new"] = " " + r["target_new"]  # ft_vl.py:73-75
+        names = self._selected_names()
+        if names != [self.vllm.engine.edit_target()]:
+            return self._execute_ft_general(requests, names)
         wname = self._edit_target()
         eng = self.vllm.engine
         w0 = nethook.get_parameter(self.vllm.model, wname)

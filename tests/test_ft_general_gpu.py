@@ -1,0 +1,65 @@
+"""GPU: FT_VL on edit targets OTHER than the last layer's fc2 matrix (the GENERAL form of editor/vllm_editors/ft_vl/ft_vl.py) against the
+REFERENCE's own FTvl.execute_ft on the same selections (tools/make_goldens_ft_general.py): fc1 of two layers; a q_proj weight + bias (a
+row block of the fused q|k|v operand here); six tensors of one layer incl. a LayerNorm.  Per-step losses, step counts, every delta; then the
+plugin contract: edit_one_piece adds the deltas in place, restore_to_original_model brings every tensor (and the GEMM operands) back."""
+import json
+import os
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = {"fp32": dict(loss=2e-4, delta=2e-3), "bf16": dict(loss=5e-2, delta=None)}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_ft_general_targets_vs_reference(gold_dir, in_gold_dir, mode):
+    import devqa_amd  # noqa: F401
+    from devqa_amd.editor.vllm_editors.ft_vl.ft_vl import FTvl, FTvlConfig
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    j = json.load(open(os.path.join(gold_dir, "tiny_ft_general_goldens.json")))
+    z = np.load(os.path.join(gold_dir, "tiny_ft_general_goldens.npz"))
+    tol = TOL[mode]
+    for case in j["cases"]:
+        vllm = BLIP2OPTForEdit(os.path.join(gold_dir, "tiny_blip2"), "cuda:0", dtype=mode)
+        cfg = FTvlConfig(edit_model_name="blip2-opt-2.7b", rewrite_module_tmp=case["rewrite_module_tmp"], layers=case["layers"], num_steps=25, lr=1e-3,
+                         weight_decay=0, norm_constraint=False, batch_size=1)
+        ed = FTvl(vllm, cfg, "cuda:0")
+        assert sorted(ed._selected_names()) == case["names"]                 # the substring rule selects the reference's tensors
+        with pytest.raises(NotImplementedError):
+            ed._edit_target()                                                # not the fast form: the batched engine declines, the generic path runs
+        r0 = case["requests"][0]["request"]
+        (x, vt), y, m = vllm.prompts_imgs_target_to_xym([r0["prompt"]], [r0["image"]], [r0["target_new"]])
+        base = vllm.get_llm_outpt(x, vt).logits.clone()
+        for rq in case["requests"]:
+            deltas = ed.execute_ft([deepcopy(rq["request"])])
+            n = len(ed.last_losses)
+            ref = np.asarray(rq["losses"])
+            mm = min(n, rq["steps"])
+            err = float(np.abs(np.asarray(ed.last_losses[:mm]) - ref[:mm]).max() / max(ref.max(), 1.0))
+            worst = 0.0
+            for name in case["names"]:
+                gold = z["%s_%d_%s" % (case["tag"], rq["record"], name)]
+                got = deltas[name].float().cpu().numpy()
+                assert got.shape == gold.shape
+                rel = float(np.linalg.norm(got - gold) / max(np.linalg.norm(gold), 1e-30))
+                worst = max(worst, rel)
+                if tol["delta"] is not None:
+                    assert rel < tol["delta"], (case["tag"], name, rel)
+                else:   # bf16: Adam moves every element by ~ +-lr whatever the gradient's size: compare norm and direction
+                    cos = float((got * gold).sum() / (np.linalg.norm(got) * np.linalg.norm(gold) + 1e-30))
+                    assert cos > 0.9 and abs(np.linalg.norm(got) / np.linalg.norm(gold) - 1) < 0.1, (case["tag"], name, cos)
+            print(mode, case["tag"], "record", rq["record"], "steps %d (ref %d)  loss err %.2e  worst delta rel_l2 %.2e" % (n, rq["steps"], err, worst))
+            assert err < tol["loss"]
+            if mode == "fp32":
+                assert n == rq["steps"]
+            # execute_ft leaves the model pristine
+            assert torch.equal(vllm.get_llm_outpt(x, vt).logits, base)
+        # plugin contract: the edit is applied in place and restored
+        ed.edit_one_piece(deepcopy(case["requests"][0]["request"]))
+        edited = vllm.get_llm_outpt(x, vt).logits
+        assert float((edited - base).abs().max()) > 1e-3 * float(base.abs().max())
+        ed.restore_to_original_model()
+        assert torch.equal(vllm.get_llm_outpt(x, vt).logits, base)
