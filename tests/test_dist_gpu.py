@@ -73,3 +73,34 @@ def test_bench_walks_the_distributed_branches_with_one_rank():
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
     assert {"roofline", "cpu_baseline", "config"} <= set(j) and j["roofline"]["bound"] == "mfma"
+    assert j["rccl_ranks"] == 1 and j["strong"]["scaling"] == "strong" and j["strong"]["cycles_total"] == 1000
+
+
+def test_two_ranks_share_the_gpu_strong_stream_equals_one_rank(tmp_path):
+    """A two-rank REHEARSAL of `bench.py --gpus 2 --scaling strong` with REAL edit+eval cycles on the one GPU of the test box (collectives
+    over gloo on the host, both ranks on cuda:0: DEVQA_DIST_BACKEND / DEVQA_BENCH_SHARE_GPU; RCCL refuses two ranks on one device): launcher,
+    block partition, every rank's block cut into >= 2 pipelined sub-batches, both scaling legs, the gather -- and the gathered score rows of
+    the 2-rank run equal the 1-rank run of the same 24-cycle stream: accuracies (12 columns), executed FT steps and final losses, although
+    the batch compositions differ (12 + 12 in 6 + 6 against 24 in 12 + 12)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = {}
+    for n in (1, 2):
+        f = str(tmp_path / ("rows%d.npy" % n))
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(DEVQA_DIST_BACKEND="gloo", DEVQA_BENCH_SHARE_GPU="1")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--cycles-per-step", "12",
+                            "--layers", "2,2,2", "--no-cpu-baseline", "--no-hbm-micro", "--ffn", "sparse", "--scaling", "strong", "--strong-cycles", "24",
+                            "--dump-rows", f], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["n_gpus"] == n and j["scaling"] == "strong" and j["config"]["cycles_total"] == 24 and j["weak"]["scaling"] == "weak"
+        assert len(j["weak"]["batches_rank0"]) == 1
+        rows[n] = np.load(f)
+    a, b = rows[1], rows[2]
+    assert a.shape == b.shape == (24, 16) and [int(v) for v in b[:, 0]] == list(range(24))
+    np.testing.assert_array_equal(a[:, :13], b[:, :13])          # sample id + the 12 accuracies
+    np.testing.assert_array_equal(a[:, 14], b[:, 14])            # executed FT steps
+    np.testing.assert_allclose(a[:, 15], b[:, 15], rtol=2e-2, atol=1e-3)      # final loss (bf16 batch-composition noise)
