@@ -16,6 +16,12 @@
 // buffers this is the deepest prefetch that satisfies both (derivation in DESIGN.md "256x256 ping-pong GEMM").
 #include "common.h"
 
+#ifdef PP_TIMING   /* hipcc -DPP_TIMING gemm_bf16_pp.hip -o build/pp_timing: where a tile's time goes (debug builds only) */
+#define PP_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(g.ws)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PP_STAMP(i) do { } while (0)
+#endif
+
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -313,6 +319,7 @@ __device__ __forceinline__ void pp_mainloop(const PPArgs& g, unsigned char* smem
         pp_vmcnt<4>();
     }
     __builtin_amdgcn_s_barrier();
+    PP_STAMP(1);
     if constexpr (BAL) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -539,6 +546,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
     float4_t acc[8][4];
     const int nk = g.K / PP_BK;
     const int tid = threadIdx.x;
+    PP_STAMP(0);
     if constexpr (!SK) {   // one whole tile per workgroup: the default
         const int bid = blockIdx.x, nwg = g.dp_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         int tile_m, tile_n;
@@ -550,8 +558,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
             return;
         }
         pp_mainloop<BAL>(g, smem, tile_m * PP_BM, tile_n * PP_BN, 0, nk, acc);
+        PP_STAMP(2);
         if (g.bf16_fast) pp_epilogue_bf16<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
         else pp_epilogue<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_STAMP(3);
         return;
     }
     // Every workgroup walks a range [it, it1) of the (tile, K-tile) iteration space.  A data-parallel workgroup owns
@@ -680,3 +691,53 @@ int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_
     }
     return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown activation %d", act);
 }
+
+#ifdef PP_TIMING
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+int devqa_fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); return code; }
+int main() {
+    struct Sh { const char* name; int M, N, K; int resid; } shapes[] = {{"qkv", 65536, 4224, 1408, 0}, {"proj", 65536, 1408, 1408, 1}, {"fc2", 65536, 1408, 6144, 1},
+                                                                       {"opt_fc1", 20480, 10240, 2560, 0}};
+    for (auto& sh : shapes) {
+        bf16_t *A, *W, *ob; float *of, *bias; unsigned long long* st;
+        hipMalloc(&A, (size_t)sh.M * sh.K * 2); hipMalloc(&W, (size_t)sh.N * sh.K * 2); hipMalloc(&ob, (size_t)sh.M * sh.N * 2);
+        hipMalloc(&of, (size_t)sh.M * sh.N * 4); hipMalloc(&bias, sh.N * 4);
+        const int T = ((sh.M + 255) / 256) * ((sh.N + 255) / 256);
+        hipMalloc(&st, (size_t)T * 64);
+        std::vector<unsigned short> h((size_t)sh.M * sh.K);
+        unsigned x = 1;
+        for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3c00 + ((x >> 9) & 0x3ff) - ((x >> 3) & 0x8000)); }
+        hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        h.resize((size_t)sh.N * sh.K);
+        for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3800 + ((x >> 9) & 0x3ff) - ((x >> 3) & 0x8000)); }
+        hipMemcpy(W, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        hipMemset(bias, 0, sh.N * 4); hipMemset(of, 0, (size_t)sh.M * sh.N * 4);
+        PPArgs g;
+        g.A = A; g.lda = sh.K; g.W = W; g.ldw = sh.K; g.bias = bias; g.M = sh.M; g.N = sh.N; g.K = sh.K; g.alpha = 1.f;
+        g.residual = sh.resid ? of : nullptr; g.out_bf16 = sh.resid ? nullptr : ob; g.out_f32 = sh.resid ? of : nullptr; g.ldc = sh.N;
+        g.tiles_m = (sh.M + 255) / 256; g.tiles_n = (sh.N + 255) / 256; g.group_m = 4; g.dp_tiles = T; g.sk_wgs = 0; g.sk_per = 1; g.sk_max_seg = 1;
+        g.ws = (float*)st; g.counters = nullptr; g.bf16_fast = !sh.resid; g.gelu_poly = 0;
+        g.half_n = sh.N - (g.tiles_n - 1) * 256 <= 128;
+        for (int rep = 0; rep < 5; ++rep) launch_pp_k<DEVQA_ACT_NONE, false>(g, nullptr);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> hs((size_t)T * 8);
+        hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> pro, loop, epi;
+        for (int t = 0; t < T; ++t) {
+            if ((t % g.tiles_n) == g.tiles_n - 1 && g.half_n) continue;      // full tiles only
+            pro.push_back((double)(hs[t * 8 + 1] - hs[t * 8 + 0]));
+            loop.push_back((double)(hs[t * 8 + 2] - hs[t * 8 + 1]));
+            epi.push_back((double)(hs[t * 8 + 3] - hs[t * 8 + 2]));
+        }
+        auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        const double p = med(pro), l = med(loop), e = med(epi);
+        printf("%-8s M=%d N=%d K=%d: median shader cycles per tile: prologue %.0f (%.1f%%)  main loop %.0f (%.1f%%)  epilogue %.0f (%.1f%%)  | MFMA issue floor %d\n",
+               sh.name, sh.M, sh.N, sh.K, p, 100 * p / (p + l + e), l, 100 * l / (p + l + e), e, 100 * e / (p + l + e), sh.K / 64 * 2048);
+        hipFree(A); hipFree(W); hipFree(ob); hipFree(of); hipFree(bias); hipFree(st);
+    }
+    return 0;
+}
+#endif
