@@ -422,6 +422,49 @@ __device__ __forceinline__ int am_swz(int R) {
 // SB (single-buffered, NW = 2: 32-query tiles) is the form for packs of SHORT sequences (the decoder pack of the edit+eval path: 32 image
 // tokens or <= ~25 text tokens per sequence behind a 32-key visible prefix, one or two chunks each): nothing to overlap a second image with,
 // so one image (24 KiB at dh 80: 6 workgroups per CU instead of 3) and two waves per (sequence, head) double the pairs in flight per CU.
+// Four V^T fragments (ds_read_b64_tr_b16 at byte offsets O0..O3 from one lane address) as ONE asm block that ends with its own lgkmcnt(0).
+// Why not the builtin: the compiler cannot tell which LDS-DMA write a transposing read may alias and puts `s_waitcnt vmcnt(0)` in front of
+// every one of them -- the P.V half of a round then waits for the chunk just put in flight, i.e. the prefetch overlapped the S = K.Q^T
+// half only (seen in the ISA of every instantiation of the kernel below; the plain ds_read_b128 K reads get no such wait).  An asm read is
+// invisible to that pass; the DMA / read ordering is the kernel's own (vmcnt + barrier per round).
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void am_tr_read4(uint32_t addr, short4_t& a, short4_t& b, short4_t& c, short4_t& d) {
+    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%5\n\t"
+                 "ds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+                 "ds_read_b64_tr_b16 %2, %4 offset:%7\n\t"
+                 "ds_read_b64_tr_b16 %3, %4 offset:%8\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+                 : "v"(addr), "n"(O0), "n"(O1), "n"(O2), "n"(O3)
+                 : "memory");
+}
+template <int O0, int O1>
+__device__ __forceinline__ void am_tr_read2(uint32_t addr, short4_t& a, short4_t& b) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\t"
+                 "ds_read_b64_tr_b16 %1, %2 offset:%4\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(addr), "n"(O0), "n"(O1)
+                 : "memory");
+}
+// lane id behind an asm the optimiser cannot hoist: per-DMA row / column arithmetic stays in the chunk loop instead of becoming (spilled) lane constants
+__device__ __forceinline__ int am_lane_opaque() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+// dot product of 8 bf16 pairs (a MFMA operand fragment against 16 bytes of a row) on the VALU, fp32 accumulate
+__device__ __forceinline__ float am_dot8(const short8_t& a, const uint4& b, float acc) {
+    const uint4 ua = *reinterpret_cast<const uint4*>(&a);
+    const uint32_t aw[4] = {ua.x, ua.y, ua.z, ua.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc = fmaf(__uint_as_float(aw[i] << 16), __uint_as_float(bw[i] << 16), acc);
+        acc = fmaf(__uint_as_float(aw[i] & 0xffff0000u), __uint_as_float(bw[i] & 0xffff0000u), acc);
+    }
+    return acc;
+}
+
 template <int DHP, int NW, bool SB = false>
 __global__ __launch_bounds__(64 * NW, ((NW == 8 && DHP <= 96) || SB) ? 4 : 2) void attention_mfma_dma_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                  const bf16_t* __restrict__ k, int64_t ldk,
@@ -624,15 +667,36 @@ __global__ __launch_bounds__(64 * NW, ((NW == 8 && DHP <= 96) || SB) ? 4 : 2) vo
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
             }
+            if constexpr (SB) {        // one image, never read while a DMA is in flight: the builtin's vmcnt(0) costs nothing there
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
+                for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    if (!FULLC && 2 * s2 >= nt) continue;
-                    const short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(Vs + 16 * (2 * s2) * ROWB + voff[dt]));
-                    const short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(Vs + 16 * (2 * s2 + 1) * ROWB + voff[dt]));
-                    const short8_t vf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], o[dt], 0, 0, 0);
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        if (!FULLC && 2 * s2 >= nt) continue;
+                        const short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(Vs + 16 * (2 * s2) * ROWB + voff[dt]));
+                        const short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(Vs + 16 * (2 * s2 + 1) * ROWB + voff[dt]));
+                        const short8_t vf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], o[dt], 0, 0, 0);
+                    }
+                }
+            } else {
+                const uint32_t vs_lds = (uint32_t)reinterpret_cast<uintptr_t>((am_lptr_t)Vs);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    short4_t b00, b01, b10, b11;
+                    if (FULLC || nt > 2) {
+                        am_tr_read4<0, 16 * ROWB, 32 * ROWB, 48 * ROWB>(vs_lds + (uint32_t)voff[dt], b00, b01, b10, b11);
+                    } else {
+                        am_tr_read2<0, 16 * ROWB>(vs_lds + (uint32_t)voff[dt], b00, b01);
+                        b10 = b00;
+                        b11 = b01;
+                    }
+                    const short8_t vf0 = {b00[0], b00[1], b00[2], b00[3], b01[0], b01[1], b01[2], b01[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pf[0], o[dt], 0, 0, 0);
+                    if (FULLC || nt > 2) {
+                        const short8_t vf1 = {b10[0], b10[1], b10[2], b10[3], b11[0], b11[1], b11[2], b11[3]};
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pf[1], o[dt], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -644,6 +708,251 @@ __global__ __launch_bounds__(64 * NW, ((NW == 8 && DHP <= 96) || SB) ? 4 : 2) vo
     if (qi >= q_len) return;
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     bf16_t* orow = out + (int64_t)(q_start + qi) * ldo + h * dh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int c = 16 * dt + 4 * fq;
+        if (c < dh) {
+            uint2 u;
+            u.x = am_pack2(o[dt][0] * inv, o[dt][1] * inv);
+            u.y = am_pack2(o[dt][2] * inv, o[dt][3] * inv);
+            *reinterpret_cast<uint2*>(orow + c) = u;
+        }
+    }
+}
+
+// ---- ring variant: NON-CAUSAL attention over long sequences (ViT-g 257 tokens, CLIP-L 577) ------------------------------------------------
+// The two-image kernel above on ViT-g (508 images x 16 heads per launch): 643 us in the bench, 2.3 TB/s of HBM, MFMA pipes 17 % busy; two
+// workgroups per CU (117 registers), five staging rounds per workgroup and three workgroups per (image, head) -- the third for the 257th query
+// alone -- that all stream the whole K / V.  In-kernel stamps (-DAM_TIMING) put a quarter of a workgroup's life into its prologue (descriptor,
+// Q rows, first chunk: nothing to issue) and showed the waits for the DMA to be short: what the kernel lacks is other workgroups to run
+// meanwhile, not a deeper prefetch.  Here:
+//   * one lean body: a partial last chunk stages clamped rows (finite) and masks their scores -- no second (masked) instantiation, no staging
+//     constants (row / column of a piece are re-derived at each DMA, ~12 VALU per KiB moved; am_lane_opaque keeps them from being hoisted and
+//     spilled), fragment offsets as one / two lane constants + immediates: 72 registers instead of 117 = THREE workgroups per CU with NB = 2
+//     (48 KiB each);
+//   * NW = 9: 144-query tiles (waves 0..7 stage, all nine compute) -- 257 queries are two tiles, K / V pass L2 -> LDS twice instead of three
+//     times and no workgroup exists for one query;
+//   * n_keys % 64 == 1 FOLDS the last key into the initial softmax state (m = its score from a VALU dot product over the Q fragments the lane
+//     already holds, l = 1, O = its V row) instead of paying a whole round -- barrier + DMA flight -- for a chunk of one key: 257 keys = 4 rounds;
+//   * V^T fragments are read by am_tr_read4 (see there), the round's barrier is a bare s_barrier (__syncthreads() carries a fence that lowers
+//     to vmcnt(0));
+//   * NB = 3 (opt-in, DEVQA_ATTENTION_NBUF=3): a ring of three chunk images, the LDS-DMA two chunks ahead behind counted waits (`vmcnt(LD)`: a
+//     wave's pieces complete in issue order, so "all but my newest LD" = the chunk about to be used has landed).  72 KiB = two workgroups per
+//     CU: measured SLOWER than NB = 2 (575 vs 493 us, tools/debug/att_vit_bench.py) -- occupancy beats prefetch depth here.
+// Descriptor semantics, operand orientation, lazy rescale and output are those of attention_mfma_dma_kernel with causal == 0.
+#ifdef AM_TIMING   /* hipcc -DAM_TIMING attention_mfma.hip -o build/am_timing: where a round's time goes (debug builds only) */
+__device__ unsigned long long* g_am_stamps;
+#define AM_STAMP(i) do { if (lane == 0 && (wave == 0 || wave == 7)) g_am_stamps[((size_t)blockIdx.x * 2 + (wave == 7)) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AM_STAMP(i) do { } while (0)
+#endif
+template <int DHP, int NW, int NB = 3>
+__global__ __launch_bounds__(64 * NW, NW == 9 ? 5 : 4) void attention_ring_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+                                                                                 const bf16_t* __restrict__ k, int64_t ldk,
+                                                                                 const bf16_t* __restrict__ v, int64_t ldv,
+                                                                                 bf16_t* __restrict__ out, int64_t ldo,
+                                                                                 const int32_t* __restrict__ seq_desc, int H, int dh,
+                                                                                 float scale, int fold_ok, int q_tiles, int n_seq) {
+    constexpr int ROWB = 2 * DHP;
+    constexpr int KS = DHP / 32;
+    constexpr int DT = DHP / 16;
+    constexpr int CH = DHP / 8;
+    constexpr int IMG = AM_KC * ROWB;
+    constexpr int NI = AM_KC * CH / 64;
+    constexpr int NS = 8;                  // staging waves
+    constexpr int LD = 2 * NI / NS;        // DMA instructions per staging wave and chunk (K and V images together)
+    constexpr int QT = 16 * NW;
+    static_assert(NW == 8 || NW == 9, "8 or 9 waves");
+    static_assert(2 * NI % NS == 0, "chunk must split evenly over the staging waves");
+    static_assert(NB == 2 || NB == 3, "two or three chunk images");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char am_ring_smem[];      // 2 * NB * IMG bytes
+    unsigned char* const Ks3 = am_ring_smem;
+    unsigned char* const Vs3 = am_ring_smem + NB * IMG;
+
+    int bid;
+    if (!am_remap(blockIdx.x, q_tiles, n_seq, H, bid)) return;
+    const int qt = bid % q_tiles;
+    const int h = (bid / q_tiles) % H;
+    const int s = bid / (q_tiles * H);
+    const int32_t* d = seq_desc + s * 6;
+    const int q_start = d[0], q_len = d[1], kp_start = d[2], kp_len = d[3], ko_start = d[4], ko_len = d[5];
+    const int q0 = qt * QT;
+    if (q0 >= q_len) return;  // uniform per workgroup
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n_all = kp_len + ko_len;
+    const bool fold = fold_ok && (n_all & (AM_KC - 1)) == 1 && n_all > 1;
+    const int n_keys = n_all - (fold ? 1 : 0);        // keys that go through the chunk loop (a folded key has index n_keys)
+    AM_STAMP(0);
+
+    const int qrow = q0 + wave * 16 + fr;
+    short8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = ks * 32 + fq * 8;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (qrow < q_len && c < dh) u = *reinterpret_cast<const uint4*>(q + (int64_t)(q_start + qrow) * ldq + h * dh + c);
+        qf[ks] = *reinterpret_cast<short8_t*>(&u);
+    }
+    // the folded key's row of K and V: requested ahead of the first chunks' DMA
+    uint4 fk[KS];
+    uint2 fv[DT];
+    if (fold) {
+        const int64_t grow = n_keys < kp_len ? (int64_t)(kp_start + n_keys) : (int64_t)(ko_start + n_keys - kp_len);
+        const bf16_t* kr = k + grow * ldk + h * dh;
+        const bf16_t* vr = v + grow * ldv + h * dh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = ks * 32 + fq * 8;
+            fk[ks] = c < dh ? *reinterpret_cast<const uint4*>(kr + c) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int c = 16 * dt + 4 * fq;
+            fv[dt] = c < dh ? *reinterpret_cast<const uint2*>(vr + c) : make_uint2(0, 0);
+        }
+    }
+    asm volatile("" ::: "memory");
+    // ---- staging: DMA instruction j of staging wave w fills LDS bytes [(j * 8 + w) * 1024, + 1024) of the K | V image pair; rows past the last
+    // key re-read it (finite data under p = 0), channel padding re-reads the last real channels (multiplied by the zero padding of Q / dropped) ----
+#define AMR_STAGE(C0, BUFI)                                                                                                  \
+    if (wave < NS) {                                                                                                        \
+        const int ln_ = am_lane_opaque();                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < LD; ++j) {                                                                    \
+            const int blk = (j * NS + wave) % NI;                                                                           \
+            const bool is_v = (j * NS + wave) >= NI;                                                                        \
+            unsigned char* dst = (is_v ? Vs3 : Ks3) + (BUFI) * IMG + blk * 1024;                                            \
+            const int p = blk * 64 + ln_;                                                                                   \
+            const int p_row = p / CH;                                                                                       \
+            const int p_col = h * dh + min(((p - p_row * CH) ^ am_swz<CH>(p_row)) * 8, dh - 8);                             \
+            const int kidx = min((C0) + p_row, n_keys - 1);                                                                 \
+            const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);        \
+            __builtin_amdgcn_global_load_lds((am_gptr_t)((is_v ? v : k) + grow * (is_v ? ldv : ldk) + p_col), (am_lptr_t)dst, 16, 0, 0); \
+        }                                                                                                                   \
+    }
+    // fragment addresses inside an image.  CH == 12 swizzles the two low piece bits only: (4 ks + fq) ^ x = 4 ks + (fq ^ x) and
+    // (2 dt + hb) ^ x = 4 (dt >> 1) + ((2 (dt & 1) + hb) ^ x): one (K) / two (V) lane constants + immediates
+    constexpr bool AFF = CH == 12;
+    const int tq = fr >> 2, tp = fr & 3;
+    int koff[AFF ? 1 : KS], voff[AFF ? 2 : DT];
+    if constexpr (AFF) {
+        koff[0] = fr * ROWB + ((fq ^ am_swz<CH>(fr)) * 16);
+        voff[0] = (4 * fq + tq) * ROWB + (((tp >> 1) ^ am_swz<CH>(4 * fq + tq)) * 16) + 8 * (tp & 1);
+        voff[1] = (4 * fq + tq) * ROWB + (((2 + (tp >> 1)) ^ am_swz<CH>(4 * fq + tq)) * 16) + 8 * (tp & 1);
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) koff[AFF ? 0 : ks] = fr * ROWB + (((4 * ks + fq) ^ am_swz<CH>(fr)) * 16);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            voff[AFF ? 0 : dt] = (4 * fq + tq) * ROWB + (((2 * dt + (tp >> 1)) ^ am_swz<CH>(4 * fq + tq)) * 16) + 8 * (tp & 1);
+    }
+#define AMR_KOFF(ks) (AFF ? koff[0] + (ks) * 64 : koff[AFF ? 0 : (ks)])
+#define AMR_VOFF(dt) (AFF ? voff[AFF ? (dt) & 1 : 0] + ((dt) >> 1) * 64 : voff[AFF ? 0 : (dt)])
+
+    float4_t o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = scale * 1.44269504088896340736f;
+    const bool wave_has_rows = q0 + wave * 16 < q_len;
+    if (n_keys > 0) { AMR_STAGE(0, 0) }
+    if (NB == 3 && n_keys > AM_KC) { AMR_STAGE(AM_KC, 1) }
+    if (fold) {        // m = s (raw score units, like every running maximum here), l = 1, O = v
+        float sp = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) sp = am_dot8(qf[ks], fk[ks], sp);
+        m_run = am_sum4(sp);
+        l_run = 1.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            o[dt] = (float4_t){__uint_as_float(fv[dt].x << 16), __uint_as_float(fv[dt].x & 0xffff0000u), __uint_as_float(fv[dt].y << 16),
+                               __uint_as_float(fv[dt].y & 0xffff0000u)};
+    }
+    int bi = 0;
+    AM_STAMP(1);
+    for (int c0 = 0; c0 < n_keys; c0 += AM_KC, bi = (bi == NB - 1 ? 0 : bi + 1)) {
+        AM_STAMP(2 + (c0 >> 6) * 6);
+        if (NB == 3 && c0 + AM_KC < n_keys) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");   // chunk c0 has landed, chunk c0 + 64 may be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AM_STAMP(3 + (c0 >> 6) * 6);
+        // LDS reads of the previous round are complete (their values fed MFMAs); DMA writes are covered by the counted wait above
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // everybody's pieces have landed, image bi + 2 (chunk c0 - 64) is consumed
+        AM_STAMP(4 + (c0 >> 6) * 6);
+        if (c0 + (NB - 1) * AM_KC < n_keys) { AMR_STAGE(c0 + (NB - 1) * AM_KC, (bi == 0 ? NB - 1 : bi - 1)) }
+        AM_STAMP(5 + (c0 >> 6) * 6);
+        if (!wave_has_rows) continue;
+        const unsigned char* Ks = Ks3 + bi * IMG;
+        const uint32_t vs_lds = (uint32_t)reinterpret_cast<uintptr_t>((am_lptr_t)(Vs3 + bi * IMG));
+        float4_t st[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const short8_t kf = *reinterpret_cast<const short8_t*>(Ks + 16 * t * ROWB + AMR_KOFF(ks));
+                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[t], 0, 0, 0);
+            }
+        }
+        if (c0 + AM_KC > n_keys) {            // the last, partial chunk (uniform): keys past the end score -inf
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[t][r] = (c0 + 16 * t + 4 * fq + r < n_keys) ? st[t][r] : -INFINITY;
+        }
+        float mloc = am_max4(am_max16(st[0], st[1], st[2], st[3]));
+        float m_new = fmaxf(m_run, mloc);
+        const bool grow = (m_new - m_run) * sc2 > 8.f;
+        const bool rescale = __builtin_amdgcn_ballot_w64(grow) != 0;
+        if (!rescale) m_new = m_run;
+        float alpha = 1.f, lloc = 0.f;
+        const float mc = m_new * sc2;        // finite: non-causal, so every query has seen key 0 of chunk 0 (or the folded key)
+        if (rescale) alpha = __builtin_amdgcn_exp2f(m_run * sc2 - mc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], sc2, -mc));
+                st[t][r] = p;
+                lloc += p;
+            }
+        lloc = am_sum4(lloc);
+        l_run = l_run * alpha + lloc;
+        m_run = m_new;
+        short8_t pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 u;
+            u.x = am_pack2(st[2 * s2][0], st[2 * s2][1]);
+            u.y = am_pack2(st[2 * s2][2], st[2 * s2][3]);
+            u.z = am_pack2(st[2 * s2 + 1][0], st[2 * s2 + 1][1]);
+            u.w = am_pack2(st[2 * s2 + 1][2], st[2 * s2 + 1][3]);
+            pf[s2] = *reinterpret_cast<short8_t*>(&u);
+        }
+        if (rescale) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        }
+        AM_STAMP(6 + (c0 >> 6) * 6);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            short4_t b00, b01, b10, b11;
+            am_tr_read4<0, 16 * ROWB, 32 * ROWB, 48 * ROWB>(vs_lds + (uint32_t)AMR_VOFF(dt), b00, b01, b10, b11);
+            const short8_t vf0 = {b00[0], b00[1], b00[2], b00[3], b01[0], b01[1], b01[2], b01[3]};
+            const short8_t vf1 = {b10[0], b10[1], b10[2], b10[3], b11[0], b11[1], b11[2], b11[3]};
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pf[0], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pf[1], o[dt], 0, 0, 0);
+        }
+        AM_STAMP(7 + (c0 >> 6) * 6);
+    }
+#undef AMR_STAGE
+#undef AMR_KOFF
+#undef AMR_VOFF
+    if (qrow >= q_len) return;
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    bf16_t* orow = out + (int64_t)(q_start + qrow) * ldo + h * dh;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         const int c = 16 * dt + 4 * fq;
@@ -829,7 +1138,7 @@ __global__ __launch_bounds__(512, 1) void attention_mfma_resident_kernel(const b
 // Variant switches (A/B measurements and the variant tests): read from the environment ONCE, and again only when the host asks
 // (devqa_attention_reload_env; lib.attention re-reads when it sees a DEVQA_ATTENTION_* variable change).  -1 = unset.
 namespace {
-struct AttnEnv { int resident = -1, qb = -1, dbuf = -1, nw = -1, exp = -1, dma = -1, shrt = -1, xcd = -1; };
+struct AttnEnv { int resident = -1, qb = -1, dbuf = -1, nw = -1, exp = -1, dma = -1, shrt = -1, xcd = -1, ring = -1, fold = -1, nbuf = -1; };
 AttnEnv g_attn_env;
 std::atomic<int> g_attn_env_ready{0};
 std::mutex g_attn_env_mu;
@@ -844,6 +1153,9 @@ void attn_env_load() {
     e.dma = env_int("DEVQA_ATTENTION_DMA");
     e.shrt = env_int("DEVQA_ATTENTION_SHORT");
     e.xcd = env_int("DEVQA_ATTENTION_XCD");
+    e.ring = env_int("DEVQA_ATTENTION_RING");
+    e.fold = env_int("DEVQA_ATTENTION_FOLD");
+    e.nbuf = env_int("DEVQA_ATTENTION_NBUF");
 #ifdef DEVQA_EXPERIMENTS
     e.exp = env_int("DEVQA_ATTENTION_EXP");      // timing experiments (WRONG results): compiled in only with -DDEVQA_EXPERIMENTS
 #endif
@@ -918,6 +1230,12 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     // query, so the larger tile stages more keys per query than it saves
     if (dhp == 128 && (causal & 1)) dma_nw = 4;
     if (env.nw == 8 || env.nw == 4) dma_nw = env.nw;
+    // non-causal long sequences (ViT-g, CLIP-L): the ring kernel (three chunk images, DMA two chunks ahead; attention_ring_kernel).  144-query
+    // tiles of 9 waves when they cover the longest sequence with fewer tiles than 128-query ones (257 tokens: 2 instead of 3).
+    // DEVQA_ATTENTION_RING=0 keeps the two-image kernel, DEVQA_ATTENTION_NW=8 / 9 picks the tile, DEVQA_ATTENTION_FOLD=0 turns the folding of
+    // key n_keys - 1 (n_keys % 64 == 1) off -- the staging variants are bit-identical to each other only without it.
+    const bool ring = dma && causal == 0 && dhp <= 96 && max_q_len >= 224 && env.ring != 0 && (env.nw == -1 || env.nw == 8 || env.nw == 9);
+    if (ring) dma_nw = env.nw != -1 ? env.nw : ((max_q_len + 143) / 144 < (max_q_len + 127) / 128 ? 9 : 8);
     // causal packs of short sequences (decoder probes): 32-query tiles of two waves on ONE LDS-DMA image (attention_mfma_dma_kernel<D, 2, true>);
     // non-causal short-query calls (Q-Former: 32 queries over 257 keys) keep the register-staged kernel
     const bool short_env = env.shrt != -1;
@@ -962,7 +1280,27 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
         else if (dma_short)                                                                                            \
             hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 2, true>), dim3((unsigned)grid), dim3(128), 0, st, q, ldq, k, ldk, v, ldv, \
                                out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg);                                     \
-        else if (dma) {                                                                                                \
+        else if (ring) {                                                                                               \
+            constexpr int DR = D <= 96 ? D : 96;                                                                       \
+            static std::atomic<unsigned> attr8{0}, attr9{0};                                                           \
+            const int fold_ok = env.fold != 0;                                                                         \
+            if (env.nbuf != 3) {      /* default: two images = three workgroups per CU; DEVQA_ATTENTION_NBUF=3: the ring of three */ \
+                if (dma_nw == 9)                                                                                       \
+                    hipLaunchKernelGGL((attention_ring_kernel<DR, 9, 2>), dim3((unsigned)grid), dim3(576), 4 * 64 * 2 * DR, st, q, ldq, k, ldk, v, ldv, \
+                                       out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                 \
+                else                                                                                                   \
+                    hipLaunchKernelGGL((attention_ring_kernel<DR, 8, 2>), dim3((unsigned)grid), dim3(512), 4 * 64 * 2 * DR, st, q, ldq, k, ldk, v, ldv, \
+                                       out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                 \
+            } else if (dma_nw == 9) {                                                                                  \
+                devqa_set_max_smem(attention_ring_kernel<DR, 9>, 6 * 64 * 2 * DR, attr9);                              \
+                hipLaunchKernelGGL((attention_ring_kernel<DR, 9>), dim3((unsigned)grid), dim3(576), 6 * 64 * 2 * DR, st, q, ldq, k, ldk, v, ldv, \
+                                   out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                     \
+            } else {                                                                                                   \
+                devqa_set_max_smem(attention_ring_kernel<DR, 8>, 6 * 64 * 2 * DR, attr8);                              \
+                hipLaunchKernelGGL((attention_ring_kernel<DR, 8>), dim3((unsigned)grid), dim3(512), 6 * 64 * 2 * DR, st, q, ldq, k, ldk, v, ldv, \
+                                   out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                     \
+            }                                                                                                          \
+        } else if (dma) {                                                                                              \
             if (dma_nw == 8)                                                                                           \
                 hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 8>), dim3((unsigned)grid), dim3(512), 0, st, q, ldq, k, ldk, v, ldv, \
                                    out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg);                                 \
@@ -990,3 +1328,82 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     DEVQA_LAUNCH_CHECK("attention_mfma");
     return DEVQA_OK;
 }
+
+#ifdef AM_TIMING
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+int devqa_fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); return code; }
+int devqa_prof_begin(int, hipStream_t) { return -1; }
+void devqa_prof_end(int, double, hipStream_t) {}
+int main(int argc, char** argv) {
+    const int n_seq = 508, H = 16, dh = 88, T = argc > 1 ? atoi(argv[1]) : 257;
+    const size_t M = (size_t)n_seq * T, ld = 3 * H * dh;
+    bf16_t *qkv, *out; int32_t* desc; unsigned long long* st;
+    hipMalloc(&qkv, M * ld * 2); hipMalloc(&out, M * H * dh * 2); hipMalloc(&desc, n_seq * 24);
+    std::vector<unsigned short> h(M * ld);
+    unsigned x = 1;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3c00 + ((x >> 9) & 0x3ff) - ((x >> 3) & 0x8000)); }
+    hipMemcpy(qkv, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    std::vector<int32_t> hd(n_seq * 6);
+    for (int i = 0; i < n_seq; ++i) { hd[i * 6] = i * T; hd[i * 6 + 1] = T; hd[i * 6 + 2] = 0; hd[i * 6 + 3] = 0; hd[i * 6 + 4] = i * T; hd[i * 6 + 5] = T; }
+    hipMemcpy(desc, hd.data(), hd.size() * 4, hipMemcpyHostToDevice);
+    for (int nw = 8; nw <= 9; ++nw) {
+        const int qt = 16 * nw, q_tiles = (T + qt - 1) / qt;
+        const long grid = (long)n_seq * H * q_tiles;
+        hipMalloc(&st, (size_t)grid * 2 * 64 * 8);
+        hipMemset(st, 0, (size_t)grid * 2 * 64 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_am_stamps), &st, sizeof(st));
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        float ms = 0;
+        for (int rep = 0; rep < 6; ++rep) {
+            if (rep == 5) hipEventRecord(e0, nullptr);
+            if (nw == 9) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attention_ring_kernel<96, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 192);
+                hipLaunchKernelGGL((attention_ring_kernel<96, 9>), dim3((unsigned)grid), dim3(576), 6 * 64 * 192, nullptr, qkv, (int64_t)ld, qkv + H * dh, (int64_t)ld,
+                                   qkv + 2 * H * dh, (int64_t)ld, out, (int64_t)(H * dh), desc, H, dh, 0.1066f, 1, q_tiles, -n_seq);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attention_ring_kernel<96, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 192);
+                hipLaunchKernelGGL((attention_ring_kernel<96, 8>), dim3((unsigned)grid), dim3(512), 6 * 64 * 192, nullptr, qkv, (int64_t)ld, qkv + H * dh, (int64_t)ld,
+                                   qkv + 2 * H * dh, (int64_t)ld, out, (int64_t)(H * dh), desc, H, dh, 0.1066f, 1, q_tiles, -n_seq);
+            }
+            if (rep == 5) hipEventRecord(e1, nullptr);
+        }
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> hs((size_t)grid * 2 * 64);
+        hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+        auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        printf("T %d, %d waves: %.1f us (stamped build), %ld workgroups\n", T, nw, ms * 1e3, grid);
+        for (int tile = 0; tile < q_tiles; ++tile) {
+            for (int wsel = 0; wsel < 2; ++wsel) {
+                std::vector<double> pro, total;
+                std::vector<double> ph[5][5];
+                for (long b = tile; b < grid; b += q_tiles) {
+                    // the kernel remaps blockIdx -> (seq, head, tile); tile = bid % q_tiles after the remap, not of blockIdx: classify by stamps only
+                    const unsigned long long* s_ = &hs[((size_t)b * 2 + wsel) * 64];
+                    if (s_[0] == 0 || s_[1] == 0) continue;
+                    pro.push_back((double)(s_[1] - s_[0]));
+                    int r = 0;
+                    for (; r < 5 && s_[2 + r * 6] != 0; ++r) {
+                        const unsigned long long* p_ = s_ + 2 + r * 6;
+                        ph[r][0].push_back((double)(p_[1] - p_[0]));       // DMA wait
+                        ph[r][1].push_back((double)(p_[2] - p_[1]));       // barrier
+                        ph[r][2].push_back((double)(p_[3] - p_[2]));       // stage issue
+                        if (p_[4] != 0) ph[r][3].push_back((double)(p_[4] - p_[3]));       // S + softmax
+                        if (p_[5] != 0) ph[r][4].push_back((double)(p_[5] - p_[4]));       // P.V
+                    }
+                }
+                printf("  blockIdx %% q_tiles == %d, wave %d: prologue %.0f;", tile, wsel ? 7 : 0, med(pro));
+                for (int r = 0; r < 5; ++r)
+                    if (!ph[r][0].empty())
+                        printf("  round %d: wait %.0f bar %.0f stage %.0f S+softmax %.0f PV %.0f |", r, med(ph[r][0]), med(ph[r][1]), med(ph[r][2]), med(ph[r][3]), med(ph[r][4]));
+                printf("\n");
+            }
+        }
+        hipFree(st);
+    }
+    return 0;
+}
+#endif
