@@ -965,6 +965,208 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 5 : 4) void attention_ring_kerne
     }
 }
 
+// ---- pack variant: packs of SHORT sequences (the decoder pack of the edit+eval path: 32 image tokens or <= ~25 text tokens per sequence,
+// usually behind a 32-key visible prefix -- one key chunk) -----------------------------------------------------------------------------------
+// OPT-IN (DEVQA_ATTENTION_PACK=1), kept as the measured answer to "is the decoder pack bound by its ~3000 wave-instructions per (sequence,
+// head)?" (profiles/r02_summary.md): no.  The tiled kernels above give such a (sequence, head) a workgroup of 2-4 waves of which one or two
+// hold queries, a staging round through a shared image and two barriers; here a WAVE is the unit -- one (sequence, head, 16-query block) per
+// wave, four independent waves per workgroup, no barrier, ~700 instructions per item -- and the launch takes the same 360-387 us (see
+// launch_attention_mfma).  What the item does:
+//   * K fragments come straight from global memory into the MFMA operand registers (lane (fr, fq) of S^T = K.Q^T holds 8 channels of key
+//     16 t + fr: a 16-byte load, one row address per 16-key tile, channel offsets are immediates);
+//   * V goes by LDS-DMA into a wave-private image in the same access shape (16 rows x 64 contiguous bytes per instruction, one row address per
+//     16 rows): block (g, kb) of 1 KiB holds the 64-byte column group kb of rows 16 g .. 16 g + 15, so a transposing read is ONE lane constant
+//     + immediates (4-way bank conflicts on 72 reads per item: noise);
+//   * masking is one compare + select per score against a per-lane limit (lim = first hidden key: end of the keys, or the causal diagonal);
+//     rows / channels past the end are clamped instead of predicated (no exec-mask branches), Q's padding channels are zeroed by a select;
+//   * every load of the item (3 Q + <= 12 K + <= 16 V-DMA) is in flight before the first wait; key tiles past the end are not loaded.
+// Sequences with more than 64 keys loop over chunks without overlap (correct, not what this form is for).  Same descriptor semantics, operand
+// orientation and arithmetic order as the kernels above (bit-identical to them on one-chunk sequences); a running maximum that grows always
+// rescales (one chunk: never).
+#ifdef AM_TIMING
+#define AMP_STAMP(i) do { if (lane == 0) g_am_stamps[(size_t)item * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AMP_STAMP(i) do { } while (0)
+#endif
+template <int DHP>
+__global__ __launch_bounds__(256) void attention_pack_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
+                                                             int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
+                                                             bf16_t* __restrict__ out, int64_t ldo, const int32_t* __restrict__ seq_desc,
+                                                             int H, int dh, float scale, int causal, int qb_shift, int n_items) {
+    constexpr int KS = DHP / 32;           // 32-channel k-steps of S = 64-byte column groups of a row
+    constexpr int DT = DHP / 16;
+    constexpr int IMG = AM_KC * 2 * DHP;   // one wave's V image: 4 row groups x KS blocks of 1 KiB
+    extern __shared__ __attribute__((aligned(1024))) unsigned char am_pack_smem[];      // 4 * IMG bytes
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wg;
+    {       // one contiguous range of workgroups per XCD (blockIdx % 8): the heads and texts of a cycle read their prefix through one L2
+        const int b = blockIdx.x, nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = b & 7, idx = b >> 3;
+        wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int item = wg * 4 + wave;
+    if (item >= n_items) return;
+    AMP_STAMP(0);
+    const int qb = item & ((1 << qb_shift) - 1);       // (items per (sequence, head): a power of two of 16-query blocks; blocks past q_len exit)
+    const int sh = item >> qb_shift;
+    const int s = sh / H;
+    const int h = sh - s * H;
+    const int32_t* d = seq_desc + s * 6;
+    const int q_start = d[0], q_len = d[1], kp_start = d[2], kp_len = d[3], ko_start = d[4], ko_len = d[5];
+    const int q0 = qb * 16;
+    if (q0 >= q_len) return;               // uniform per wave
+    AMP_STAMP(1);
+    const int ldq32 = (int)ldq, ldk32 = (int)ldk, ldv32 = (int)ldv;       // (row strides fit 31 bits: checked by the launcher) one v_mad_i64_i32 per row address
+    const int fr = lane & 15, fq = lane >> 4;
+    const int causal_off = ko_len - q_len;
+    const int own_hi = causal ? max(0, min(ko_len, q0 + 16 + causal_off)) : ko_len;
+    const int n_keys = kp_len + own_hi;
+    const int qrow = q0 + fr;
+    // first key this lane's query does NOT see: the end of the keys, or the causal diagonal (the visible prefix is never hidden)
+    const int lim = causal ? min(n_keys, kp_len + max(0, qrow + causal_off + 1)) : n_keys;
+    unsigned char* const Vs = am_pack_smem + wave * IMG;
+    const int tq = fr >> 2, tp = fr & 3;
+    const uint32_t va = (uint32_t)reinterpret_cast<uintptr_t>((am_lptr_t)Vs) + (uint32_t)((4 * fq + tq) * 64 + (tp >> 1) * 16 + 8 * (tp & 1));
+    // channel offsets (elements) of this lane's 16-byte pieces: K / Q fragments (8 fq) and V staging (8 (lane & 3)); only the last 64-byte
+    // group can run past dh: it re-reads the last real channels (K, V: multiplied by zeros of Q / dropped with the output padding)
+    const int kc_last = min((KS - 1) * 32 + fq * 8, dh - 8), vc_last = min((KS - 1) * 32 + (lane & 3) * 8, dh - 8);
+    const bool q_pad = (KS - 1) * 32 + fq * 8 >= dh;
+
+    short8_t qf[KS];
+    {
+        const bf16_t* qr = q + (int64_t)(q_start + min(qrow, q_len - 1)) * ldq32 + h * dh;       // rows past the end repeat the last one (never stored)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 u = *reinterpret_cast<const uint4*>(qr + (ks < KS - 1 ? ks * 32 + fq * 8 : kc_last));
+            if (ks == KS - 1) {
+                u.x = q_pad ? 0u : u.x;
+                u.y = q_pad ? 0u : u.y;
+                u.z = q_pad ? 0u : u.z;
+                u.w = q_pad ? 0u : u.w;
+            }
+            qf[ks] = *reinterpret_cast<short8_t*>(&u);
+        }
+    }
+    float4_t o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = scale * 1.44269504088896340736f;
+    for (int c0 = 0; c0 < n_keys; c0 += AM_KC) {
+        const int nt = min(4, (n_keys - c0 + 15) >> 4);            // 16-key tiles of this chunk that hold a key (uniform)
+        if (c0 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the previous chunk's image is consumed: its reads fed MFMAs)
+        // ---- V: row group g = rows 16 g + (lane >> 2); rows past the last key re-read it (finite data under p = 0) ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g >= ((nt + 1) >> 1) * 2) continue;                 // (uniform) only the 32-key k-steps of P.V that hold a key
+            const int kidx = min(c0 + 16 * g + (lane >> 2), n_keys - 1);
+            const int grow = kidx < kp_len ? kp_start + kidx : ko_start + kidx - kp_len;
+            const bf16_t* vr = v + (int64_t)grow * ldv32 + h * dh;
+#pragma unroll
+            for (int kb = 0; kb < KS; ++kb)
+                __builtin_amdgcn_global_load_lds((am_gptr_t)(vr + (kb < KS - 1 ? kb * 32 + (lane & 3) * 8 : vc_last)),
+                                                 (am_lptr_t)(Vs + (g * KS + kb) * 1024), 16, 0, 0);
+        }
+        // ---- S^T = K.Q^T with K from global memory ----
+        short8_t kf[4][KS];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t >= nt) continue;
+            const int kidx = min(c0 + 16 * t + fr, n_keys - 1);
+            const int grow = kidx < kp_len ? kp_start + kidx : ko_start + kidx - kp_len;
+            const bf16_t* kr = k + (int64_t)grow * ldk32 + h * dh;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 u = *reinterpret_cast<const uint4*>(kr + (ks < KS - 1 ? ks * 32 + fq * 8 : kc_last));
+                kf[t][ks] = *reinterpret_cast<const short8_t*>(&u);
+            }
+        }
+        AMP_STAMP(2);
+        float4_t st[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            st[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (t >= nt) continue;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], st[t], 0, 0, 0);
+        }
+        AMP_STAMP(3);
+        const int rel = lim - c0 - 4 * fq;                          // score (t, r) of this lane is visible iff 16 t + r < rel
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[t][r] = (16 * t + r < rel) ? st[t][r] : -INFINITY;      // (tiles past nt: their keys are past lim)
+        const float mloc = am_max4(am_max16(st[0], st[1], st[2], st[3]));
+        const float m_new = fmaxf(m_run, mloc);
+        const float mc = m_new == -INFINITY ? 0.f : m_new * sc2;
+        const float alpha = __builtin_amdgcn_exp2f(m_run * sc2 - mc);       // first chunk: exp2(-inf) = 0
+        float lloc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], sc2, -mc));
+                st[t][r] = p;
+                lloc += p;
+            }
+        lloc = am_sum4(lloc);
+        l_run = l_run * alpha + lloc;
+        m_run = m_new;
+        short8_t pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 u;
+            u.x = am_pack2(st[2 * s2][0], st[2 * s2][1]);
+            u.y = am_pack2(st[2 * s2][2], st[2 * s2][3]);
+            u.z = am_pack2(st[2 * s2 + 1][0], st[2 * s2 + 1][1]);
+            u.w = am_pack2(st[2 * s2 + 1][2], st[2 * s2 + 1][3]);
+            pf[s2] = *reinterpret_cast<short8_t*>(&u);
+        }
+        if (c0 > 0) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        }
+        AMP_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's V image has landed (nobody else reads or writes it)
+        AMP_STAMP(5);
+        if (nt > 2) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                short4_t b00, b01, b10, b11;
+                am_tr_read4<0, KS * 1024, 2 * KS * 1024, 3 * KS * 1024>(va + (dt >> 1) * 1024 + (dt & 1) * 32, b00, b01, b10, b11);
+                const short8_t vf0 = {b00[0], b00[1], b00[2], b00[3], b01[0], b01[1], b01[2], b01[3]};
+                const short8_t vf1 = {b10[0], b10[1], b10[2], b10[3], b11[0], b11[1], b11[2], b11[3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pf[0], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pf[1], o[dt], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                short4_t b00, b01;
+                am_tr_read2<0, KS * 1024>(va + (dt >> 1) * 1024 + (dt & 1) * 32, b00, b01);
+                const short8_t vf0 = {b00[0], b00[1], b00[2], b00[3], b01[0], b01[1], b01[2], b01[3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pf[0], o[dt], 0, 0, 0);
+            }
+        }
+    }
+    AMP_STAMP(6);
+    if (qrow >= q_len) return;
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    bf16_t* orow = out + (int64_t)(q_start + qrow) * ldo + h * dh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int c = 16 * dt + 4 * fq;
+        if (c < dh) {
+            uint2 u;
+            u.x = am_pack2(o[dt][0] * inv, o[dt][1] * inv);
+            u.y = am_pack2(o[dt][2] * inv, o[dt][3] * inv);
+            *reinterpret_cast<uint2*>(orow + c) = u;
+        }
+    }
+}
+
 // ---- resident variant: non-causal self-attention over short sequences (ViT-g: 257 tokens) ------------------------------------
 // One workgroup of 8 waves per (sequence, head).  K and V of the WHOLE sequence are staged into LDS once (rows padded to a multiple
 // of 64: 320 x 224 B x 2 = 140 KiB for ViT-g), one barrier, then every wave streams the key chunks out of LDS for two 16-query blocks
@@ -1138,7 +1340,7 @@ __global__ __launch_bounds__(512, 1) void attention_mfma_resident_kernel(const b
 // Variant switches (A/B measurements and the variant tests): read from the environment ONCE, and again only when the host asks
 // (devqa_attention_reload_env; lib.attention re-reads when it sees a DEVQA_ATTENTION_* variable change).  -1 = unset.
 namespace {
-struct AttnEnv { int resident = -1, qb = -1, dbuf = -1, nw = -1, exp = -1, dma = -1, shrt = -1, xcd = -1, ring = -1, fold = -1, nbuf = -1; };
+struct AttnEnv { int resident = -1, qb = -1, dbuf = -1, nw = -1, exp = -1, dma = -1, shrt = -1, xcd = -1, ring = -1, fold = -1, nbuf = -1, pack = -1; };
 AttnEnv g_attn_env;
 std::atomic<int> g_attn_env_ready{0};
 std::mutex g_attn_env_mu;
@@ -1156,6 +1358,7 @@ void attn_env_load() {
     e.ring = env_int("DEVQA_ATTENTION_RING");
     e.fold = env_int("DEVQA_ATTENTION_FOLD");
     e.nbuf = env_int("DEVQA_ATTENTION_NBUF");
+    e.pack = env_int("DEVQA_ATTENTION_PACK");
 #ifdef DEVQA_EXPERIMENTS
     e.exp = env_int("DEVQA_ATTENTION_EXP");      // timing experiments (WRONG results): compiled in only with -DDEVQA_EXPERIMENTS
 #endif
@@ -1245,6 +1448,32 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     // dh 128 only; DEVQA_ATTENTION_SHORT=1 forces it for every head size, =0 turns it off
     const bool short_ok = short_env ? env.shrt != 0 : dhp == 128;
     const bool dma_short = causal && !dma && !dma_env && nw == 4 && qb == 1 && !dbuf && exp_id == 0 && !nw_env && max_q_len <= 64 && short_ok;
+    // causal packs of sequences of <= 64 queries, OPT-IN (DEVQA_ATTENTION_PACK=1): one (sequence, head, 16-query block) per WAVE
+    // (attention_pack_kernel).  Built, tested (bit-identical to the tiled forms on one-chunk sequences) and NOT the default: on the bench's decoder
+    // pack (2159 sequences x 32 heads x 80) it measured 360-387 us in three forms of very different instruction counts against 369 us for the
+    // register-staged tiles (tools/debug/att_pack_bench.py) -- the pack is bound by neither issue slots nor HBM (2.4 TB/s) but by the CU's address
+    // path: every form fetches 160-byte row slices per head, 16 rows x 64 bytes per wave instruction (profiles/r03_summary.md G).
+    const bool pack_ok = (causal & 1) && max_q_len <= 64 && env.pack == 1 && !dma_env && !nw_env && !short_env && qb == 1 &&
+                         !dbuf && exp_id == 0 && dh % 8 == 0;
+    if (pack_ok) {
+        const int qb_shift = max_q_len <= 16 ? 0 : max_q_len <= 32 ? 1 : 2;
+        const long n_items = ((long)n_seq * H) << qb_shift;
+        DEVQA_CHECK_SHAPE(ldq < (1ll << 31) && ldk < (1ll << 31) && ldv < (1ll << 31), "attention: row stride too large");
+        const long wgs = (n_items + 3) / 4;
+        DEVQA_CHECK_SHAPE(wgs < 2147483647L && n_items < 2147483647L, "attention: grid too large");
+        const int ph = devqa_prof_begin(DEVQA_PROF_ATTENTION, st0);
+#define LAUNCH_PACK(D)                                                                                                     \
+        hipLaunchKernelGGL((attention_pack_kernel<D>), dim3((unsigned)wgs), dim3(256), 4 * 64 * 2 * D, st0, q, ldq, k, ldk, v, ldv, out, ldo, \
+                           seq_desc, H, dh, scale, causal & 1, qb_shift, (int)n_items)
+        if (dhp == 32) LAUNCH_PACK(32);
+        else if (dhp == 64) LAUNCH_PACK(64);
+        else if (dhp == 96) LAUNCH_PACK(96);
+        else LAUNCH_PACK(128);
+#undef LAUNCH_PACK
+        devqa_prof_end(ph, 4.0 * (double)n_seq * H * (double)max_q_len * (double)max_q_len * dh * 0.5, st0);
+        DEVQA_LAUNCH_CHECK("attention_pack");
+        return DEVQA_OK;
+    }
     const int qt = dma_short ? 32 : dma ? 16 * dma_nw : 16 * nw * qb;
     const int q_tiles = (max_q_len + qt - 1) / qt;
     // workgroup -> XCD mapping (am_remap): sequence units for CAUSAL packs with LONG sequences (balance: the LLaMA decoders' mixed packs of
@@ -1337,7 +1566,66 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
 int devqa_fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); return code; }
 int devqa_prof_begin(int, hipStream_t) { return -1; }
 void devqa_prof_end(int, double, hipStream_t) {}
+static int pack_main() {
+    // the bench's decoder pack: per cycle 4 image prefixes of 32 rows, 13 texts of ~17 rows, 11 of them behind a prefix; OPT heads 32 x 80
+    const int cycles = 127, H = 32, dh = 80;
+    std::vector<int32_t> hd;
+    int pos = 0;
+    unsigned x = 7;
+    for (int c = 0; c < cycles; ++c) {
+        int pre[4];
+        for (int i = 0; i < 4; ++i) { pre[i] = pos; int32_t e[6] = {pos, 32, 0, 0, pos, 32}; hd.insert(hd.end(), e, e + 6); pos += 32; }
+        for (int i = 0; i < 13; ++i) {
+            x = x * 1664525u + 1013904223u;
+            const int n = 12 + (int)((x >> 16) % 11);
+            int32_t e[6] = {pos, n, i < 11 ? pre[i % 4] : 0, i < 11 ? 32 : 0, pos, n};
+            hd.insert(hd.end(), e, e + 6);
+            pos += n;
+        }
+    }
+    const int n_seq = (int)hd.size() / 6;
+    const size_t M = pos, ld = 3 * H * dh;
+    bf16_t *qkv, *out; int32_t* desc; unsigned long long* st;
+    hipMalloc(&qkv, M * ld * 2); hipMalloc(&out, M * H * dh * 2); hipMalloc(&desc, hd.size() * 4);
+    std::vector<unsigned short> h(M * ld);
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3c00 + ((x >> 9) & 0x3ff) - ((x >> 3) & 0x8000)); }
+    hipMemcpy(qkv, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(desc, hd.data(), hd.size() * 4, hipMemcpyHostToDevice);
+    const int q_blocks = 2;
+    const long n_items = (long)n_seq * H * q_blocks, wgs = (n_items + 3) / 4;
+    hipMalloc(&st, (size_t)n_items * 64);
+    hipMemset(st, 0, (size_t)n_items * 64);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_am_stamps), &st, sizeof(st));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 6; ++rep) {
+        if (rep == 5) hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL((attention_pack_kernel<96>), dim3((unsigned)wgs), dim3(256), 4 * 64 * 192, nullptr, qkv, (int64_t)ld, qkv + H * dh, (int64_t)ld,
+                           qkv + 2 * H * dh, (int64_t)ld, out, (int64_t)(H * dh), desc, H, dh, 1.0f, 1, 1, (int)n_items);
+        if (rep == 5) hipEventRecord(e1, nullptr);
+    }
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> hs((size_t)n_items * 8);
+    hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+    auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    std::vector<double> ph[6];
+    unsigned long long tmin = ~0ull, tmax = 0;
+    long live = 0;
+    for (long i = 0; i < n_items; ++i) {
+        const unsigned long long* s_ = &hs[(size_t)i * 8];
+        if (s_[0] == 0 || s_[6] == 0) continue;
+        ++live;
+        for (int p_ = 0; p_ < 6; ++p_) ph[p_].push_back((double)(s_[p_ + 1] - s_[p_]));
+        tmin = std::min(tmin, s_[0]); tmax = std::max(tmax, s_[6]);
+    }
+    printf("pack: %d sequences, %zu rows, %ld items (%ld with queries): %.1f us (stamped build); kernel span %.0f cycles\n", n_seq, M, n_items, live, ms * 1e3, (double)(tmax - tmin));
+    printf("  median cycles: descriptor %.0f | issue Q, V-DMA, K loads %.0f | S MFMAs (waits for Q, K) %.0f | softmax %.0f | wait V %.0f | P.V %.0f\n",
+           med(ph[0]), med(ph[1]), med(ph[2]), med(ph[3]), med(ph[4]), med(ph[5]));
+    return 0;
+}
 int main(int argc, char** argv) {
+    if (argc > 1 && atoi(argv[1]) == 0) return pack_main();
     const int n_seq = 508, H = 16, dh = 88, T = argc > 1 ? atoi(argv[1]) : 257;
     const size_t M = (size_t)n_seq * T, ld = 3 * H * dh;
     bf16_t *qkv, *out; int32_t* desc; unsigned long long* st;

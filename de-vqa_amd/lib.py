@@ -416,7 +416,7 @@ def colsum_(x, out, accumulate=True):
 
 
 _ATT_ENV_KEYS = ("DEVQA_ATTENTION_DMA", "DEVQA_ATTENTION_NW", "DEVQA_ATTENTION_QB", "DEVQA_ATTENTION_DBUF", "DEVQA_ATTENTION_SHORT",
-                 "DEVQA_ATTENTION_RESIDENT", "DEVQA_ATTENTION_EXP", "DEVQA_ATTENTION_XCD", "DEVQA_ATTENTION_RING", "DEVQA_ATTENTION_FOLD", "DEVQA_ATTENTION_NBUF")
+                 "DEVQA_ATTENTION_RESIDENT", "DEVQA_ATTENTION_EXP", "DEVQA_ATTENTION_XCD", "DEVQA_ATTENTION_RING", "DEVQA_ATTENTION_FOLD", "DEVQA_ATTENTION_NBUF", "DEVQA_ATTENTION_PACK")
 _att_env_seen = None
 
 

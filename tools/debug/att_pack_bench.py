@@ -52,15 +52,20 @@ def main():
     out = torch.zeros(M, H * dh, device="cuda", dtype=torch.bfloat16)
     fn = lambda: lib.attention(q, k, v, d, len(desc), mx, H, dh, dh ** -0.5, 1, out=out)
     res = {}
+    gb = (3 * M * H * dh * 2 + M * H * dh * 2) / 1e9
     for rep in range(2):
-        for var in ("1", "0"):
-            os.environ["DEVQA_ATTENTION_SHORT"] = var
+        for label, env in (("pack kernel (wave per item)", {}), ("tiled, register-staged", {"DEVQA_ATTENTION_PACK": "0", "DEVQA_ATTENTION_SHORT": "0"}),
+                           ("tiled, single-image DMA", {"DEVQA_ATTENTION_PACK": "0", "DEVQA_ATTENTION_SHORT": "1"})):
+            os.environ.update(env)
             out.zero_()
             fn()
-            res.setdefault(var, out.clone())
-            print("SHORT=%s  %d sequences, %d rows, max q %d: %7.1f us" % (var, len(desc), M, mx, t_us(fn)), flush=True)
-    del os.environ["DEVQA_ATTENTION_SHORT"]
-    print("bit-identical:", bool(torch.equal(res["0"], res["1"])))
+            res.setdefault(label, out.clone())
+            us = t_us(fn, warm=50)
+            for k_ in env:
+                del os.environ[k_]
+            print("%-28s %d sequences, %d rows, max q %d: %7.1f us  (q, k, v, out once: %.2f GB = %.2f TB/s)" % (label, len(desc), M, mx, us, gb, gb / us * 1e3), flush=True)
+    vals = list(res.values())
+    print("max |pack - tiled|:", (vals[0].float() - vals[1].float()).abs().max().item(), " tiled forms bit-identical:", bool(torch.equal(vals[1], vals[2])))
 
 
 if __name__ == "__main__":
