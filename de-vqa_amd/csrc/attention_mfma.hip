@@ -747,7 +747,7 @@ __device__ unsigned long long* g_am_stamps;
 #define AM_STAMP(i) do { } while (0)
 #endif
 template <int DHP, int NW, int NB = 3>
-__global__ __launch_bounds__(64 * NW, NW == 9 ? 5 : 4) void attention_ring_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+__global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                                  const bf16_t* __restrict__ k, int64_t ldk,
                                                                                  const bf16_t* __restrict__ v, int64_t ldv,
                                                                                  bf16_t* __restrict__ out, int64_t ldo,
@@ -950,8 +950,38 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 5 : 4) void attention_ring_kerne
 #undef AMR_STAGE
 #undef AMR_KOFF
 #undef AMR_VOFF
-    if (qrow >= q_len) return;
+    if (!wave_has_rows) return;
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    // ---- output: whole row slices.  A lane holds 4 channels of ONE query per 16-channel tile: stored as they stand, a wave instruction writes 16 rows
+    // x 32 bytes -- 16 cache lines for 512 bytes, six times per wave, and the CU's address path (a line per cycle) is what bounds this kernel.  Waves
+    // 0..7 pass their 16 x dh block through a quarter of the chunk image that is free (image `bi`: consumed a round ago, nothing in flight into it
+    // after the last round's vmcnt(0)) and store 16-byte pieces of consecutive channels: ~5.8 rows of dh x 2 contiguous bytes per instruction.
+    // The ninth wave (16 rows of tile 0, one of ViT-g's tile 1) and head dims that are not multiples of 8 keep the direct form. ----
+    if (wave < 8 && (dh & 7) == 0) {
+        unsigned char* ob = (wave < 4 ? Ks3 : Vs3) + bi * IMG + (wave & 3) * (16 * ROWB);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            uint2 u;
+            u.x = am_pack2(o[dt][0] * inv, o[dt][1] * inv);
+            u.y = am_pack2(o[dt][2] * inv, o[dt][3] * inv);
+            *reinterpret_cast<uint2*>(ob + fr * ROWB + 32 * dt + 8 * fq) = u;
+        }
+        const int np = dh >> 3;                                  // 16-byte pieces per row
+        const int magic = 65536 / np + 1;                        // p / np for p < 256 (np <= 16)
+        const int row0 = q0 + wave * 16;
+#pragma unroll
+        for (int j = 0; j < (16 * CH + 63) / 64; ++j) {
+            const int p_ = j * 64 + lane;
+            const int r = (p_ * magic) >> 16;
+            const int c = p_ - r * np;
+            if (r < 16 && row0 + r < q_len) {
+                const uint4 u = *reinterpret_cast<const uint4*>(ob + r * ROWB + c * 16);
+                *reinterpret_cast<uint4*>(out + (int64_t)(q_start + row0 + r) * ldo + h * dh + c * 8) = u;
+            }
+        }
+        return;
+    }
+    if (qrow >= q_len) return;
     bf16_t* orow = out + (int64_t)(q_start + qrow) * ldo + h * dh;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
