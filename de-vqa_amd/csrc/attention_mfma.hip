@@ -732,8 +732,10 @@ __global__ __launch_bounds__(64 * NW, ((NW == 8 && DHP <= 96) || SB) ? 4 : 2) vo
 //     (48 KiB each);
 //   * NW = 9: 144-query tiles (waves 0..7 stage, all nine compute) -- 257 queries are two tiles, K / V pass L2 -> LDS twice instead of three
 //     times and no workgroup exists for one query;
-//   * n_keys % 64 == 1 FOLDS the last key into the initial softmax state (m = its score from a VALU dot product over the Q fragments the lane
-//     already holds, l = 1, O = its V row) instead of paying a whole round -- barrier + DMA flight -- for a chunk of one key: 257 keys = 4 rounds;
+//   * n_keys % 64 == 1 FOLDS the last key: its K / V rows ride into 512 spare bytes of LDS with chunk 0 and it is processed after the last chunk,
+//     where the chunk loop would have met it, on the VALU (a dot product over the Q fragments the lane holds, one lazy-rescale step) -- instead of
+//     a whole round (barrier + DMA flight) for a chunk of one key: 257 keys = 4 rounds.  Same order of operations as the unfolded form, so results
+//     differ from it only where the fp32 score does (VALU fma chain against the MFMA's internal sum), not by a different softmax reference point;
 //   * V^T fragments are read by am_tr_read4 (see there), the round's barrier is a bare s_barrier (__syncthreads() carries a fence that lowers
 //     to vmcnt(0));
 //   * NB = 3 (opt-in, DEVQA_ATTENTION_NBUF=3): a ring of three chunk images, the LDS-DMA two chunks ahead behind counted waits (`vmcnt(LD)`: a
@@ -795,25 +797,15 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kerne
         if (qrow < q_len && c < dh) u = *reinterpret_cast<const uint4*>(q + (int64_t)(q_start + qrow) * ldq + h * dh + c);
         qf[ks] = *reinterpret_cast<short8_t*>(&u);
     }
-    // the folded key's row of K and V: requested ahead of the first chunks' DMA
-    uint4 fk[KS];
-    uint2 fv[DT];
-    if (fold) {
+    // the folded key's rows of K and V go into 512 bytes behind the images (one DMA of wave 0, issued before -- so landed with -- chunk 0): piece i of
+    // the K row at byte 16 i, of the V row at 256 + 16 i
+    unsigned char* const odd = am_ring_smem + 2 * NB * IMG;
+    if (fold && wave == 0 && (lane < CH || (lane >= 16 && lane < 16 + CH))) {
         const int64_t grow = n_keys < kp_len ? (int64_t)(kp_start + n_keys) : (int64_t)(ko_start + n_keys - kp_len);
-        const bf16_t* kr = k + grow * ldk + h * dh;
-        const bf16_t* vr = v + grow * ldv + h * dh;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int c = ks * 32 + fq * 8;
-            fk[ks] = c < dh ? *reinterpret_cast<const uint4*>(kr + c) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int c = 16 * dt + 4 * fq;
-            fv[dt] = c < dh ? *reinterpret_cast<const uint2*>(vr + c) : make_uint2(0, 0);
-        }
+        const int c = min((lane & 15) * 8, dh - 8);
+        const bf16_t* src = (lane < 16 ? k + grow * ldk : v + grow * ldv) + h * dh + c;
+        __builtin_amdgcn_global_load_lds((am_gptr_t)src, (am_lptr_t)odd, 16, 0, 0);
     }
-    asm volatile("" ::: "memory");
     // ---- staging: DMA instruction j of staging wave w fills LDS bytes [(j * 8 + w) * 1024, + 1024) of the K | V image pair; rows past the last
     // key re-read it (finite data under p = 0), channel padding re-reads the last real channels (multiplied by the zero padding of Q / dropped) ----
 #define AMR_STAGE(C0, BUFI)                                                                                                  \
@@ -858,17 +850,6 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kerne
     const bool wave_has_rows = q0 + wave * 16 < q_len;
     if (n_keys > 0) { AMR_STAGE(0, 0) }
     if (NB == 3 && n_keys > AM_KC) { AMR_STAGE(AM_KC, 1) }
-    if (fold) {        // m = s (raw score units, like every running maximum here), l = 1, O = v
-        float sp = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) sp = am_dot8(qf[ks], fk[ks], sp);
-        m_run = am_sum4(sp);
-        l_run = 1.f;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            o[dt] = (float4_t){__uint_as_float(fv[dt].x << 16), __uint_as_float(fv[dt].x & 0xffff0000u), __uint_as_float(fv[dt].y << 16),
-                               __uint_as_float(fv[dt].y & 0xffff0000u)};
-    }
     int bi = 0;
     AM_STAMP(1);
     for (int c0 = 0; c0 < n_keys; c0 += AM_KC, bi = (bi == NB - 1 ? 0 : bi + 1)) {
@@ -946,6 +927,32 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kerne
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pf[1], o[dt], 0, 0, 0);
         }
         AM_STAMP(7 + (c0 >> 6) * 6);
+    }
+    if (fold && wave_has_rows) {
+        // the folded key, after the last chunk (where the chunk loop would have met it), on the VALU: score = dot of the lane's Q fragments with
+        // its channels of the K row (summed over the four lanes of the query), then the same lazy-rescale step as a chunk with this one score;
+        // P is rounded to bf16 for the product as the MFMA operand would be, the normaliser takes it unrounded (as in the chunk body)
+        float sp = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) sp = am_dot8(qf[ks], *reinterpret_cast<const uint4*>(odd + 16 * (4 * ks + fq)), sp);
+        const float sod = am_sum4(sp);
+        float m_new = fmaxf(m_run, sod);
+        const bool grow = (m_new - m_run) * sc2 > 8.f;
+        const bool rescale = __builtin_amdgcn_ballot_w64(grow) != 0;
+        if (!rescale) m_new = m_run;
+        const float mc = m_new * sc2;
+        const float alpha = rescale ? __builtin_amdgcn_exp2f(m_run * sc2 - mc) : 1.f;
+        const float p = __builtin_amdgcn_exp2f(fmaf(sod, sc2, -mc));
+        l_run = l_run * alpha + p;
+        m_run = m_new;
+        const float pb = __uint_as_float(am_pack2(p, 0.f) << 16);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const uint2 u = *reinterpret_cast<const uint2*>(odd + 256 + 32 * dt + 8 * fq);
+            const float vv[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] = fmaf(pb, vv[r], rescale ? o[dt][r] * alpha : o[dt][r]);
+        }
     }
 #undef AMR_STAGE
 #undef AMR_KOFF
@@ -1545,18 +1552,18 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
             const int fold_ok = env.fold != 0;                                                                         \
             if (env.nbuf != 3) {      /* default: two images = three workgroups per CU; DEVQA_ATTENTION_NBUF=3: the ring of three */ \
                 if (dma_nw == 9)                                                                                       \
-                    hipLaunchKernelGGL((attention_ring_kernel<DR, 9, 2>), dim3((unsigned)grid), dim3(576), 4 * 64 * 2 * DR, st, q, ldq, k, ldk, v, ldv, \
+                    hipLaunchKernelGGL((attention_ring_kernel<DR, 9, 2>), dim3((unsigned)grid), dim3(576), 4 * 64 * 2 * DR + 512, st, q, ldq, k, ldk, v, ldv, \
                                        out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                 \
                 else                                                                                                   \
-                    hipLaunchKernelGGL((attention_ring_kernel<DR, 8, 2>), dim3((unsigned)grid), dim3(512), 4 * 64 * 2 * DR, st, q, ldq, k, ldk, v, ldv, \
+                    hipLaunchKernelGGL((attention_ring_kernel<DR, 8, 2>), dim3((unsigned)grid), dim3(512), 4 * 64 * 2 * DR + 512, st, q, ldq, k, ldk, v, ldv, \
                                        out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                 \
             } else if (dma_nw == 9) {                                                                                  \
-                devqa_set_max_smem(attention_ring_kernel<DR, 9>, 6 * 64 * 2 * DR, attr9);                              \
-                hipLaunchKernelGGL((attention_ring_kernel<DR, 9>), dim3((unsigned)grid), dim3(576), 6 * 64 * 2 * DR, st, q, ldq, k, ldk, v, ldv, \
+                devqa_set_max_smem(attention_ring_kernel<DR, 9>, 6 * 64 * 2 * DR + 512, attr9);                              \
+                hipLaunchKernelGGL((attention_ring_kernel<DR, 9>), dim3((unsigned)grid), dim3(576), 6 * 64 * 2 * DR + 512, st, q, ldq, k, ldk, v, ldv, \
                                    out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                     \
             } else {                                                                                                   \
-                devqa_set_max_smem(attention_ring_kernel<DR, 8>, 6 * 64 * 2 * DR, attr8);                              \
-                hipLaunchKernelGGL((attention_ring_kernel<DR, 8>), dim3((unsigned)grid), dim3(512), 6 * 64 * 2 * DR, st, q, ldq, k, ldk, v, ldv, \
+                devqa_set_max_smem(attention_ring_kernel<DR, 8>, 6 * 64 * 2 * DR + 512, attr8);                              \
+                hipLaunchKernelGGL((attention_ring_kernel<DR, 8>), dim3((unsigned)grid), dim3(512), 6 * 64 * 2 * DR + 512, st, q, ldq, k, ldk, v, ldv, \
                                    out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                     \
             }                                                                                                          \
         } else if (dma) {                                                                                              \
@@ -1678,12 +1685,12 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 6; ++rep) {
             if (rep == 5) hipEventRecord(e0, nullptr);
             if (nw == 9) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(attention_ring_kernel<96, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 192);
-                hipLaunchKernelGGL((attention_ring_kernel<96, 9>), dim3((unsigned)grid), dim3(576), 6 * 64 * 192, nullptr, qkv, (int64_t)ld, qkv + H * dh, (int64_t)ld,
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attention_ring_kernel<96, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 192 + 512);
+                hipLaunchKernelGGL((attention_ring_kernel<96, 9>), dim3((unsigned)grid), dim3(576), 6 * 64 * 192 + 512, nullptr, qkv, (int64_t)ld, qkv + H * dh, (int64_t)ld,
                                    qkv + 2 * H * dh, (int64_t)ld, out, (int64_t)(H * dh), desc, H, dh, 0.1066f, 1, q_tiles, -n_seq);
             } else {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(attention_ring_kernel<96, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 192);
-                hipLaunchKernelGGL((attention_ring_kernel<96, 8>), dim3((unsigned)grid), dim3(512), 6 * 64 * 192, nullptr, qkv, (int64_t)ld, qkv + H * dh, (int64_t)ld,
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attention_ring_kernel<96, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 192 + 512);
+                hipLaunchKernelGGL((attention_ring_kernel<96, 8>), dim3((unsigned)grid), dim3(512), 6 * 64 * 192 + 512, nullptr, qkv, (int64_t)ld, qkv + H * dh, (int64_t)ld,
                                    qkv + 2 * H * dh, (int64_t)ld, out, (int64_t)(H * dh), desc, H, dh, 0.1066f, 1, q_tiles, -n_seq);
             }
             if (rep == 5) hipEventRecord(e1, nullptr);

@@ -548,7 +548,7 @@ def test_attention_is_deterministic_and_variants_agree(L):
                 assert torch.equal(base, folded)          # only the non-causal ring kernel folds
             else:
                 err = (base.float() - folded.float()).abs().max().item()
-                assert 0 < err < 4e-2, err                 # one bf16 ulp of an O(1) output is 2^-7 at most here
+                assert err < 4e-2, err                     # (the folded key's fp32 score comes from a VALU fma chain: an output may move by a bf16 ulp)
             for var in ("DEVQA_ATTENTION_DBUF", "DEVQA_ATTENTION_QB"):
                 os.environ[var] = "1" if var.endswith("DBUF") else "2"
                 try:
