@@ -745,8 +745,11 @@ __global__ __launch_bounds__(64 * NW, ((NW == 8 && DHP <= 96) || SB) ? 4 : 2) vo
 #ifdef AM_TIMING   /* hipcc -DAM_TIMING attention_mfma.hip -o build/am_timing: where a round's time goes (debug builds only) */
 __device__ unsigned long long* g_am_stamps;
 #define AM_STAMP(i) do { if (lane == 0 && (wave == 0 || wave == 7)) g_am_stamps[((size_t)blockIdx.x * 2 + (wave == 7)) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ int g_am_hs;            // layout experiment of the harness: element offset between heads of q / k / v (0: h * dh, the product layout)
+#define AMR_HOFF (g_am_hs ? h * g_am_hs : h * dh)
 #else
 #define AM_STAMP(i) do { } while (0)
+#define AMR_HOFF (h * dh)
 #endif
 template <int DHP, int NW, int NB = 3>
 __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kernel(const bf16_t* __restrict__ q, int64_t ldq,
@@ -794,7 +797,7 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kerne
     for (int ks = 0; ks < KS; ++ks) {
         const int c = ks * 32 + fq * 8;
         uint4 u = make_uint4(0, 0, 0, 0);
-        if (qrow < q_len && c < dh) u = *reinterpret_cast<const uint4*>(q + (int64_t)(q_start + qrow) * ldq + h * dh + c);
+        if (qrow < q_len && c < dh) u = *reinterpret_cast<const uint4*>(q + (int64_t)(q_start + qrow) * ldq + AMR_HOFF + c);
         qf[ks] = *reinterpret_cast<short8_t*>(&u);
     }
     // the folded key's rows of K and V go into 512 bytes behind the images (one DMA of wave 0, issued before -- so landed with -- chunk 0): piece i of
@@ -803,7 +806,7 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kerne
     if (fold && wave == 0 && (lane < CH || (lane >= 16 && lane < 16 + CH))) {
         const int64_t grow = n_keys < kp_len ? (int64_t)(kp_start + n_keys) : (int64_t)(ko_start + n_keys - kp_len);
         const int c = min((lane & 15) * 8, dh - 8);
-        const bf16_t* src = (lane < 16 ? k + grow * ldk : v + grow * ldv) + h * dh + c;
+        const bf16_t* src = (lane < 16 ? k + grow * ldk : v + grow * ldv) + AMR_HOFF + c;
         __builtin_amdgcn_global_load_lds((am_gptr_t)src, (am_lptr_t)odd, 16, 0, 0);
     }
     // ---- staging: DMA instruction j of staging wave w fills LDS bytes [(j * 8 + w) * 1024, + 1024) of the K | V image pair; rows past the last
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kerne
             unsigned char* dst = (is_v ? Vs3 : Ks3) + (BUFI) * IMG + blk * 1024;                                            \
             const int p = blk * 64 + ln_;                                                                                   \
             const int p_row = p / CH;                                                                                       \
-            const int p_col = h * dh + min(((p - p_row * CH) ^ am_swz<CH>(p_row)) * 8, dh - 8);                             \
+            const int p_col = AMR_HOFF + min(((p - p_row * CH) ^ am_swz<CH>(p_row)) * 8, dh - 8);                           \
             const int kidx = min((C0) + p_row, n_keys - 1);                                                                 \
             const int64_t grow = (kidx < kp_len) ? (int64_t)(kp_start + kidx) : (int64_t)(ko_start + kidx - kp_len);        \
             __builtin_amdgcn_global_load_lds((am_gptr_t)((is_v ? v : k) + grow * (is_v ? ldv : ldk) + p_col), (am_lptr_t)dst, 16, 0, 0); \
@@ -1674,6 +1677,45 @@ int main(int argc, char** argv) {
     std::vector<int32_t> hd(n_seq * 6);
     for (int i = 0; i < n_seq; ++i) { hd[i * 6] = i * T; hd[i * 6 + 1] = T; hd[i * 6 + 2] = 0; hd[i * 6 + 3] = 0; hd[i * 6 + 4] = i * T; hd[i * 6 + 5] = T; }
     hipMemcpy(desc, hd.data(), hd.size() * 4, hipMemcpyHostToDevice);
+    // layout experiment: the same values head-major and padded, [3][H][M][96] (rows of one head contiguous: whole-line requests)
+    bf16_t* hm;
+    hipMalloc(&hm, (size_t)3 * H * M * 96 * 2);
+    {
+        std::vector<unsigned short> g((size_t)3 * H * M * 96, 0);
+        for (size_t r = 0; r < M; ++r)
+            for (int w = 0; w < 3; ++w)
+                for (int hh = 0; hh < H; ++hh)
+                    for (int c = 0; c < dh; ++c) g[(((size_t)w * H + hh) * M + r) * 96 + c] = h[r * ld + (size_t)w * H * dh + hh * dh + c];
+        hipMemcpy(hm, g.data(), g.size() * 2, hipMemcpyHostToDevice);
+    }
+    for (int lay = 0; lay < 2; ++lay) {
+        const int hs = lay ? (int)(M * 96) : 0;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_am_hs), &hs, sizeof(hs));
+        const bf16_t* qp = lay ? hm : qkv;
+        const bf16_t* kp = lay ? hm + (size_t)H * M * 96 : qkv + H * dh;
+        const bf16_t* vp = lay ? hm + (size_t)2 * H * M * 96 : qkv + 2 * H * dh;
+        const int64_t ldl = lay ? 96 : (int64_t)ld;
+        const int q_tiles = (T + 143) / 144;
+        const long grid = (long)n_seq * H * q_tiles;
+        hipMalloc(&st, (size_t)grid * 2 * 64 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_am_stamps), &st, sizeof(st));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_ring_kernel<96, 9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 192 + 512);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        float best = 1e9f;
+        for (int rep = 0; rep < 12; ++rep) {
+            hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL((attention_ring_kernel<96, 9, 2>), dim3((unsigned)grid), dim3(576), 4 * 64 * 192 + 512, nullptr, qp, ldl, kp, ldl, vp, ldl, out,
+                               (int64_t)(H * dh), desc, H, dh, 0.1066f, 1, q_tiles, -n_seq);
+            hipEventRecord(e1, nullptr);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rep >= 2) best = std::min(best, ms);
+        }
+        printf("layout %s: ring<96, 9, 2> best of 10: %.1f us (stamped build)\n", lay ? "head-major padded [3][H][M][96]" : "row-major fused qkv [M][3 H dh]", best * 1e3);
+        hipFree(st);
+    }
+    { const int hs = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_am_hs), &hs, sizeof(hs)); }
     for (int nw = 8; nw <= 9; ++nw) {
         const int qt = 16 * nw, q_tiles = (T + qt - 1) / qt;
         const long grid = (long)n_seq * H * q_tiles;
