@@ -77,10 +77,24 @@ class IKEvl(VLLMBaseEditor):
     def retrieve(self, prompt: str, target: str) -> List[str]:
         new_fact = prompt + " " + target
         query = ike_sentence(new_fact, new_fact)                       # ike_main.py:196-198
-        q = torch.as_tensor(np.asarray(self.encode([query]), np.float32)).to(self.device).contiguous()
         k = min(self.cfg.k, self.stored.shape[0])
-        idx, _ = lib.cosine_topk(self.stored, q, k, True, True, corpus_inv_norm=self.stored_inv_norm)   # normalize_embeddings + semantic_search(dot)
-        icl = [self.stored_sentences[int(i)] for i in idx[0].tolist()]
+        # on its own stream: the ids are needed on the host now, and waiting for them must not wait for the probes the evaluator has
+        # queued on the main stream (it prepares this edit while the previous split's probes run)
+        side = self.__dict__.get("_retr_stream")
+        if side is None and torch.device(self.device).type == "cuda":
+            side = self._retr_stream = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))       # (the corpus and its norms were written on the main stream)
+        q_host = torch.as_tensor(np.asarray(self.encode([query]), np.float32))
+        if side is not None:
+            with torch.cuda.stream(side):
+                q = lib.h2d(q_host, torch.float32, self.device).contiguous()
+                idx, _ = lib.cosine_topk(self.stored, q, k, True, True, corpus_inv_norm=self.stored_inv_norm)   # normalize_embeddings + semantic_search(dot)
+                ids = idx[0].cpu().tolist()
+        else:
+            q = q_host.to(self.device).contiguous()
+            idx, _ = lib.cosine_topk(self.stored, q, k, True, True, corpus_inv_norm=self.stored_inv_norm)
+            ids = idx[0].tolist()
+        icl = [self.stored_sentences[int(i)] for i in ids]
         icl.append(query)                                              # ike_main.py:205-206
         return icl
 

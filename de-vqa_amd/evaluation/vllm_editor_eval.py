@@ -88,18 +88,21 @@ class VLLMEditorEvaluation:
         return [("pfx", ident, j) for j in range(pfx.shape[0])]
 
     @staticmethod
-    def _argmax_many(vllm, probes, max_rows=12288, prefix_fn=None):
+    def _argmax_many(vllm, probes, max_rows=12288, prefix_fn=None, defer=False):
         """[(prompt, image, target)] -> [(pre, y, m)], same values as _argmax_last per probe, but the probes of one
         evaluation phase (the model does not change inside a phase: 9 locality probes per sample before the edit, 12
         after, vllm_editor_eval.py:98-121) go through the decoder TOGETHER: inputs are built per probe through the
         plugin API (so editor hooks on get_llm_input_embeds still apply), packed without padding rows -- common prefixes once,
         see _plan_shared_prefixes -- the decoder runs once per <= max_rows rows and logits are computed on the label rows
         only.  `prefix_fn(prompt, image, target)` (retrieval editors: LTE_VL's `probe_prefix`) may return rows to put in front
-        of a probe's input; label rows are the LAST L, so nothing else moves."""
+        of a probe's input; label rows are the LAST L, so nothing else moves.
+        defer=True: everything is QUEUED (the argmax rows travel to pinned host memory behind an event) and a zero-argument function is
+        returned that waits for the event and yields the list -- the caller prepares its next phase on the host meanwhile."""
         from .. import lib
         eng = vllm.engine
         out = [None] * len(probes)
         items = []
+        waiting = []
         share = os.environ.get("DEVQA_PROBE_PREFIX_SHARE", "1") != "0"
         if hasattr(vllm, "image_features"):   # one batched encoder call for the phase's distinct images (fills the cache)
             uniq = {}
@@ -157,15 +160,35 @@ class VLLMEditorEvaluation:
             idx = lib.h2d(label_rows, torch.int32, rows.device)
             logits = eng.lm_head(lib.gather_rows(x_fin, idx))
             pre, _, _ = lib.vocab_rows(logits)
-            pre = pre.to(torch.long).cpu()      # ONE device -> host transfer for the whole phase: decoding and accuracies are host work
-            r0 = 0
-            for p_ in order:
-                i, _, y, m, _k = items[p_]
-                L = y.shape[1]
-                out[i] = (pre[r0:r0 + L].unsqueeze(0), VLLMEditorEvaluation._host(y), VLLMEditorEvaluation._host(m))
-                r0 += L
+            if defer:
+                pre_dev = pre.to(torch.long)
+                pre_host = torch.empty(pre_dev.shape, dtype=torch.long, pin_memory=True)
+                pre_host.copy_(pre_dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                waiting.append((ev, pre_host, pre_dev, order))
+            else:
+                pre = pre.to(torch.long).cpu()      # ONE device -> host transfer for the whole phase: decoding and accuracies are host work
+                VLLMEditorEvaluation._scatter_pre(out, items, order, pre)
             start = end
-        return out
+        if not defer:
+            return out
+
+        def finish():
+            for ev, pre_host, _pre_dev, order in waiting:
+                ev.synchronize()
+                VLLMEditorEvaluation._scatter_pre(out, items, order, pre_host)
+            return out
+        return finish
+
+    @staticmethod
+    def _scatter_pre(out, items, order, pre):
+        r0 = 0
+        for p_ in order:
+            i, _, y, m, _k = items[p_]
+            L = y.shape[1]
+            out[i] = (pre[r0:r0 + L].unsqueeze(0), VLLMEditorEvaluation._host(y), VLLMEditorEvaluation._host(m))
+            r0 += L
 
     @staticmethod
     def _host(t):
@@ -189,28 +212,33 @@ class VLLMEditorEvaluation:
             label_masks = label_masks.cpu() if label_masks.is_cuda else label_masks
         return float(((pre_y == label_ids) * label_masks).sum() / label_masks.sum())
 
-    def __get_results_after_edit__(self, vllm, ed, rd, batch_probes=False, prefix_fn=None):
+    def __get_results_after_edit__(self, vllm, ed, rd, batch_probes=False, prefix_fn=None, defer=False):
+        """defer (batched probes only): the probes are queued and a function is returned that completes `rd` once they have run."""
         tok = vllm.get_llm_tokenizer()
         if batch_probes:
             probes = [(e["prompt"], e["image"], e["target_new"]) for e in ed["requests"]]
             probes += [(e["prompt"], e["image"], e["target"]) for g in ed["generality"] for e in ed["generality"][g]]
             probes += [(e["prompt"], e["image"], e["target"]) for l in ed["locality"] for e in ed["locality"][l]]
-            res = iter(self._argmax_many(vllm, probes, prefix_fn=prefix_fn))
-            for rdr in rd["reliability"]:
-                pre, y, m = next(res)
-                rdr["predict_after_edit"] = tok.decode(pre[m.to(bool)])
-                rdr["acc"] = self._acc(pre, y, m)
-            for gen_name in ed["generality"]:
-                for rdg in rd["generality"][gen_name]:
+            got = self._argmax_many(vllm, probes, prefix_fn=prefix_fn, defer=defer)
+
+            def fill():
+                res = iter(got() if defer else got)
+                for rdr in rd["reliability"]:
                     pre, y, m = next(res)
-                    rdg["predict_after_edit"] = tok.decode(pre[m.to(bool)])
-                    rdg["acc"] = self._acc(pre, y, m)
-            for loc_name in ed["locality"]:
-                for rdl, edl in zip(rd["locality"][loc_name], ed["locality"][loc_name]):
-                    pre, _, m = next(res)
-                    rdl["predict_after_edit"] = tok.decode(pre[m.to(bool)])
-                    rdl["acc"] = self._acc(pre, edl["before_edit_ids"], m)
-            return rd
+                    rdr["predict_after_edit"] = tok.decode(pre[m.to(bool)])
+                    rdr["acc"] = self._acc(pre, y, m)
+                for gen_name in ed["generality"]:
+                    for rdg in rd["generality"][gen_name]:
+                        pre, y, m = next(res)
+                        rdg["predict_after_edit"] = tok.decode(pre[m.to(bool)])
+                        rdg["acc"] = self._acc(pre, y, m)
+                for loc_name in ed["locality"]:
+                    for rdl, edl in zip(rd["locality"][loc_name], ed["locality"][loc_name]):
+                        pre, _, m = next(res)
+                        rdl["predict_after_edit"] = tok.decode(pre[m.to(bool)])
+                        rdl["acc"] = self._acc(pre, edl["before_edit_ids"], m)
+                return rd
+            return fill if defer else fill()
         for rdr, edr in zip(rd["reliability"], ed["requests"]):
             pre, y, m = self._argmax_last(vllm, edr["prompt"], edr["image"], edr["target_new"])
             rdr["predict_after_edit"] = tok.decode(pre[m.to(bool)])
@@ -345,6 +373,18 @@ class VLLMEditorEvaluation:
         pfx = getattr(editor, "probe_prefix", None) if bp else None
         editor.restore_to_original_model()
         results = []
+        # batched probes: the host runs ONE SPLIT AHEAD of the GPU -- a split's post-edit probes are queued, the next split's edit and
+        # inputs are prepared (tokenisation, prompt assembly: tens of ms per split for the in-context editors) while they run, and only then
+        # are the queued split's argmax rows read back and decoded.  Same kernels in the same stream order, same results.
+        look_ahead = bp and os.environ.get("DEVQA_EVAL_LOOKAHEAD", "1") != "0"
+        pending = None           # (fill functions of the queued split, its result list)
+
+        def flush():
+            nonlocal pending
+            if pending is not None:
+                fills, split_res = pending
+                split_res.extend(f() for f in fills)
+                pending = None
         for g0 in range(0, len(eval_data), group):
             grp = list(zip(result_data[g0:g0 + group], eval_data[g0:g0 + group]))
             pairs = []
@@ -373,11 +413,19 @@ class VLLMEditorEvaluation:
                         start_t = time()
                         editor.edit_one_piece(edr)
                         rdr["edit_time"] = time() - start_t
+                if look_ahead:
+                    fills = [self.__get_results_after_edit__(editor.vllm, ed, rd, bp, pfx, defer=True) for rd, ed in zip(split_rd, split_ed)]
+                    editor.restore_to_original_model()
+                    flush()                       # the PREVIOUS split: its probes ran while this one was prepared
+                    pending = (fills, split_res)
+                    results.append(split_res)
+                    continue
                 for rd, ed in zip(split_rd, split_ed):
                     rd = self.__get_results_after_edit__(editor.vllm, ed, rd, bp, pfx)
                     split_res.append(rd)
                 editor.restore_to_original_model()
                 results.append(split_res)
+        flush()
         return results
 
     # -- vllm_editor_eval.py:177-229 ------------------------------------------------------------------
