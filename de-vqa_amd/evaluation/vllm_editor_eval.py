@@ -388,6 +388,20 @@ class VLLMEditorEvaluation:
         for g0 in range(0, len(eval_data), group):
             grp = list(zip(result_data[g0:g0 + group], eval_data[g0:g0 + group]))
             pairs = []
+            if bp and hasattr(editor.vllm, "image_features") and hasattr(editor.vllm, "image_key"):
+                # every image the group's probes will show (pre- AND post-edit: the rephrase image is first seen after the edit) through
+                # the vision tower in ONE call -- per split it would be a one-image call: ~160 launches of a 257-row ViT
+                uniq = {}
+                for _, split_ed in grp:
+                    for ed in split_ed:
+                        entries = list(ed["requests"]) + [e for g in ed["generality"] for e in ed["generality"][g]]
+                        entries += [e for ln in ed["locality"] for e in ed["locality"][ln]]
+                        for e in entries:
+                            k = editor.vllm.image_key(e.get("image"))
+                            if k is not None:
+                                uniq.setdefault(k, e["image"])
+                if 1 < len(uniq) <= 128:       # (the wrapper's cache holds 160 images)
+                    editor.vllm.image_features(list(uniq.values()))
             for split_rd, split_ed in grp:
                 for rd, ed in zip(split_rd, split_ed):
                     rd["reliability"] = rd.pop("requests")
