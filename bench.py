@@ -198,8 +198,9 @@ def cpu_baseline(cfg, seed, threads, arrays, cycles, n_cycles, style="opt", trac
 
 
 def hbm_micro(dev, d_out=2560, d_in=10240):
-    """HBM-regime kernels measured on their own with HIP events (lib.profile slots): the DENSE ft_adamw_step sweep
-    (6 x 4 x 2560 x 10240 = 629 MB per edit-step) and cosine top-k over the VLKEB-shaped corpus 15000 x 384 (config #5)."""
+    """HBM-regime kernels measured on their own with HIP events (lib.profile slots): the DENSE ft_adamw_step sweep in the form the path
+    runs it (first moment kept as its rank-L factors: w and v cross HBM, 4 x 4 x 2560 x 10240 = 419 MB per edit-step; the form with a
+    first-moment matrix, 6 x 4 = 629 MB, beside it) and cosine top-k over the VLKEB-shaped corpus 15000 x 384 (config #5)."""
     import torch
     from devqa_amd import lib
     out = {}
@@ -208,24 +209,27 @@ def hbm_micro(dev, d_out=2560, d_in=10240):
     w0 = torch.randn((d_out, d_in), device=dev, generator=g) * 0.01
     w = torch.empty((E, d_out, d_in), device=dev)
     mom, var = torch.empty_like(w), torch.empty_like(w)
+    dstate = torch.empty((E, L, d_out), device=dev)
     a = torch.rand((E, L, d_in), device=dev, generator=g)
     dy = torch.randn((E, L, d_out), device=dev, generator=g) * 1e-3
     y = torch.empty((E, L, d_out), device=dev)
     one = torch.ones(E, dtype=torch.int32, device=dev)
     t = torch.zeros(E, dtype=torch.int32, device=dev)
-    for it in range(steps + 2):
-        if it == 2:
-            torch.cuda.synchronize()
-            lib.profile(1)
-        t += 1
-        lib.ft_adamw_step(w, mom, var, w0, a, dy, y, one, t, 1e-3, 0.9, 0.999, 1e-8, 0.0, -1.0)
-    lib.profile(0)
-    ms, _, n = lib.profile_read(lib.PROF_FT_ADAMW)
-    per = 24.0 * d_out * d_in
-    out["ft_adamw_step_dense"] = {"kernel": "ft_adamw_step_kernel (dense [2560,10240] per edit)", "bytes_per_edit_step": per,
-                                  "edits": E, "launches": int(n), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
-                                  "achieved": round(per * E * n / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(per * E * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    for name, per, fn in (("ft_adamw_step_dense", 16.0 * d_out * d_in, lambda: lib.ft_adamw_step_fm(w, dstate, var, w0, a, dy, y, one, t, 1e-3, 0.9, 0.999, 1e-8, 0.0, -1.0)),
+                          ("ft_adamw_step_dense_m_matrix", 24.0 * d_out * d_in, lambda: lib.ft_adamw_step(w, mom, var, w0, a, dy, y, one, t, 1e-3, 0.9, 0.999, 1e-8, 0.0, -1.0))):
+        t.zero_()
+        for it in range(steps + 2):
+            if it == 2:
+                torch.cuda.synchronize()
+                lib.profile(1)
+            t += 1
+            fn()
+        lib.profile(0)
+        ms, _, n = lib.profile_read(lib.PROF_FT_ADAMW)
+        out[name] = {"kernel": "ft_adamw_step_kernel (dense [2560,10240] per edit%s)" % ("; first moment from its rank-L factors" if "matrix" not in name else "; first-moment matrix"),
+                     "bytes_per_edit_step": per, "edits": E, "launches": int(n), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
+                     "achieved": round(per * E * n / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(per * E * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del w, mom, var
     N, D, Q = 15000, 384, 1000
     corpus = torch.randn((N, D), device=dev, generator=g)
@@ -556,7 +560,7 @@ def side_kernels(be, elapsed):
           "achieved": round(by / 1e9 / (ms / 1e3), 1) if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": round(by / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms > 0 else 0.0,
           "algorithmic_bytes": by, "updates": int(be.stats.get("updates", 0)), "npad_mean": round(npad_mean, 1),
-          "bytes_rule": "fp32 [2560, npad] per edit: first update 4 tensors (read w0; write w, m, v), later updates 6 (read + write w, m, v)",
+          "bytes_rule": "fp32 [2560, npad] per edit: first update 3 tensors (read w0; write w, v), later updates 4 (read + write w, v); the first moment is rebuilt per element from the EMA of dy (devqa_ft_adamw_step_fm), it has no matrix",
           "time_frac_of_step": round(ms / 1e3 / elapsed, 3)}
     return att, ln, ft
 

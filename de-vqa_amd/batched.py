@@ -490,12 +490,12 @@ class BatchedEditEval:
         meta = [(int(steps_h[e]), float(losses_h[e, max(int(steps_h[e]) - 1, 0)])) for e in range(E)]
         self.stats["cycles"] += E
         self.stats["steps"] += int(steps_h.sum())
-        # algorithmic HBM bytes of the executed AdamW updates (include/devqa.h, devqa_ft_adamw_step): the first update of an edit
-        # reads w0 and writes w, m, v (4 tensors), every later one reads and writes w, m, v (6 tensors), fp32, on [Dout, npad]
+        # algorithmic HBM bytes of the executed AdamW updates (include/devqa.h, devqa_ft_adamw_step_fm): the first update of an edit
+        # reads w0 and writes w, v (3 tensors), every later one reads and writes w, v (4 tensors), fp32, on [Dout, npad]
         Dout_, npad_ = h["ft_shape"]
         n_upd = int(upd_h.sum())
         self.stats["updates"] = self.stats.get("updates", 0) + n_upd
-        self.stats["ft_bytes"] = self.stats.get("ft_bytes", 0) + 4 * Dout_ * npad_ * (6 * n_upd - 2 * int((upd_h > 0).sum()))
+        self.stats["ft_bytes"] = self.stats.get("ft_bytes", 0) + 4 * Dout_ * npad_ * (4 * n_upd - int((upd_h > 0).sum()))
         self.last_losses = losses_h
         self.last_steps = steps_h
         self.stats["t_host"] += time.time() - t5
@@ -574,7 +574,9 @@ class BatchedEditEval:
         losses = torch.zeros((E, cfg.num_steps), dtype=torch.float32, device=dev)
         # engines without a path-level context (LLaVA / MiniGPT-4 decoders): the same loop, launched from here
         w = torch.empty((E, Dout, npad), dtype=torch.float32, device=dev) if dense else w0.clone()   # dense: the first update reads w0
-        mom = torch.empty_like(w)
+        factored = os.environ.get("DEVQA_FT_FACTORED", "1") != "0"
+        # EMA of dy: first moment = dstate^T (x) a_ft (ft_adamw_step_fm); DEVQA_FT_FACTORED=0: the first-moment matrix
+        dstate = torch.empty((E, kmax, Dout), dtype=torch.float32, device=dev) if factored else torch.empty_like(w)
         var = torch.empty_like(w)
         y = lib.rows_matvec(w0, a_ft)  # step-0 fc2 rows with the pristine matrix (active columns carry all of W.a)
         dl_dtype = eng.adt
@@ -586,14 +588,15 @@ class BatchedEditEval:
             lib.ft_step_control(nll, t_mask, it, cfg.num_steps, 1e-2, active, do_update, n_steps, adam_t, losses)
             dH = lib.gemm_rows_longk(dlog, self.vllm.model.embed_T)
             dy = eng.final_norm_bwd(y2, dH, add=resid_ft).view(E, kmax, Dout)
-            lib.ft_adamw_step(w, mom, var, w0, a_ft, dy, y, do_update, adam_t, cfg.lr, 0.9, 0.999, 1e-8, cfg.weight_decay,
-                              clamp)
+            (lib.ft_adamw_step_fm if factored else lib.ft_adamw_step)(w, dstate, var, w0, a_ft, dy, y, do_update, adam_t, cfg.lr, 0.9, 0.999, 1e-8,
+                                                                      cfg.weight_decay, clamp)
         self._adam_t = adam_t
         self._ft_shape = (Dout, npad)
+        delta = var           # (the second-moment buffer is free now)
         if dense:   # edits that never updated (first loss already under the floor) have an unwritten w: their delta is zero
-            mom.zero_()
+            delta.zero_()
             for e in torch.nonzero(adam_t > 0).flatten().tolist():
-                lib.delta_op(0, w[e], w0, mom[e])
+                lib.delta_op(0, w[e], w0, delta[e])
         else:
-            lib.delta_op(0, w, w0, mom)  # mom := w - w0 (reuse the buffer): the compacted delta
-        return n_steps, losses, mom, idx, cnt, npad
+            lib.delta_op(0, w, w0, delta)  # delta := w - w0: the compacted delta
+        return n_steps, losses, delta, idx, cnt, npad

@@ -5,6 +5,12 @@
 //                   -> AdamW (torch.optim.AdamW semantics) -> optional L-inf clamp
 //                   -> y = W_new . a for the next step's forward, all in one sweep.
 //                   Algorithmic bytes per edit-step: 6 x 4 x Dout x Din (r/w of w, m, v).
+//   ..._fm        : the same step WITHOUT a first-moment matrix (FM = factored momentum).  Inside one edit's loop the a-rows are constant
+//                   (everything below the edited matrix is frozen), so every gradient is dy_t^T a and the first moment is
+//                   m_t = D_t^T a with D_t = lerp(D_{t-1}, dy_t, 1 - beta1): an [L, Dout] state instead of a [Dout, Din] matrix.  m_t is
+//                   rebuilt per element from D_t and the a-values the sweep holds anyway (L fmas); only w and v cross HBM:
+//                   4 x 4 x Dout x Din bytes per edit-step instead of 6 x 4 (first update: read w0, write w, v).  The second moment
+//                   cannot be factored the same way in fp32 (sums of squares of sums cancel), it stays a matrix.
 //   rows_matvec   : y = W . a (+bias +resid) for a few cached rows.
 //
 // Work decomposition: one workgroup (256 threads) owns ROWS consecutive output rows i of one
@@ -16,7 +22,7 @@
 
 // NARROW (column-compacted matrices, Din of a few hundred): every WAVE owns its own ROWS rows (the workgroup 4 x ROWS) and
 // strides Din with its 64 lanes -- with 256 threads on one row group only Din/4 of them would have a float4 to work on.
-template <int L, int ROWS, bool NARROW = false>
+template <int L, int ROWS, bool NARROW = false, bool FM = false>
 __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ w, float* __restrict__ m,
                                                             float* __restrict__ v, const float* __restrict__ w0,
                                                             const float* __restrict__ a, const float* __restrict__ dy,
@@ -40,7 +46,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
     const int i0 = NARROW ? (rb * 4 + (int)(threadIdx.x >> 6)) * ROWS : rb * ROWS;
     const int64_t mat = (int64_t)Dout * Din;
     float* we = w + (int64_t)e * mat;
-    float* me = m + (int64_t)e * mat;
+    float* me = FM ? m + (int64_t)e * Lmax * Dout : m + (int64_t)e * mat;       // FM: the [Lmax, Dout] state D (laid out like dy)
     float* ve = v + (int64_t)e * mat;
     const float* ae = a + (int64_t)e * Lmax * Din;
     const float* dye = dy + (int64_t)e * Lmax * Dout;
@@ -50,6 +56,16 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
         for (int l = 0; l < L; ++l) dyv[r][l] = (i0 + r < Dout && l < Lmax) ? dye[(int64_t)l * Dout + i0 + r] : 0.f;
+    float dn[FM ? ROWS : 1][FM ? L : 1];      // FM: D_t of this workgroup's (wave's) rows
+    if constexpr (FM) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const float dold = (!first && i0 + r < Dout && l < Lmax) ? me[(int64_t)l * Dout + i0 + r] : 0.f;
+                dn[r][l] = dold + (dyv[r][l] - dold) * (1.f - beta1);
+            }
+    }
 
     float ysum[ROWS][L];
 #pragma unroll
@@ -68,15 +84,14 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
             const int i = i0 + r;
             if (i >= Dout) continue;
             const int64_t off = (int64_t)i * nv + c;
-            float4 wv, mv, vv, w0v;
+            float4 wv, mv = make_float4(0.f, 0.f, 0.f, 0.f), vv, w0v;
             if (first) {
                 w0v = reinterpret_cast<const float4*>(w0)[off];
                 wv = w0v;
-                mv = make_float4(0.f, 0.f, 0.f, 0.f);
                 vv = mv;
             } else {
                 wv = reinterpret_cast<const float4*>(we)[off];
-                mv = reinterpret_cast<const float4*>(me)[off];
+                if constexpr (!FM) mv = reinterpret_cast<const float4*>(me)[off];
                 vv = reinterpret_cast<const float4*>(ve)[off];
                 if (clamp_eps >= 0.f) w0v = reinterpret_cast<const float4*>(w0)[off];
             }
@@ -92,18 +107,27 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
             float mq[4] = {mv.x, mv.y, mv.z, mv.w};
             float vq[4] = {vv.x, vv.y, vv.z, vv.w};
             const float w0q[4] = {w0v.x, w0v.y, w0v.z, w0v.w};
+            if constexpr (FM) {           // m_t = D_t^T a (the lerp was taken on D)
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    mq[0] += dn[r][l] * av[l].x;
+                    mq[1] += dn[r][l] * av[l].y;
+                    mq[2] += dn[r][l] * av[l].z;
+                    mq[3] += dn[r][l] * av[l].w;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 // torch.optim.AdamW (single-tensor path): decay, lerp m, addcmul v, addcdiv
                 wq[k] *= decay;
-                mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
+                if constexpr (!FM) mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
                 vq[k] = vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
                 const float denom = sqrtf(vq[k]) / bc2_sqrt + eps;
                 wq[k] -= step_size * (mq[k] / denom);
                 if (clamp_eps >= 0.f) wq[k] = fminf(fmaxf(wq[k], w0q[k] - clamp_eps), w0q[k] + clamp_eps);
             }
             reinterpret_cast<float4*>(we)[off] = make_float4(wq[0], wq[1], wq[2], wq[3]);
-            reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
+            if constexpr (!FM) reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
             reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
 #pragma unroll
             for (int l = 0; l < L; ++l)
@@ -117,7 +141,10 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const float s = wave_sum(ysum[r][l]);
-                if (lane == 0 && i0 + r < Dout && l < Lmax) y[((int64_t)e * Lmax + l) * Dout + i0 + r] = s;
+                if (lane == 0 && i0 + r < Dout && l < Lmax) {
+                    y[((int64_t)e * Lmax + l) * Dout + i0 + r] = s;
+                    if constexpr (FM) me[(int64_t)l * Dout + i0 + r] = dn[r][l];      // (every lane of the wave read the old value at entry)
+                }
             }
         return;
     }
@@ -134,6 +161,10 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
         if (i0 + r < Dout && l < Lmax) {
             const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
             y[((int64_t)e * Lmax + l) * Dout + i0 + r] = s;
+            if constexpr (FM) {       // behind the barrier: every thread read the old D at entry
+                const float dold = first ? 0.f : me[(int64_t)l * Dout + i0 + r];
+                me[(int64_t)l * Dout + i0 + r] = dold + (dye[(int64_t)l * Dout + i0 + r] - dold) * (1.f - beta1);
+            }
         }
     }
 }
@@ -143,7 +174,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
 // bench line reported): G lanes own a row (G = 16 or 8: 256- or 128-byte contiguous pieces per row and step), a wave 64 / G rows,
 // a workgroup 4 x 64 / G; ceil(nv / G) steps cover a row with at most G - 1 idle lane-steps (68 float4: 9 steps of 8, 94 %).
 // The per-row dot products for the next forward reduce inside the G-lane group.  Same per-element arithmetic as above.
-template <int L, int G>
+template <int L, int G, bool FM = false>
 __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __restrict__ w, float* __restrict__ m,
                                                                     float* __restrict__ v, const float* __restrict__ w0,
                                                                     const float* __restrict__ a, const float* __restrict__ dy,
@@ -170,15 +201,19 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
     const int ic = row_ok ? i : Dout - 1;                  // idle groups shadow the last row (loads only)
     const int64_t mat = (int64_t)Dout * Din;
     float* we = w + (int64_t)e * mat;
-    float* me = m + (int64_t)e * mat;
+    float* me = FM ? m + (int64_t)e * Lmax * Dout : m + (int64_t)e * mat;       // FM: the [Lmax, Dout] state D (laid out like dy)
     float* ve = v + (int64_t)e * mat;
     const float* ae = a + (int64_t)e * Lmax * Din;
     const float* dye = dy + (int64_t)e * Lmax * Dout;
-    float dyv[L], ysum[L];
+    float dyv[L], ysum[L], dn[FM ? L : 1];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         dyv[l] = (l < Lmax) ? dye[(int64_t)l * Dout + ic] : 0.f;
         ysum[l] = 0.f;
+        if constexpr (FM) {
+            const float dold = (!first && l < Lmax) ? me[(int64_t)l * Dout + ic] : 0.f;
+            dn[l] = dold + (dyv[l] - dold) * (1.f - beta1);
+        }
     }
     const int nv = Din >> 2;
 #pragma unroll 2
@@ -188,15 +223,14 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
         for (int l = 0; l < L; ++l)
             av[l] = (l < Lmax) ? reinterpret_cast<const float4*>(ae + (int64_t)l * Din)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         const int64_t off = (int64_t)ic * nv + c;
-        float4 wv, mv, vv, w0v;
+        float4 wv, mv = make_float4(0.f, 0.f, 0.f, 0.f), vv, w0v;
         if (first) {
             w0v = reinterpret_cast<const float4*>(w0)[off];
             wv = w0v;
-            mv = make_float4(0.f, 0.f, 0.f, 0.f);
             vv = mv;
         } else {
             wv = reinterpret_cast<const float4*>(we)[off];
-            mv = reinterpret_cast<const float4*>(me)[off];
+            if constexpr (!FM) mv = reinterpret_cast<const float4*>(me)[off];
             vv = reinterpret_cast<const float4*>(ve)[off];
             if (clamp_eps >= 0.f) w0v = reinterpret_cast<const float4*>(w0)[off];
         }
@@ -212,10 +246,19 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
         float mq[4] = {mv.x, mv.y, mv.z, mv.w};
         float vq[4] = {vv.x, vv.y, vv.z, vv.w};
         const float w0q[4] = {w0v.x, w0v.y, w0v.z, w0v.w};
+        if constexpr (FM) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                mq[0] += dn[l] * av[l].x;
+                mq[1] += dn[l] * av[l].y;
+                mq[2] += dn[l] * av[l].z;
+                mq[3] += dn[l] * av[l].w;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             wq[k] *= decay;
-            mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
+            if constexpr (!FM) mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
             vq[k] = vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
             const float denom = sqrtf(vq[k]) / bc2_sqrt + eps;
             wq[k] -= step_size * (mq[k] / denom);
@@ -223,7 +266,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
         }
         if (row_ok) {
             reinterpret_cast<float4*>(we)[off] = make_float4(wq[0], wq[1], wq[2], wq[3]);
-            reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
+            if constexpr (!FM) reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
             reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
         }
 #pragma unroll
@@ -235,14 +278,17 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
         float s = ysum[l];
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (sub == 0 && row_ok && l < Lmax) y[((int64_t)e * Lmax + l) * Dout + i] = s;
+        if (sub == 0 && row_ok && l < Lmax) {
+            y[((int64_t)e * Lmax + l) * Dout + i] = s;
+            if constexpr (FM) me[(int64_t)l * Dout + i] = dn[l];          // (the group's lanes read the old value at entry, same wave)
+        }
     }
 }
 
 // WIDE (17..64 loss rows per edit: long targets, e.g. captions): the G = 16 lane-group form with the a-rows NOT held in registers --
 // each float4 column step reads the L a-values twice (gradient, then next-forward dot products) from L1 / L2, where the [L, Din]
 // block of an edit (<= 2.6 MB) lives anyway.  Same per-element arithmetic and summation order over l as the kernels above.
-template <int L>
+template <int L, bool FM = false>
 __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                                  const float* __restrict__ w0, const float* __restrict__ a,
                                                                  const float* __restrict__ dy, float* __restrict__ y,
@@ -268,32 +314,36 @@ __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restri
     const int ic = row_ok ? i : Dout - 1;
     const int64_t mat = (int64_t)Dout * Din;
     float* we = w + (int64_t)e * mat;
-    float* me = m + (int64_t)e * mat;
+    float* me = FM ? m + (int64_t)e * Lmax * Dout : m + (int64_t)e * mat;       // FM: the [Lmax, Dout] state D (laid out like dy)
     float* ve = v + (int64_t)e * mat;
     const float* ae = a + (int64_t)e * Lmax * Din;
     const float* dye = dy + (int64_t)e * Lmax * Dout;
-    float dyv[L], ysum[L];
+    float dyv[L], ysum[L], dn[FM ? L : 1];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         dyv[l] = (l < Lmax) ? dye[(int64_t)l * Dout + ic] : 0.f;
         ysum[l] = 0.f;
+        if constexpr (FM) {
+            const float dold = (!first && l < Lmax) ? me[(int64_t)l * Dout + ic] : 0.f;
+            dn[l] = dold + (dyv[l] - dold) * (1.f - beta1);
+        }
     }
     const int nv = Din >> 2;
     for (int c = sub; c < nv; c += G) {
         const int64_t off = (int64_t)ic * nv + c;
-        float4 wv, mv, vv, w0v;
+        float4 wv, mv = make_float4(0.f, 0.f, 0.f, 0.f), vv, w0v;
         if (first) {
             w0v = reinterpret_cast<const float4*>(w0)[off];
             wv = w0v;
-            mv = make_float4(0.f, 0.f, 0.f, 0.f);
             vv = mv;
         } else {
             wv = reinterpret_cast<const float4*>(we)[off];
-            mv = reinterpret_cast<const float4*>(me)[off];
+            if constexpr (!FM) mv = reinterpret_cast<const float4*>(me)[off];
             vv = reinterpret_cast<const float4*>(ve)[off];
             if (clamp_eps >= 0.f) w0v = reinterpret_cast<const float4*>(w0)[off];
         }
         float g[4] = {0.f, 0.f, 0.f, 0.f};
+        float mq[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             if (l < Lmax) {
@@ -302,16 +352,21 @@ __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restri
                 g[1] += dyv[l] * av.y;
                 g[2] += dyv[l] * av.z;
                 g[3] += dyv[l] * av.w;
+                if constexpr (FM) {
+                    mq[0] += dn[l] * av.x;
+                    mq[1] += dn[l] * av.y;
+                    mq[2] += dn[l] * av.z;
+                    mq[3] += dn[l] * av.w;
+                }
             }
         }
         float wq[4] = {wv.x, wv.y, wv.z, wv.w};
-        float mq[4] = {mv.x, mv.y, mv.z, mv.w};
         float vq[4] = {vv.x, vv.y, vv.z, vv.w};
         const float w0q[4] = {w0v.x, w0v.y, w0v.z, w0v.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             wq[k] *= decay;
-            mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
+            if constexpr (!FM) mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
             vq[k] = vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
             const float denom = sqrtf(vq[k]) / bc2_sqrt + eps;
             wq[k] -= step_size * (mq[k] / denom);
@@ -319,7 +374,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restri
         }
         if (row_ok) {
             reinterpret_cast<float4*>(we)[off] = make_float4(wq[0], wq[1], wq[2], wq[3]);
-            reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
+            if constexpr (!FM) reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
             reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
         }
 #pragma unroll
@@ -335,24 +390,27 @@ __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restri
         float s = ysum[l];
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (sub == 0 && row_ok && l < Lmax) y[((int64_t)e * Lmax + l) * Dout + i] = s;
+        if (sub == 0 && row_ok && l < Lmax) {
+            y[((int64_t)e * Lmax + l) * Dout + i] = s;
+            if constexpr (FM) me[(int64_t)l * Dout + i] = dn[l];
+        }
     }
 }
 
-template <int L>
+template <int L, bool FM>
 static int launch_adamw_wide(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
                              const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din, float lr,
                              float beta1, float beta2, float eps, float wd, float clamp_eps, int64_t w0_stride_e, hipStream_t st) {
     const int row_blocks = (Dout + 15) / 16;
     const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
-    hipLaunchKernelGGL((ft_adamw_step_wide_kernel<L>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update, adam_t,
+    hipLaunchKernelGGL((ft_adamw_step_wide_kernel<L, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update, adam_t,
                        Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
-    devqa_prof_end(ph, 24.0 * E * (double)Dout * Din, st);
+    devqa_prof_end(ph, (FM ? 16.0 : 24.0) * E * (double)Dout * Din, st);
     DEVQA_LAUNCH_CHECK("ft_adamw_step(wide)");
     return DEVQA_OK;
 }
 
-template <int L, int ROWS>
+template <int L, int ROWS, bool FM>
 static int launch_adamw(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
                         const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din, float lr,
                         float beta1, float beta2, float eps, float wd, float clamp_eps, int64_t w0_stride_e, hipStream_t st) {
@@ -366,37 +424,38 @@ static int launch_adamw(float* w, float* m, float* v, const float* w0, const flo
         const int row_blocks = (Dout + rows_wg - 1) / rows_wg;
         const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
         if (G == 16)
-            hipLaunchKernelGGL((ft_adamw_step_grouped_kernel<L, 16>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update,
+            hipLaunchKernelGGL((ft_adamw_step_grouped_kernel<L, 16, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update,
                                adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
         else
-            hipLaunchKernelGGL((ft_adamw_step_grouped_kernel<L, 8>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update,
+            hipLaunchKernelGGL((ft_adamw_step_grouped_kernel<L, 8, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update,
                                adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
-        devqa_prof_end(ph, 24.0 * E * (double)Dout * Din, st);
+        devqa_prof_end(ph, (FM ? 16.0 : 24.0) * E * (double)Dout * Din, st);
         DEVQA_LAUNCH_CHECK("ft_adamw_step(grouped)");
         return DEVQA_OK;
     }
     if (Din <= 1024) {
         const int row_blocks = (Dout + 4 * ROWS - 1) / (4 * ROWS);
         const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
-        hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS, true>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
+        hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS, true, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
                            do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
-        devqa_prof_end(ph, 24.0 * E * (double)Dout * Din, st);
+        devqa_prof_end(ph, (FM ? 16.0 : 24.0) * E * (double)Dout * Din, st);
         DEVQA_LAUNCH_CHECK("ft_adamw_step");
         return DEVQA_OK;
     }
     const int row_blocks = (Dout + ROWS - 1) / ROWS;
     const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
-    hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
+    hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS, false, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
                        do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
-    devqa_prof_end(ph, 24.0 * E * (double)Dout * Din, st);
+    devqa_prof_end(ph, (FM ? 16.0 : 24.0) * E * (double)Dout * Din, st);
     DEVQA_LAUNCH_CHECK("ft_adamw_step");
     return DEVQA_OK;
 }
 
-extern "C" int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
-                                   const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
-                                   float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
-                                   int64_t w0_stride_e, void* stream) {
+template <bool FM>
+static int ft_adamw_step_impl(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
+                              const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
+                              int64_t w0_stride_e, void* stream) {
     DEVQA_CHECK_ARG(w && m && v && w0 && a && dy && y && do_update && adam_t, "ft_adamw_step: null pointer");
     if (E == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(E > 0 && Lmax >= 1 && Lmax <= DEVQA_FT_MAX_ROWS, "ft_adamw_step: Lmax=%d unsupported (1..64)", Lmax);
@@ -404,14 +463,30 @@ extern "C" int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0
     DEVQA_CHECK_SHAPE((long)E * ((Dout + 1) / 2) < 2147483647L, "ft_adamw_step: grid too large");
     hipStream_t st = (hipStream_t)stream;
 #define ARGS w, m, v, w0, a, dy, y, do_update, adam_t, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps, w0_stride_e, st
-    if (Lmax <= 1) return launch_adamw<1, 4>(ARGS);
-    if (Lmax <= 2) return launch_adamw<2, 4>(ARGS);
-    if (Lmax <= 4) return launch_adamw<4, 2>(ARGS);
-    if (Lmax <= 8) return launch_adamw<8, 2>(ARGS);
-    if (Lmax <= 16) return launch_adamw<16, 1>(ARGS);
-    if (Lmax <= 32) return launch_adamw_wide<32>(ARGS);
-    return launch_adamw_wide<64>(ARGS);
+    if (Lmax <= 1) return launch_adamw<1, 4, FM>(ARGS);
+    if (Lmax <= 2) return launch_adamw<2, 4, FM>(ARGS);
+    if (Lmax <= 4) return launch_adamw<4, 2, FM>(ARGS);
+    if (Lmax <= 8) return launch_adamw<8, 2, FM>(ARGS);
+    if (Lmax <= 16) return launch_adamw<16, 1, FM>(ARGS);
+    if (Lmax <= 32) return launch_adamw_wide<32, FM>(ARGS);
+    return launch_adamw_wide<64, FM>(ARGS);
 #undef ARGS
+}
+
+extern "C" int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
+                                   const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
+                                   float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
+                                   int64_t w0_stride_e, void* stream) {
+    return ft_adamw_step_impl<false>(w, m, v, w0, a, dy, y, do_update, adam_t, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps,
+                                     w0_stride_e, stream);
+}
+
+extern "C" int devqa_ft_adamw_step_fm(float* w, float* dstate, float* v, const float* w0, const float* a, const float* dy, float* y,
+                                      const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
+                                      float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
+                                      int64_t w0_stride_e, void* stream) {
+    return ft_adamw_step_impl<true>(w, dstate, v, w0, a, dy, y, do_update, adam_t, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps,
+                                    w0_stride_e, stream);
 }
 
 // ------------------------------------------------------------------------------------------

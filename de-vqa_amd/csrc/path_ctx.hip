@@ -681,7 +681,7 @@ __global__ void ft_delta_kernel(const float* __restrict__ w, const float* __rest
 }
 
 struct FtPlan {
-    float *w, *var, *y, *logits, *nll, *coef, *dH, *dy, *skws;
+    float *w, *var, *dstate, *y, *logits, *nll, *coef, *dH, *dy, *skws;
     void *h, *dlog;
     int32_t *active, *do_update;
     int splits, g0, g1;
@@ -700,6 +700,7 @@ int64_t plan_ft(const Ctx& c, int E, int kmax, int npad, Arena& a, FtPlan& p) {
     const int64_t Dout = c.d.t_hidden, V = c.d.t_vocab, R = (int64_t)E * kmax, e = esz(c);
     p.w = (float*)a.take((int64_t)E * Dout * npad * 4);
     p.var = (float*)a.take((int64_t)E * Dout * npad * 4);
+    p.dstate = (float*)a.take(R * Dout * 4);          // EMA of dy: the first moment is dstate^T (x) a_rows (devqa_ft_adamw_step_fm)
     p.y = (float*)a.take(R * Dout * 4);
     p.h = a.take(R * Dout * e);
     p.logits = (float*)a.take(R * V * 4);
@@ -742,7 +743,6 @@ extern "C" int devqa_ft_edit(devqa_ctx_t h, const float* w0, int64_t w0_stride_e
     const Weight *fg = nullptr, *et = nullptr;
     RC(need(c, llama_dec(c) ? "language_model.model.norm.weight" : "language_model.model.decoder.final_layer_norm.weight", &fg, DEVQA_DTYPE_F32));
     if (c.bf16) RC(need(c, "derived.embed_T", &et, DEVQA_DTYPE_BF16));
-    float* mom = out_delta;      // the first-moment buffer becomes the delta at the end (same shape)
     hipLaunchKernelGGL(ft_init_kernel, dim3((E + 63) / 64), dim3(64), 0, st, mask, E, kmax, cfg->num_steps, p.coef, p.active, p.do_update, out_steps,
                        out_updates, out_losses);
     DEVQA_LAUNCH_CHECK("ft_init");
@@ -764,8 +764,15 @@ extern "C" int devqa_ft_edit(devqa_ctx_t h, const float* w0, int64_t w0_stride_e
         }
         if (llama_dec(c)) RC(devqa_rmsnorm_bwd_dx(p.y, resid_rows, (const float*)fg->ptr, p.dH, R, Dout, c.d.t_rms_eps, p.dy, st));
         else RC(devqa_layernorm_bwd_dx(p.y, resid_rows, (const float*)fg->ptr, p.dH, R, Dout, c.d.t_ln_eps, p.dy, st));
-        RC(devqa_ft_adamw_step(p.w, mom, p.var, w0, a_rows, p.dy, p.y, p.do_update, out_updates, E, kmax, Dout, npad, cfg->lr, cfg->beta1, cfg->beta2,
-                               cfg->eps, cfg->weight_decay, cfg->clamp_eps, w0_stride_e, st));
+        // (a_rows is the same at every step: the first moment is kept as its rank-kmax factors, no [Dout, npad] matrix; DEVQA_FT_FACTORED=0: the
+        // form with the matrix, in out_delta's storage -- the delta is written there only after the loop)
+        static const bool factored = !(getenv("DEVQA_FT_FACTORED") && atoi(getenv("DEVQA_FT_FACTORED")) == 0);
+        if (factored)
+            RC(devqa_ft_adamw_step_fm(p.w, p.dstate, p.var, w0, a_rows, p.dy, p.y, p.do_update, out_updates, E, kmax, Dout, npad, cfg->lr, cfg->beta1,
+                                      cfg->beta2, cfg->eps, cfg->weight_decay, cfg->clamp_eps, w0_stride_e, st));
+        else
+            RC(devqa_ft_adamw_step(p.w, out_delta, p.var, w0, a_rows, p.dy, p.y, p.do_update, out_updates, E, kmax, Dout, npad, cfg->lr, cfg->beta1,
+                                   cfg->beta2, cfg->eps, cfg->weight_decay, cfg->clamp_eps, w0_stride_e, st));
     }
     const int64_t per = (int64_t)Dout * npad;
     hipLaunchKernelGGL(ft_delta_kernel, dim3((unsigned)((per / 4 + 255) / 256 < 1024 ? (per / 4 + 255) / 256 : 1024), E), dim3(256), 0, st, p.w, w0,

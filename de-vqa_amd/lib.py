@@ -72,6 +72,7 @@ def load():
     _sig(L.devqa_layernorm_bwd_params, [P, P, P, I, I, F, I, I, P, P, P, P])
     _sig(L.devqa_colsum_f32, [P, I, I, I, P, P])
     _sig(L.devqa_ft_adamw_step, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I64, P])
+    _sig(L.devqa_ft_adamw_step_fm, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I64, P])
     _sig(L.devqa_active_columns, [P, I, I, I, P, P, P])
     _sig(L.devqa_gather_cols_f32, [P, I64, I64, I, P, I64, P, I, I, P, P])
     _sig(L.devqa_gather_cols_bf16, [P, I64, I64, I, P, I64, P, I, I, P, P])
@@ -146,7 +147,7 @@ EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "dev
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
            "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
-           "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_layernorm_bwd_params", "devqa_colsum_f32", "devqa_ft_adamw_step", "devqa_rows_matvec_f32", "devqa_delta_op",
+           "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_layernorm_bwd_params", "devqa_colsum_f32", "devqa_ft_adamw_step", "devqa_ft_adamw_step_fm", "devqa_rows_matvec_f32", "devqa_delta_op",
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk", "devqa_attention_bwd",
            "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_mend_normalize_concat",
            "devqa_mend_lrlinear_epilogue", "devqa_logit_kl_rows", "devqa_kl_dlogits", "devqa_welford_rows",
@@ -533,6 +534,22 @@ def ft_adamw_step(w, m, v, w0, a, dy, y, do_update, adam_t, lr, beta1, beta2, ep
     _chk(load().devqa_ft_adamw_step(_p(w), _p(m), _p(v), _p(w0), _p(a), _p(dy), _p(y), _p(do_update), _p(adam_t), E, Lmax,
                                     Dout, Din, float(lr), float(beta1), float(beta2), float(eps), float(wd),
                                     float(clamp_eps), w0_stride, _stream()), "devqa_ft_adamw_step")
+
+
+def ft_adamw_step_fm(w, dstate, v, w0, a, dy, y, do_update, adam_t, lr, beta1, beta2, eps, wd, clamp_eps):
+    """ft_adamw_step without a first-moment matrix (include/devqa.h, devqa_ft_adamw_step_fm): `dstate` fp32 [E, Lmax, Dout] holds the EMA of
+    dy; a[e] must not change between two first updates of edit e."""
+    E, Dout, Din = w.shape
+    Lmax = a.shape[1]
+    for t, n in ((w, "w"), (dstate, "dstate"), (v, "v"), (w0, "w0"), (a, "a"), (dy, "dy"), (y, "y")):
+        _need(t, torch.float32, "ft_adamw_step_fm " + n)
+    assert a.shape == (E, Lmax, Din) and dy.shape == (E, Lmax, Dout) and y.shape == (E, Lmax, Dout)
+    assert w0.shape in ((Dout, Din), (E, Dout, Din)) and dstate.shape == (E, Lmax, Dout) and v.shape == w.shape
+    assert do_update.dtype == torch.int32 and adam_t.dtype == torch.int32
+    w0_stride = Dout * Din if w0.dim() == 3 else 0
+    _chk(load().devqa_ft_adamw_step_fm(_p(w), _p(dstate), _p(v), _p(w0), _p(a), _p(dy), _p(y), _p(do_update), _p(adam_t), E, Lmax,
+                                       Dout, Din, float(lr), float(beta1), float(beta2), float(eps), float(wd),
+                                       float(clamp_eps), w0_stride, _stream()), "devqa_ft_adamw_step_fm")
 
 
 def active_columns(a):

@@ -320,6 +320,20 @@ int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0, const flo
                         float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
                         int64_t w0_stride_e, void* stream);
 
+/* The same step without a first-moment MATRIX ("factored momentum"; what the path's FT_VL loops call).  Inside one edit's loop the rows a[e]
+ * are constant -- every layer below the edited matrix is frozen (ft_vl.py:111-146 re-runs the same forward) -- so every gradient is
+ * dy_t^T (x) a and the first moment is m_t = D_t^T (x) a with D_t = lerp(D_{t-1}, dy_t, 1 - beta1): a state of [Lmax][Dout] floats per edit
+ * instead of [Dout][Din].  The kernel keeps D in `dstate`, rebuilds m_t per element from D_t and the a-values it holds anyway (L fmas) and
+ * streams only w and v: 4*4*Dout*Din bytes per edit-step (first update: read w0, write w, v = 3*4) instead of 6*4.  Exact in exact
+ * arithmetic; in fp32 m_t differs from the recurrence by rounding only (the second moment is NOT factored: sums of squares of sums cancel).
+ * CONTRACT: a[e] must hold the same values at every step between two first updates (adam_t[e] == 1) of edit e.
+ *   dstate : fp32 [E][Lmax][Dout] (laid out like dy; contents ignored at adam_t[e] == 1), everything else as devqa_ft_adamw_step.
+ */
+int devqa_ft_adamw_step_fm(float* w, float* dstate, float* v, const float* w0, const float* a, const float* dy, float* y,
+                           const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
+                           int64_t w0_stride_e, void* stream);
+
 /* ---- column compaction of the FT loop (csrc/ft_compact.hip) ------------------------------------------
  * With a = relu(.) constant over the loop, a column j of the edited matrix whose a[e,r,j] == 0 for every
  * loss row r has zero gradient, zero moments and zero update at every step (weight_decay == 0), so the loop
