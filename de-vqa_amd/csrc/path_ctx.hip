@@ -953,12 +953,27 @@ extern "C" int devqa_gather_scores(devqa_comm_t h, const float* local, int n_row
 // ---- K16 / K17: MEND_VL's hyper-network transform and low-rank delta application as two calls ------------------------------------
 // K16 (R/editor/vllm_editors/mend_vl/auxiliary_networks.py:112-151, 62-83, inference mode): rows idx[0..n) of (x [R, du], delta [R, dv])
 // -> normalise with the stored statistics and concatenate [n, D = du + dv] -> n_layers low-rank residual layers
-// out = x + relu((x v^T) u^T + bias) * mode_scale + mode_shift (exact-fp32 GEMMs) -> split into (x~ [n, du], delta~ [n, dv]).
+// out = x + relu((x v^T) u^T + bias) * mode_scale + mode_shift (exact-fp32 GEMMs; DEVQA_MEND_SPLIT_BF16: three bf16 products of split operands, what
+// the bf16 compute mode asks for -- 1284 -> ~450 us per GEMM pair of the BLIP-2 hyper-network) -> split into (x~ [n, du], delta~ [n, dv]).
 extern "C" int64_t devqa_mend_transform_workspace(int n, int du, int dv, int rank) {
     if (n <= 0 || du <= 0 || dv <= 0 || rank <= 0) return 256;
     const int64_t D = (int64_t)du + dv;
-    return 3 * al256((int64_t)n * D * 4) + al256((int64_t)n * rank * 4);
+    // + the split-bf16 form's operands: (hi, lo) of the activations [n, D], of the low-rank product [n, rank] and of one weight [rank, D]
+    return 3 * al256((int64_t)n * D * 4) + al256((int64_t)n * rank * 4) + 2 * al256((int64_t)n * D * 2) + 2 * al256((int64_t)n * rank * 2) +
+           2 * al256((int64_t)rank * D * 2);
 }
+
+namespace {
+// C [M, N] fp32 = A . W^T on the bf16 MFMA from split operands: A_hi.W_lo + A_lo.W_hi + A_hi.W_hi (small terms first), fp32 accumulation
+int gemm_split3(const devqa_bf16* a_hi, const devqa_bf16* a_lo, const devqa_bf16* w_hi, const devqa_bf16* w_lo, int M, int N, int K, float* out,
+                void* stream) {
+    int rc = devqa_gemm_bf16(a_hi, K, w_lo, K, nullptr, M, N, K, 1.f, DEVQA_ACT_NONE, nullptr, nullptr, out, N, stream);
+    if (rc != DEVQA_OK) return rc;
+    rc = devqa_gemm_bf16(a_lo, K, w_hi, K, nullptr, M, N, K, 1.f, DEVQA_ACT_NONE, out, nullptr, out, N, stream);
+    if (rc != DEVQA_OK) return rc;
+    return devqa_gemm_bf16(a_hi, K, w_hi, K, nullptr, M, N, K, 1.f, DEVQA_ACT_NONE, out, nullptr, out, N, stream);
+}
+}  // namespace
 
 extern "C" int devqa_mend_transform(const float* x, const float* delta, const int32_t* idx, int n, int du, int dv,
                                     const devqa_mend_net* net, float* out_x, float* out_d, void* workspace, int64_t ws_bytes, void* stream) {
@@ -969,12 +984,20 @@ extern "C" int devqa_mend_transform(const float* x, const float* delta, const in
     DEVQA_CHECK_SHAPE((du + dv) % 4 == 0 && net->rank % 4 == 0, "mend_transform: D=%d and rank=%d must be multiples of 4 (exact-fp32 GEMM)", du + dv, net->rank);
     DEVQA_CHECK_ARG((((uintptr_t)workspace) & 255) == 0, "mend_transform: workspace must be 256-byte aligned");
     DEVQA_CHECK_SHAPE(ws_bytes >= devqa_mend_transform_workspace(n, du, dv, net->rank), "mend_transform: workspace too small");
-    const int D = du + dv;
+    const int D = du + dv, rank = net->rank;
     char* ws = (char*)workspace;
     float* a = (float*)ws;
     float* b = (float*)(ws + al256((int64_t)n * D * 4));
     float* pre = (float*)(ws + 2 * al256((int64_t)n * D * 4));
     float* low = (float*)(ws + 3 * al256((int64_t)n * D * 4));
+    char* sp = ws + 3 * al256((int64_t)n * D * 4) + al256((int64_t)n * rank * 4);
+    devqa_bf16* a_hi = (devqa_bf16*)sp;
+    devqa_bf16* a_lo = (devqa_bf16*)(sp + al256((int64_t)n * D * 2));
+    devqa_bf16* l_hi = (devqa_bf16*)(sp + 2 * al256((int64_t)n * D * 2));
+    devqa_bf16* l_lo = (devqa_bf16*)(sp + 2 * al256((int64_t)n * D * 2) + al256((int64_t)n * rank * 2));
+    devqa_bf16* w_hi = (devqa_bf16*)(sp + 2 * al256((int64_t)n * D * 2) + 2 * al256((int64_t)n * rank * 2));
+    devqa_bf16* w_lo = (devqa_bf16*)((char*)w_hi + al256((int64_t)rank * D * 2));
+    const bool split = (net->flags & DEVQA_MEND_SPLIT_BF16) && D % 8 == 0 && rank % 8 == 0;
     int rc = devqa_mend_normalize_concat(x, delta, idx, net->u_mean, net->u_std, net->v_mean, net->v_std, 1e-7f, n, du, dv, a, stream);
     if (rc != DEVQA_OK) return rc;
     float* cur = a;
@@ -982,10 +1005,20 @@ extern "C" int devqa_mend_transform(const float* x, const float* delta, const in
     for (int l = 0; l < net->n_layers; ++l) {
         const devqa_mend_layer& L = net->layers[l];
         DEVQA_CHECK_ARG(L.u && L.v && L.bias && L.mode_scale && L.mode_shift, "mend_transform: layer %d has a null pointer", l);
-        rc = devqa_gemm_f32(cur, D, L.v, D, nullptr, n, net->rank, D, 1.f, DEVQA_ACT_NONE, nullptr, low, net->rank, stream);      // x v^T
-        if (rc != DEVQA_OK) return rc;
-        rc = devqa_gemm_f32(low, net->rank, L.u, net->rank, nullptr, n, D, net->rank, 1.f, DEVQA_ACT_NONE, nullptr, pre, D, stream);  // . u^T
-        if (rc != DEVQA_OK) return rc;
+        if (split) {
+            rc = devqa_split_f32_bf16x2(cur, a_hi, a_lo, (int64_t)n * D, stream);
+            if (rc == DEVQA_OK) rc = devqa_split_f32_bf16x2(L.v, w_hi, w_lo, (int64_t)rank * D, stream);
+            if (rc == DEVQA_OK) rc = gemm_split3(a_hi, a_lo, w_hi, w_lo, n, rank, D, low, stream);                                   // x v^T
+            if (rc == DEVQA_OK) rc = devqa_split_f32_bf16x2(low, l_hi, l_lo, (int64_t)n * rank, stream);
+            if (rc == DEVQA_OK) rc = devqa_split_f32_bf16x2(L.u, w_hi, w_lo, (int64_t)rank * D, stream);
+            if (rc == DEVQA_OK) rc = gemm_split3(l_hi, l_lo, w_hi, w_lo, n, D, rank, pre, stream);                                   // . u^T
+            if (rc != DEVQA_OK) return rc;
+        } else {
+            rc = devqa_gemm_f32(cur, D, L.v, D, nullptr, n, rank, D, 1.f, DEVQA_ACT_NONE, nullptr, low, rank, stream);      // x v^T
+            if (rc != DEVQA_OK) return rc;
+            rc = devqa_gemm_f32(low, rank, L.u, rank, nullptr, n, D, rank, 1.f, DEVQA_ACT_NONE, nullptr, pre, D, stream);  // . u^T
+            if (rc != DEVQA_OK) return rc;
+        }
         rc = devqa_mend_lrlinear_epilogue(pre, L.bias, L.mode_scale, L.mode_shift, cur, nxt, n, D, stream);
         if (rc != DEVQA_OK) return rc;
         float* t = cur; cur = nxt; nxt = t;

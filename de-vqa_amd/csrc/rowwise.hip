@@ -476,6 +476,42 @@ extern "C" int devqa_cast_f32_bf16(const float* in, devqa_bf16* out, int64_t n, 
     return DEVQA_OK;
 }
 
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits of x in two bf16 operands (the three-product form of an fp32 GEMM on the
+// bf16 MFMA: A.W ~ A_hi.W_hi + A_hi.W_lo + A_lo.W_hi, fp32 accumulation; the dropped A_lo.W_lo term and the tails are <= 2^-16 relative)
+__global__ void split_f32_bf16x2_kernel(const float* __restrict__ in, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t n4, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        bf16_t h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = f32_to_bf16(x[k]);
+            l[k] = f32_to_bf16(x[k] - bf16_to_f32(h[k]));
+        }
+        reinterpret_cast<uint2*>(hi)[i] = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        reinterpret_cast<uint2*>(lo)[i] = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const bf16_t h = f32_to_bf16(in[i]);
+        hi[i] = h;
+        lo[i] = f32_to_bf16(in[i] - bf16_to_f32(h));
+    }
+}
+
+extern "C" int devqa_split_f32_bf16x2(const float* in, devqa_bf16* hi, devqa_bf16* lo, int64_t n, void* stream) {
+    DEVQA_CHECK_ARG(in && hi && lo, "split_f32_bf16x2: null pointer");
+    if (n <= 0) return DEVQA_OK;
+    DEVQA_CHECK_ARG(((((uintptr_t)in) & 15) | (((uintptr_t)hi) & 7) | (((uintptr_t)lo) & 7)) == 0, "split_f32_bf16x2: misaligned pointer");
+    const int64_t n4 = n >> 2;
+    int64_t grid = (n4 + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(split_f32_bf16x2_kernel, dim3(grid < 1 ? 1 : (unsigned)grid), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)hi, (bf16_t*)lo, n4, n);
+    DEVQA_LAUNCH_CHECK("split_f32_bf16x2");
+    return DEVQA_OK;
+}
+
 // out = act(in) on fp32 pre-activations (act: DEVQA_ACT_NONE / DEVQA_ACT_RELU), written as bf16 and / or fp32.  Used where a low-rank
 // term has to enter BEFORE the activation (MEND_VL's edited fc1: relu(h W^T + b + (h x~^T) d~), mend_vl.py:72-79), which the GEMM
 // epilogue (residual after the activation) cannot express: the GEMM leaves fp32 pre-activations, this pass finishes them.

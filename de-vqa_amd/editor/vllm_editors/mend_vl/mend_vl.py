@@ -266,7 +266,7 @@ class MENDvl(VLLMBaseEditorWithTraining):
             D_, rank_ = xin32.shape[1] + d32.shape[1], layers[0]["v"].shape[0]
             if self.n_layers <= lib.MEND_MAX_LAYERS and D_ % 4 == 0 and rank_ % 4 == 0:
                 stats = (A[pre + "u_mean"], A[pre + "u_std"], A[pre + "v_mean"], A[pre + "v_std"]) if norm else None
-                xt, dt = lib.mend_transform(xin32, d32, nz, layers, stats)
+                xt, dt = lib.mend_transform(xin32, d32, nz, layers, stats, split_bf16=self._split_bf16())
                 return xt, dt, None
         inp = lib.mend_normalize_concat(xin32, d32, nz, A[pre + "u_mean"] if norm else None, A[pre + "u_std"] if norm else None,
                                         A[pre + "v_mean"] if norm else None, A[pre + "v_std"] if norm else None, 1e-7)
@@ -294,7 +294,12 @@ class MENDvl(VLLMBaseEditorWithTraining):
                    "mode_scale": A[pre + "mlp.layers.%d.mode_scale.weight" % l][m["idx"]].contiguous(),
                    "mode_shift": A[pre + "mlp.layers.%d.mode_shift.weight" % l][m["idx"]].contiguous()} for l in range(self.n_layers)]
         stats = (A[pre + "u_mean"], A[pre + "u_std"], A[pre + "v_mean"], A[pre + "v_std"]) if bool(self.cfg.aux_model.norm) else None
-        return lib.mend_transform(x32, d32, None, layers, stats)
+        return lib.mend_transform(x32, d32, None, layers, stats, split_bf16=self._split_bf16())
+
+    def _split_bf16(self):
+        """bf16 compute mode: the hyper-network's two GEMMs per layer run as three bf16 MFMA products of split fp32 operands (~2e-5 relative,
+        3x the exact-fp32 GEMM's speed; include/devqa.h, DEVQA_MEND_SPLIT_BF16).  fp32 mode and DEVQA_MEND_SPLIT=0 keep the exact GEMM."""
+        return getattr(self.vllm.model, "compute_dtype", "fp32") == "bf16" and os.environ.get("DEVQA_MEND_SPLIT", "1") != "0"
 
     def _install_deltas(self):
         """Factors of the running-mean delta weight for the engine: dW = X^T D / n with X, D the concatenated rows of

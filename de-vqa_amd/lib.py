@@ -146,7 +146,7 @@ EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "dev
            "devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
-           "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16",
+           "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16", "devqa_split_f32_bf16x2",
            "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_layernorm_bwd_params", "devqa_colsum_f32", "devqa_ft_adamw_step", "devqa_ft_adamw_step_fm", "devqa_rows_matvec_f32", "devqa_delta_op",
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk", "devqa_attention_bwd",
            "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_mend_normalize_concat",
@@ -831,10 +831,13 @@ class MendLayer(ctypes.Structure):
 
 class MendNet(ctypes.Structure):
     _fields_ = [("n_layers", ctypes.c_int32), ("rank", ctypes.c_int32), ("u_mean", c_void_p), ("u_std", c_void_p), ("v_mean", c_void_p),
-                ("v_std", c_void_p), ("layers", MendLayer * MEND_MAX_LAYERS)]
+                ("v_std", c_void_p), ("layers", MendLayer * MEND_MAX_LAYERS), ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
-def mend_transform(x, delta, idx, layers, stats=None):
+MEND_SPLIT_BF16 = 1
+
+
+def mend_transform(x, delta, idx, layers, stats=None, split_bf16=False):
     """K16 (devqa_mend_transform): rows `idx` (int32, or None = all) of fp32 x [R, du] / delta [R, dv] through the hyper-network in
     inference mode.  layers: list of dicts {u [D, rank], v [rank, D], bias, mode_scale, mode_shift [D]} (fp32, contiguous; the mode row
     of the edited module already selected); stats: (u_mean, u_std, v_mean, v_std) or None.  -> (x~ [n, du], delta~ [n, dv])"""
@@ -847,6 +850,7 @@ def mend_transform(x, delta, idx, layers, stats=None):
         return out_x, out_d
     net = MendNet()
     net.n_layers, net.rank = len(layers), int(layers[0]["v"].shape[0])
+    net.flags = MEND_SPLIT_BF16 if split_bf16 else 0     # the GEMMs as three bf16 MFMA products of split operands (bf16 compute mode)
     keep = []
     if stats is not None:
         for name, t in zip(("u_mean", "u_std", "v_mean", "v_std"), stats):

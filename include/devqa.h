@@ -265,6 +265,8 @@ int devqa_embed_rows_f32(const int32_t* token, const int32_t* src_row, const int
 int devqa_gather_rows(const void* in, const int32_t* idx, int R, int D, int elem_bytes, void* out, void* stream);
 /* fp32 -> bf16 (round to nearest even), n elements */
 int devqa_cast_f32_bf16(const float* in, devqa_bf16* out, int64_t n, void* stream);
+/* x = hi + lo, hi = bf16(x), lo = bf16(x - hi): the operands of the three-product bf16 form of an fp32 GEMM (devqa_mend_transform, DEVQA_MEND_SPLIT_BF16) */
+int devqa_split_f32_bf16x2(const float* in, devqa_bf16* hi, devqa_bf16* lo, int64_t n, void* stream);
 /* out = act(in) over n fp32 values (act: DEVQA_ACT_NONE or DEVQA_ACT_RELU), written as bf16 and / or fp32 (either may be NULL, out_f32
  * may alias in).  Finishes fp32 pre-activations that received a low-rank term before the activation (MEND_VL's edited fc1,
  * R/editor/vllm_editors/mend_vl/mend_vl.py:72-79). */
@@ -550,17 +552,22 @@ int devqa_gather_scores(devqa_comm_t comm, const float* local, int n_rows, float
  *   transform: rows idx[0..n) (nullptr: rows 0..n) of x [R, du] and delta [R, dv] (fp32) -> (x - u_mean) / (u_std + 1e-7) | same for
  *     delta (statistics nullptr: no normalisation) -> n_layers times  out = in + relu((in v^T) u^T + bias) * mode_scale + mode_shift
  *     with v [rank, D], u [D, rank], bias / mode_scale / mode_shift [D] (the mode row of the edited module already selected; D = du +
- *     dv) on the exact-fp32 GEMM -> out_x [n, du], out_d [n, dv].  D % 4 == 0, rank % 4 == 0.
+ *     dv) on the exact-fp32 GEMM (net->flags & DEVQA_MEND_SPLIT_BF16: three bf16 products of split operands) -> out_x [n, du], out_d [n, dv].
+ *     D % 4 == 0, rank % 4 == 0.
  *   apply: y [R, dout] fp32 += (h [R, din] . xt^T) . dt with the factors xt [npad, din] and dtT [dout, npad] in the compute dtype
  *     (delta_W = xt^T dt is never materialised), npad % 64 == 0 (zero rows). */
 #define DEVQA_MEND_MAX_LAYERS 4
 typedef struct devqa_mend_layer {
     const float *u, *v, *bias, *mode_scale, *mode_shift;
 } devqa_mend_layer;
+#define DEVQA_MEND_SPLIT_BF16 1   /* flags: the two GEMMs of a layer as three bf16 MFMA products each of split operands (x = hi + lo, fp32 accumulation;
+                                    ~2e-5 relative instead of the exact-fp32 GEMM's 1e-7, 3x its speed): what the bf16 compute mode asks for.  Needs D % 8 == 0
+                                    and rank % 8 == 0, otherwise the exact form runs */
 typedef struct devqa_mend_net {
     int32_t n_layers, rank;
     const float *u_mean, *u_std, *v_mean, *v_std;   /* nullptr: aux_model.norm = False */
     devqa_mend_layer layers[DEVQA_MEND_MAX_LAYERS];
+    int32_t flags, reserved;
 } devqa_mend_net;
 int64_t devqa_mend_transform_workspace(int n, int du, int dv, int rank);
 int devqa_mend_transform(const float* x, const float* delta, const int32_t* idx, int n, int du, int dv, const devqa_mend_net* net,

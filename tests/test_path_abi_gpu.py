@@ -323,6 +323,24 @@ def test_mend_transform_and_apply_entry_points():
         prea = lib.gemm(lib.gemm(inp32, cu(L_["v"])), cu(L_["u"]))
         inp32 = lib.mend_lrlinear_epilogue(prea, cu(L_["bias"]), cu(L_["mode_scale"]), cu(L_["mode_shift"]), inp32)
     assert torch.equal(ox, inp32[:, :du].contiguous()) and torch.equal(od, inp32[:, du:].contiguous())
+    # DEVQA_MEND_SPLIT_BF16 (the bf16 compute mode's form: three bf16 MFMA products of split operands per GEMM) against the exact-fp32 form
+    sx, sd = lib.mend_transform(cu(x), cu(dl), cu(idx), [{k: cu(v) for k, v in L_.items()} for L_ in layers], [cu(t) for t in stats], split_bf16=True)
+    ex_small = torch.cat([ox, od], 1).double()
+    assert float((torch.cat([sx, sd], 1).double() - ex_small).abs().max()) < 1e-4 * float(ex_small.abs().max()) and not torch.equal(sx, ox)
+    # ... and at the BLIP-2 hyper-network's width (D = 12800, rank 1920), where K is long enough for the dropped lo.lo term to show
+    g2 = torch.Generator().manual_seed(6)
+    n2, du2, dv2, rank2 = 37, 10240, 2560, 1920
+    x2, d2 = torch.randn(n2, du2, generator=g2), torch.randn(n2, dv2, generator=g2)
+    lay2 = {"u": torch.randn(du2 + dv2, rank2, generator=g2) * 0.02, "v": torch.randn(rank2, du2 + dv2, generator=g2) * 0.01,
+            "bias": torch.randn(du2 + dv2, generator=g2) * 0.1, "mode_scale": torch.rand(du2 + dv2, generator=g2) + 0.5,
+            "mode_shift": torch.randn(du2 + dv2, generator=g2) * 0.1}
+    ex = torch.cat(lib.mend_transform(cu(x2), cu(d2), None, [{k: cu(v) for k, v in lay2.items()}], None), 1).double()
+    sp = torch.cat(lib.mend_transform(cu(x2), cu(d2), None, [{k: cu(v) for k, v in lay2.items()}], None, split_bf16=True), 1).double()
+    pre64 = (torch.cat([x2, d2], 1).double() @ lay2["v"].double().T) @ lay2["u"].double().T        # what the two GEMMs compute, in float64
+    err = float((sp - ex).abs().max())
+    print("mend_transform at D 12800 / rank 1920: max |split bf16 - exact fp32| %.3g (pre-activations up to %.3g, outputs up to %.3g)"
+          % (err, float(pre64.abs().max()), float(ex.abs().max())))
+    assert err < 1e-4 * float(pre64.abs().max())
     for mode in (torch.float32, torch.bfloat16):
         npad, din, dout, Rr = 64, 48, 40, 13
         h = torch.randn(Rr, din, generator=g).to(mode).cuda()
