@@ -752,7 +752,7 @@ __device__ int g_am_hs;            // layout experiment of the harness: element 
 #define AMR_HOFF (h * dh)
 #endif
 template <int DHP, int NW, int NB = 3>
-__global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+__global__ __launch_bounds__(64 * NW, DHP > 96 ? 4 : (NW == 9 ? 7 : 6)) void attention_ring_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                                  const bf16_t* __restrict__ k, int64_t ldk,
                                                                                  const bf16_t* __restrict__ v, int64_t ldv,
                                                                                  bf16_t* __restrict__ out, int64_t ldo,
@@ -786,12 +786,21 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kerne
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int n_all = kp_len + ko_len;
-    const bool fold = fold_ok && (n_all & (AM_KC - 1)) == 1 && n_all > 1;
+    // fold_ok bit 1 (value 2): the own key range is causal (query i sees own keys 0 .. i + ko_len - q_len); a tile's chunk loop then ends at its
+    // last query's diagonal, and a wave whose 16 queries all lie above a chunk skips it
+    const bool causal = (fold_ok & 2) != 0;
+    const int causal_off = ko_len - q_len;
+    const int own_hi = causal ? max(0, min(ko_len, q0 + min(QT, q_len - q0) + causal_off)) : ko_len;
+    const int n_all = kp_len + own_hi;
+    const bool fold = (fold_ok & 1) && !causal && (n_all & (AM_KC - 1)) == 1 && n_all > 1;
     const int n_keys = n_all - (fold ? 1 : 0);        // keys that go through the chunk loop (a folded key has index n_keys)
     AM_STAMP(0);
 
     const int qrow = q0 + wave * 16 + fr;
+    // first key this lane's query does NOT see, and the same for the first / last query of the wave (uniform)
+    const int lim = causal ? min(n_keys, kp_len + max(0, qrow + causal_off + 1)) : n_keys;
+    const int lim_lo = causal ? min(n_keys, kp_len + max(0, q0 + wave * 16 + causal_off + 1)) : n_keys;
+    const int lim_hi = causal ? min(n_keys, kp_len + max(0, q0 + wave * 16 + 15 + causal_off + 1)) : n_keys;
     short8_t qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -865,7 +874,7 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kerne
         AM_STAMP(4 + (c0 >> 6) * 6);
         if (c0 + (NB - 1) * AM_KC < n_keys) { AMR_STAGE(c0 + (NB - 1) * AM_KC, (bi == 0 ? NB - 1 : bi - 1)) }
         AM_STAMP(5 + (c0 >> 6) * 6);
-        if (!wave_has_rows) continue;
+        if (!wave_has_rows || c0 >= lim_hi) continue;          // (causal: every query of this wave lies above the chunk)
         const unsigned char* Ks = Ks3 + bi * IMG;
         const uint32_t vs_lds = (uint32_t)reinterpret_cast<uintptr_t>((am_lptr_t)(Vs3 + bi * IMG));
         float4_t st[4];
@@ -878,11 +887,12 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kerne
                 st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[t], 0, 0, 0);
             }
         }
-        if (c0 + AM_KC > n_keys) {            // the last, partial chunk (uniform): keys past the end score -inf
+        if (c0 + AM_KC > lim_lo) {            // (uniform per wave) a partial last chunk or the causal diagonal: hidden keys score -inf
+            const int rel = lim - c0 - 4 * fq;            // score (t, r) of this lane is visible iff 16 t + r < rel
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[t][r] = (c0 + 16 * t + 4 * fq + r < n_keys) ? st[t][r] : -INFINITY;
+                for (int r = 0; r < 4; ++r) st[t][r] = (16 * t + r < rel) ? st[t][r] : -INFINITY;
         }
         float mloc = am_max4(am_max16(st[0], st[1], st[2], st[3]));
         float m_new = fmaxf(m_run, mloc);
@@ -890,7 +900,7 @@ __global__ __launch_bounds__(64 * NW, NW == 9 ? 7 : 6) void attention_ring_kerne
         const bool rescale = __builtin_amdgcn_ballot_w64(grow) != 0;
         if (!rescale) m_new = m_run;
         float alpha = 1.f, lloc = 0.f;
-        const float mc = m_new * sc2;        // finite: non-causal, so every query has seen key 0 of chunk 0 (or the folded key)
+        const float mc = m_new == -INFINITY ? 0.f : m_new * sc2;       // (-inf: a causal query that sees no key yet -- its p are exp2(-inf) = 0)
         if (rescale) alpha = __builtin_amdgcn_exp2f(m_run * sc2 - mc);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -1477,8 +1487,13 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
     // tiles of 9 waves when they cover the longest sequence with fewer tiles than 128-query ones (257 tokens: 2 instead of 3).
     // DEVQA_ATTENTION_RING=0 keeps the two-image kernel, DEVQA_ATTENTION_NW=8 / 9 picks the tile, DEVQA_ATTENTION_FOLD=0 turns the folding of
     // key n_keys - 1 (n_keys % 64 == 1) off -- the staging variants are bit-identical to each other only without it.
-    const bool ring = dma && causal == 0 && dhp <= 96 && max_q_len >= 224 && env.ring != 0 && (env.nw == -1 || env.nw == 8 || env.nw == 9);
-    if (ring) dma_nw = env.nw != -1 ? env.nw : ((max_q_len + 143) / 144 < (max_q_len + 127) / 128 ? 9 : 8);
+    // causal long sequences (the LLaMA decoders' 577-row image prefixes): the same kernel with the diagonal masked per lane and chunks above a
+    // wave's queries skipped, 128-query tiles.  The LLaVA decoder pack of a 16-cycle batch (64 prefixes of 577 rows + 192 texts behind them, 32
+    // heads x 128; tools/debug/att_llava_bench.py): 986 -> 606 us against attention_mfma_dma_kernel<128, 4> (167 registers, two 4-wave
+    // workgroups per CU; here 106 registers, two 8-wave workgroups), bit-identical outputs.  DEVQA_ATTENTION_RING=0: the tiled kernel.
+    const bool ring_causal = (causal & 1) != 0;
+    const bool ring = dma && (causal == 0 ? dhp <= 96 : ring_causal) && max_q_len >= 224 && env.ring != 0 && (env.nw == -1 || env.nw == 8 || env.nw == 9);
+    if (ring) dma_nw = env.nw != -1 ? env.nw : ((causal & 1) ? 8 : ((max_q_len + 143) / 144 < (max_q_len + 127) / 128 ? 9 : 8));
     // causal packs of short sequences (decoder probes): 32-query tiles of two waves on ONE LDS-DMA image (attention_mfma_dma_kernel<D, 2, true>);
     // non-causal short-query calls (Q-Former: 32 queries over 257 keys) keep the register-staged kernel
     const bool short_env = env.shrt != -1;
@@ -1550,23 +1565,25 @@ int launch_attention_mfma(const bf16_t* q, int64_t ldq, const bf16_t* k, int64_t
             hipLaunchKernelGGL((attention_mfma_dma_kernel<D, 2, true>), dim3((unsigned)grid), dim3(128), 0, st, q, ldq, k, ldk, v, ldv, \
                                out, ldo, seq_desc, H, dh, scale, causal, q_tiles, n_seq_arg);                                     \
         else if (ring) {                                                                                               \
-            constexpr int DR = D <= 96 ? D : 96;                                                                       \
-            static std::atomic<unsigned> attr8{0}, attr9{0};                                                           \
-            const int fold_ok = env.fold != 0;                                                                         \
-            if (env.nbuf != 3) {      /* default: two images = three workgroups per CU; DEVQA_ATTENTION_NBUF=3: the ring of three */ \
-                if (dma_nw == 9)                                                                                       \
-                    hipLaunchKernelGGL((attention_ring_kernel<DR, 9, 2>), dim3((unsigned)grid), dim3(576), 4 * 64 * 2 * DR + 512, st, q, ldq, k, ldk, v, ldv, \
-                                       out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                 \
-                else                                                                                                   \
-                    hipLaunchKernelGGL((attention_ring_kernel<DR, 8, 2>), dim3((unsigned)grid), dim3(512), 4 * 64 * 2 * DR + 512, st, q, ldq, k, ldk, v, ldv, \
-                                       out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                 \
+            static std::atomic<unsigned> a82{0}, a92{0}, a83{0}, a93{0};                                               \
+            const int fold_ok = (env.fold != 0 ? 1 : 0) | ((causal & 1) ? 2 : 0);                                      \
+            const int nb = env.nbuf == 3 ? 3 : 2;      /* default: two images = three workgroups per CU; DEVQA_ATTENTION_NBUF=3: the ring of three */ \
+            const size_t smem = (size_t)2 * nb * 64 * 2 * D + 512;                                                     \
+            if (nb == 2 && dma_nw == 9) {                                                                              \
+                devqa_set_max_smem(attention_ring_kernel<D, 9, 2>, smem, a92);                                         \
+                hipLaunchKernelGGL((attention_ring_kernel<D, 9, 2>), dim3((unsigned)grid), dim3(576), smem, st, q, ldq, k, ldk, v, ldv, \
+                                   out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                     \
+            } else if (nb == 2) {                                                                                      \
+                devqa_set_max_smem(attention_ring_kernel<D, 8, 2>, smem, a82);                                         \
+                hipLaunchKernelGGL((attention_ring_kernel<D, 8, 2>), dim3((unsigned)grid), dim3(512), smem, st, q, ldq, k, ldk, v, ldv, \
+                                   out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                     \
             } else if (dma_nw == 9) {                                                                                  \
-                devqa_set_max_smem(attention_ring_kernel<DR, 9>, 6 * 64 * 2 * DR + 512, attr9);                              \
-                hipLaunchKernelGGL((attention_ring_kernel<DR, 9>), dim3((unsigned)grid), dim3(576), 6 * 64 * 2 * DR + 512, st, q, ldq, k, ldk, v, ldv, \
+                devqa_set_max_smem(attention_ring_kernel<D, 9, 3>, smem, a93);                                         \
+                hipLaunchKernelGGL((attention_ring_kernel<D, 9, 3>), dim3((unsigned)grid), dim3(576), smem, st, q, ldq, k, ldk, v, ldv, \
                                    out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                     \
             } else {                                                                                                   \
-                devqa_set_max_smem(attention_ring_kernel<DR, 8>, 6 * 64 * 2 * DR + 512, attr8);                              \
-                hipLaunchKernelGGL((attention_ring_kernel<DR, 8>), dim3((unsigned)grid), dim3(512), 6 * 64 * 2 * DR + 512, st, q, ldq, k, ldk, v, ldv, \
+                devqa_set_max_smem(attention_ring_kernel<D, 8, 3>, smem, a83);                                         \
+                hipLaunchKernelGGL((attention_ring_kernel<D, 8, 3>), dim3((unsigned)grid), dim3(512), smem, st, q, ldq, k, ldk, v, ldv, \
                                    out, ldo, seq_desc, H, dh, scale, fold_ok, q_tiles, n_seq_arg);                     \
             }                                                                                                          \
         } else if (dma) {                                                                                              \

@@ -25,6 +25,7 @@ Two execution forms behind the same `execute_ft`:
 Targets outside the language model's decoder layers (vision tower, Q-Former, embeddings, final norm) would need a backward pass
 through those parts and raise NotImplementedError.
 """
+import os
 from copy import deepcopy
 from dataclasses import dataclass
 from typing import Dict, List, Tuple

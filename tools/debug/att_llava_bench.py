@@ -63,9 +63,16 @@ def main(cycles=16):
                      ("texts only (max_q 577)", lambda: lib.attention(q, k, v, d_txt, len(desc) - n_pre, P, H, dh, dh ** -0.5, 1, out=out2))):
         us = t_us(fn)
         print("%-26s %8.1f us   (%.0f TFLOP/s on the whole pack's %.1f GFLOP)" % (name, us, flops / us / 1e6, flops / 1e9))
-    for var in ({"DEVQA_ATTENTION_NW": "4"}, {"DEVQA_ATTENTION_DMA": "0"}):
+    ref = out1.clone()
+    for var in ({"DEVQA_ATTENTION_NW": "4"}, {"DEVQA_ATTENTION_DMA": "0"}, {"DEVQA_ATTENTION_RING": "2"}, {"DEVQA_ATTENTION_RING": "2", "DEVQA_ATTENTION_NBUF": "3"}):
         os.environ.update(var)
-        print(var, "prefixes only %8.1f us" % t_us(lambda: lib.attention(q, k, v, d_pre, n_pre, P, H, dh, dh ** -0.5, 1, out=out2)))
+        out1.zero_()
+        one()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(out1, ref))
+        print(var, "prefixes only %8.1f us, one launch %8.1f us (identical to the default: %s, max diff %.3g)" % (
+            t_us(lambda: lib.attention(q, k, v, d_pre, n_pre, P, H, dh, dh ** -0.5, 1, out=out2)), t_us(one), same,
+            (out1.float() - ref.float()).abs().max().item()))
         for k_ in var:
             del os.environ[k_]
 
