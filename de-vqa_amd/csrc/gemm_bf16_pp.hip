@@ -388,6 +388,14 @@ __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem
                 const int sw = HALF ? ((row >> 1) & 7) : (row & 15);
                 *reinterpret_cast<float4_t*>(stg + row * RB + (((j * 4 + fq) ^ sw) << 4)) = acc[half * 4 + i][j];
             }
+        if (residual != nullptr) {
+            // Every residual value is made "used" HERE, behind the LDS writes: on gfx950 stores count in vmcnt like loads, and with loads AND
+            // stores pending the compiler cannot count (the two kinds complete out of order) -- it waited vmcnt(0) in front of the add of every
+            // later iteration, i.e. for the PREVIOUS iteration's store to be acknowledged: 32 serialised store round trips per tile, the 22-30 k
+            // cycles the -DPP_TIMING stamps showed for this epilogue.  One wait for the loads, then the 16 stores of a half pipeline freely.
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rv[it].x), "+v"(rv[it].y), "+v"(rv[it].z), "+v"(rv[it].w));
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int row = it * RPI + lrow;
