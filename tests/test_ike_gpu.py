@@ -62,3 +62,22 @@ def test_ike_plugin_end_to_end(gold_dir, in_gold_dir, tmp_path):
     res = VLLMEditorEvaluation(ed, data, "EVQA", str(tmp_path)).evaluate_sequential_edit(1, False, None)
     assert len(res) == 2 and 0.0 <= res[0][0]["reliability"][0]["acc"] <= 1.0
     assert os.path.exists(os.path.join(str(tmp_path), "ike_vl", "blip2-opt-2.7b", "EVQA", "sequential_edit_1", "mean_results.json"))
+    # the evaluator's look-ahead (a split's probes queued, read back after the next split is prepared; one vision call per group) against the
+    # split-by-split order: same records, with three splits so that a queued split is completed both inside the loop and at its end
+    def strip(results):
+        out = deepcopy(results)
+        for sp in out:
+            for r in sp:
+                for x in r["reliability"]:
+                    x.pop("edit_time", None)
+        return out
+    runs = {}
+    for la in ("1", "0"):
+        os.environ["DEVQA_EVAL_LOOKAHEAD"] = la
+        try:
+            d3 = Data(deepcopy(rec["records"][:3]), deepcopy(rec["records"][:3]))
+            runs[la] = strip(VLLMEditorEvaluation(ed, d3, "EVQA", str(tmp_path)).evaluate_sequential_edit(1, False, None, save=False))
+        finally:
+            del os.environ["DEVQA_EVAL_LOOKAHEAD"]
+    assert runs["1"] == runs["0"] and len(runs["1"]) == 3
+
