@@ -209,7 +209,7 @@ def hbm_micro(dev, d_out=2560, d_in=10240):
     w0 = torch.randn((d_out, d_in), device=dev, generator=g) * 0.01
     w = torch.empty((E, d_out, d_in), device=dev)
     mom, var = torch.empty_like(w), torch.empty_like(w)
-    dstate = torch.empty((E, L, d_out), device=dev)
+    dstate = torch.empty((E, L + 1, d_out), device=dev)
     a = torch.rand((E, L, d_in), device=dev, generator=g)
     dy = torch.randn((E, L, d_out), device=dev, generator=g) * 1e-3
     y = torch.empty((E, L, d_out), device=dev)
@@ -560,7 +560,8 @@ def side_kernels(be, elapsed):
           "achieved": round(by / 1e9 / (ms / 1e3), 1) if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": round(by / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms > 0 else 0.0,
           "algorithmic_bytes": by, "updates": int(be.stats.get("updates", 0)), "npad_mean": round(npad_mean, 1),
-          "bytes_rule": "fp32 [2560, npad] per edit: first update 3 tensors (read w0; write w, v), later updates 4 (read + write w, v); the first moment is rebuilt per element from the EMA of dy (devqa_ft_adamw_step_fm), it has no matrix",
+          "bytes_rule": "fp32 [2560, npad] per edit: first update 3 tensors (read w0; write w, v), later updates 4 (read + write w, v); the first moment is rebuilt per element from the EMA of dy (devqa_ft_adamw_step_fm), it has no matrix; an edit with ONE loss row has no second-moment matrix either (v = EMA(dy^2) (x) a^2): 2 tensors per update",
+          "one_row_edits": int(be.stats.get("one_row_edits", 0)), "one_row_updates": int(be.stats.get("one_row_updates", 0)), "edits": int(be.stats.get("cycles", 0)),
           "time_frac_of_step": round(ms / 1e3 / elapsed, 3)}
     return att, ln, ft
 

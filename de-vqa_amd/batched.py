@@ -490,12 +490,17 @@ class BatchedEditEval:
         meta = [(int(steps_h[e]), float(losses_h[e, max(int(steps_h[e]) - 1, 0)])) for e in range(E)]
         self.stats["cycles"] += E
         self.stats["steps"] += int(steps_h.sum())
-        # algorithmic HBM bytes of the executed AdamW updates (include/devqa.h, devqa_ft_adamw_step_fm): the first update of an edit
-        # reads w0 and writes w, v (3 tensors), every later one reads and writes w, v (4 tensors), fp32, on [Dout, npad]
+        # algorithmic HBM bytes of the executed AdamW updates (include/devqa.h, devqa_ft_adamw_step_fm), fp32 on [Dout, npad]: the first update of an
+        # edit reads w0 and writes w, v (3 tensors), every later one reads and writes w, v (4); an edit with ONE loss row has no v matrix either:
+        # 2 tensors per update (read w0 / w, write w)
         Dout_, npad_ = h["ft_shape"]
         n_upd = int(upd_h.sum())
         self.stats["updates"] = self.stats.get("updates", 0) + n_upd
-        self.stats["ft_bytes"] = self.stats.get("ft_bytes", 0) + 4 * Dout_ * npad_ * (4 * n_upd - int((upd_h > 0).sum()))
+        one = np.asarray(c["mask"]).sum(1) == 1
+        tensors = int(2 * upd_h[one].sum()) + int(4 * upd_h[~one].sum() - (upd_h[~one] > 0).sum())
+        self.stats["ft_bytes"] = self.stats.get("ft_bytes", 0) + 4 * Dout_ * npad_ * tensors
+        self.stats["one_row_edits"] = self.stats.get("one_row_edits", 0) + int(one.sum())
+        self.stats["one_row_updates"] = self.stats.get("one_row_updates", 0) + int(upd_h[one].sum())
         self.last_losses = losses_h
         self.last_steps = steps_h
         self.stats["t_host"] += time.time() - t5
@@ -576,7 +581,9 @@ class BatchedEditEval:
         w = torch.empty((E, Dout, npad), dtype=torch.float32, device=dev) if dense else w0.clone()   # dense: the first update reads w0
         factored = os.environ.get("DEVQA_FT_FACTORED", "1") != "0"
         # EMA of dy: first moment = dstate^T (x) a_ft (ft_adamw_step_fm); DEVQA_FT_FACTORED=0: the first-moment matrix
-        dstate = torch.empty((E, kmax, Dout), dtype=torch.float32, device=dev) if factored else torch.empty_like(w)
+        dstate = torch.empty((E, kmax + 1, Dout), dtype=torch.float32, device=dev) if factored else torch.empty_like(w)
+        # edits with ONE loss row (label slots are filled from 0): their second moment factors too, v is not touched (devqa_ft_adamw_step_fm)
+        single = lib.h2d((np.asarray(mask).sum(1) == 1).astype(np.int32), torch.int32, dev) if factored else None
         var = torch.empty_like(w)
         y = lib.rows_matvec(w0, a_ft)  # step-0 fc2 rows with the pristine matrix (active columns carry all of W.a)
         dl_dtype = eng.adt
@@ -588,8 +595,10 @@ class BatchedEditEval:
             lib.ft_step_control(nll, t_mask, it, cfg.num_steps, 1e-2, active, do_update, n_steps, adam_t, losses)
             dH = lib.gemm_rows_longk(dlog, self.vllm.model.embed_T)
             dy = eng.final_norm_bwd(y2, dH, add=resid_ft).view(E, kmax, Dout)
-            (lib.ft_adamw_step_fm if factored else lib.ft_adamw_step)(w, dstate, var, w0, a_ft, dy, y, do_update, adam_t, cfg.lr, 0.9, 0.999, 1e-8,
-                                                                      cfg.weight_decay, clamp)
+            if factored:
+                lib.ft_adamw_step_fm(w, dstate, var, w0, a_ft, dy, y, do_update, adam_t, cfg.lr, 0.9, 0.999, 1e-8, cfg.weight_decay, clamp, single=single)
+            else:
+                lib.ft_adamw_step(w, dstate, var, w0, a_ft, dy, y, do_update, adam_t, cfg.lr, 0.9, 0.999, 1e-8, cfg.weight_decay, clamp)
         self._adam_t = adam_t
         self._ft_shape = (Dout, npad)
         delta = var           # (the second-moment buffer is free now)

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
                                                             float* __restrict__ v, const float* __restrict__ w0,
                                                             const float* __restrict__ a, const float* __restrict__ dy,
                                                             float* __restrict__ y, const int32_t* __restrict__ do_update,
-                                                            const int32_t* __restrict__ adam_t, int Lmax, int Dout, int Din,
+                                                            const int32_t* __restrict__ adam_t, const int32_t* __restrict__ single, int Lmax, int Dout, int Din,
                                                             float lr, float beta1, float beta2, float eps, float wd,
                                                             float clamp_eps, int row_blocks, int64_t w0_stride_e) {
     __shared__ float red[4][ROWS * L];
@@ -46,10 +46,13 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
     const int i0 = NARROW ? (rb * 4 + (int)(threadIdx.x >> 6)) * ROWS : rb * ROWS;
     const int64_t mat = (int64_t)Dout * Din;
     float* we = w + (int64_t)e * mat;
-    float* me = FM ? m + (int64_t)e * Lmax * Dout : m + (int64_t)e * mat;       // FM: the [Lmax, Dout] state D (laid out like dy)
+    float* me = FM ? m + (int64_t)e * (Lmax + 1) * Dout : m + (int64_t)e * mat;       // FM: the [Lmax + 1, Dout] state: D (laid out like dy) | e (SGL)
     float* ve = v + (int64_t)e * mat;
     const float* ae = a + (int64_t)e * Lmax * Din;
     const float* dye = dy + (int64_t)e * Lmax * Dout;
+    // SGL (single[e] != 0: only loss row 0 of this edit is ever non-zero): the second moment factors too, v_t[i, j] = e_t[i] a[0, j]^2 with
+    // e_t = beta2 e_{t-1} + (1 - beta2) dy_t[0, i]^2 -- one term, nothing cancels -- so only w crosses HBM (8 bytes per element and step)
+    const bool sgl = FM && single != nullptr && single[e] != 0;
 
     float dyv[ROWS][L];
 #pragma unroll
@@ -57,14 +60,18 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
 #pragma unroll
         for (int l = 0; l < L; ++l) dyv[r][l] = (i0 + r < Dout && l < Lmax) ? dye[(int64_t)l * Dout + i0 + r] : 0.f;
     float dn[FM ? ROWS : 1][FM ? L : 1];      // FM: D_t of this workgroup's (wave's) rows
+    float en[FM ? ROWS : 1];                  // SGL: e_t of these rows
     if constexpr (FM) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r)
+        for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const float dold = (!first && i0 + r < Dout && l < Lmax) ? me[(int64_t)l * Dout + i0 + r] : 0.f;
                 dn[r][l] = dold + (dyv[r][l] - dold) * (1.f - beta1);
             }
+            const float eold = (sgl && !first && i0 + r < Dout) ? me[(int64_t)Lmax * Dout + i0 + r] : 0.f;
+            en[r] = eold * beta2 + (1.f - beta2) * dyv[r][0] * dyv[r][0];
+        }
     }
 
     float ysum[ROWS][L];
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
             } else {
                 wv = reinterpret_cast<const float4*>(we)[off];
                 if constexpr (!FM) mv = reinterpret_cast<const float4*>(me)[off];
-                vv = reinterpret_cast<const float4*>(ve)[off];
+                vv = sgl ? mv : reinterpret_cast<const float4*>(ve)[off];
                 if (clamp_eps >= 0.f) w0v = reinterpret_cast<const float4*>(w0)[off];
             }
             float g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -121,14 +128,15 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
                 // torch.optim.AdamW (single-tensor path): decay, lerp m, addcmul v, addcdiv
                 wq[k] *= decay;
                 if constexpr (!FM) mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
-                vq[k] = vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
+                const float a0k = k == 0 ? av[0].x : k == 1 ? av[0].y : k == 2 ? av[0].z : av[0].w;
+                vq[k] = (FM && sgl) ? en[FM ? r : 0] * (a0k * a0k) : vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
                 const float denom = sqrtf(vq[k]) / bc2_sqrt + eps;
                 wq[k] -= step_size * (mq[k] / denom);
                 if (clamp_eps >= 0.f) wq[k] = fminf(fmaxf(wq[k], w0q[k] - clamp_eps), w0q[k] + clamp_eps);
             }
             reinterpret_cast<float4*>(we)[off] = make_float4(wq[0], wq[1], wq[2], wq[3]);
             if constexpr (!FM) reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
-            reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+            if (!sgl) reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
 #pragma unroll
             for (int l = 0; l < L; ++l)
                 ysum[r][l] += (wq[0] * av[l].x + wq[1] * av[l].y) + (wq[2] * av[l].z + wq[3] * av[l].w);
@@ -143,7 +151,10 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
                 const float s = wave_sum(ysum[r][l]);
                 if (lane == 0 && i0 + r < Dout && l < Lmax) {
                     y[((int64_t)e * Lmax + l) * Dout + i0 + r] = s;
-                    if constexpr (FM) me[(int64_t)l * Dout + i0 + r] = dn[r][l];      // (every lane of the wave read the old value at entry)
+                    if constexpr (FM) {
+                        me[(int64_t)l * Dout + i0 + r] = dn[r][l];      // (every lane of the wave read the old value at entry)
+                        if (sgl && l == 0) me[(int64_t)Lmax * Dout + i0 + r] = en[r];
+                    }
                 }
             }
         return;
@@ -163,7 +174,12 @@ __global__ __launch_bounds__(256) void ft_adamw_step_kernel(float* __restrict__ 
             y[((int64_t)e * Lmax + l) * Dout + i0 + r] = s;
             if constexpr (FM) {       // behind the barrier: every thread read the old D at entry
                 const float dold = first ? 0.f : me[(int64_t)l * Dout + i0 + r];
-                me[(int64_t)l * Dout + i0 + r] = dold + (dye[(int64_t)l * Dout + i0 + r] - dold) * (1.f - beta1);
+                const float dyl = dye[(int64_t)l * Dout + i0 + r];
+                me[(int64_t)l * Dout + i0 + r] = dold + (dyl - dold) * (1.f - beta1);
+                if (sgl && l == 0) {
+                    const float eold = first ? 0.f : me[(int64_t)Lmax * Dout + i0 + r];
+                    me[(int64_t)Lmax * Dout + i0 + r] = eold * beta2 + (1.f - beta2) * dyl * dyl;
+                }
             }
         }
     }
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
                                                                     float* __restrict__ v, const float* __restrict__ w0,
                                                                     const float* __restrict__ a, const float* __restrict__ dy,
                                                                     float* __restrict__ y, const int32_t* __restrict__ do_update,
-                                                                    const int32_t* __restrict__ adam_t, int Lmax, int Dout, int Din,
+                                                                    const int32_t* __restrict__ adam_t, const int32_t* __restrict__ single, int Lmax, int Dout, int Din,
                                                                     float lr, float beta1, float beta2, float eps, float wd,
                                                                     float clamp_eps, int row_blocks, int64_t w0_stride_e) {
     constexpr int RW = 64 / G;      // rows per wave
@@ -201,10 +217,11 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
     const int ic = row_ok ? i : Dout - 1;                  // idle groups shadow the last row (loads only)
     const int64_t mat = (int64_t)Dout * Din;
     float* we = w + (int64_t)e * mat;
-    float* me = FM ? m + (int64_t)e * Lmax * Dout : m + (int64_t)e * mat;       // FM: the [Lmax, Dout] state D (laid out like dy)
+    float* me = FM ? m + (int64_t)e * (Lmax + 1) * Dout : m + (int64_t)e * mat;       // FM: the [Lmax + 1, Dout] state: D (laid out like dy) | e (SGL)
     float* ve = v + (int64_t)e * mat;
     const float* ae = a + (int64_t)e * Lmax * Din;
     const float* dye = dy + (int64_t)e * Lmax * Dout;
+    const bool sgl = FM && single != nullptr && single[e] != 0;        // see ft_adamw_step_kernel
     float dyv[L], ysum[L], dn[FM ? L : 1];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -214,6 +231,11 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
             const float dold = (!first && l < Lmax) ? me[(int64_t)l * Dout + ic] : 0.f;
             dn[l] = dold + (dyv[l] - dold) * (1.f - beta1);
         }
+    }
+    float en = 0.f;
+    if (sgl) {
+        const float eold = first ? 0.f : me[(int64_t)Lmax * Dout + ic];
+        en = eold * beta2 + (1.f - beta2) * dyv[0] * dyv[0];
     }
     const int nv = Din >> 2;
 #pragma unroll 2
@@ -231,7 +253,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
         } else {
             wv = reinterpret_cast<const float4*>(we)[off];
             if constexpr (!FM) mv = reinterpret_cast<const float4*>(me)[off];
-            vv = reinterpret_cast<const float4*>(ve)[off];
+            vv = sgl ? mv : reinterpret_cast<const float4*>(ve)[off];
             if (clamp_eps >= 0.f) w0v = reinterpret_cast<const float4*>(w0)[off];
         }
         float g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -259,7 +281,8 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
         for (int k = 0; k < 4; ++k) {
             wq[k] *= decay;
             if constexpr (!FM) mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
-            vq[k] = vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
+            const float a0k = k == 0 ? av[0].x : k == 1 ? av[0].y : k == 2 ? av[0].z : av[0].w;
+            vq[k] = sgl ? en * (a0k * a0k) : vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
             const float denom = sqrtf(vq[k]) / bc2_sqrt + eps;
             wq[k] -= step_size * (mq[k] / denom);
             if (clamp_eps >= 0.f) wq[k] = fminf(fmaxf(wq[k], w0q[k] - clamp_eps), w0q[k] + clamp_eps);
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
         if (row_ok) {
             reinterpret_cast<float4*>(we)[off] = make_float4(wq[0], wq[1], wq[2], wq[3]);
             if constexpr (!FM) reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
-            reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+            if (!sgl) reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
         }
 #pragma unroll
         for (int l = 0; l < L; ++l)
@@ -280,7 +303,10 @@ __global__ __launch_bounds__(256) void ft_adamw_step_grouped_kernel(float* __res
         for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (sub == 0 && row_ok && l < Lmax) {
             y[((int64_t)e * Lmax + l) * Dout + i] = s;
-            if constexpr (FM) me[(int64_t)l * Dout + i] = dn[l];          // (the group's lanes read the old value at entry, same wave)
+            if constexpr (FM) {
+                me[(int64_t)l * Dout + i] = dn[l];          // (the group's lanes read the old value at entry, same wave)
+                if (sgl && l == 0) me[(int64_t)Lmax * Dout + i] = en;
+            }
         }
     }
 }
@@ -292,7 +318,7 @@ template <int L, bool FM = false>
 __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                                  const float* __restrict__ w0, const float* __restrict__ a,
                                                                  const float* __restrict__ dy, float* __restrict__ y,
-                                                                 const int32_t* __restrict__ do_update, const int32_t* __restrict__ adam_t,
+                                                                 const int32_t* __restrict__ do_update, const int32_t* __restrict__ adam_t, const int32_t* __restrict__ single,
                                                                  int Lmax, int Dout, int Din, float lr, float beta1, float beta2, float eps,
                                                                  float wd, float clamp_eps, int row_blocks, int64_t w0_stride_e) {
     constexpr int G = 16, RW = 64 / G;
@@ -314,10 +340,11 @@ __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restri
     const int ic = row_ok ? i : Dout - 1;
     const int64_t mat = (int64_t)Dout * Din;
     float* we = w + (int64_t)e * mat;
-    float* me = FM ? m + (int64_t)e * Lmax * Dout : m + (int64_t)e * mat;       // FM: the [Lmax, Dout] state D (laid out like dy)
+    float* me = FM ? m + (int64_t)e * (Lmax + 1) * Dout : m + (int64_t)e * mat;       // FM: the [Lmax + 1, Dout] state: D (laid out like dy) | e (SGL)
     float* ve = v + (int64_t)e * mat;
     const float* ae = a + (int64_t)e * Lmax * Din;
     const float* dye = dy + (int64_t)e * Lmax * Dout;
+    const bool sgl = FM && single != nullptr && single[e] != 0;        // see ft_adamw_step_kernel
     float dyv[L], ysum[L], dn[FM ? L : 1];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -327,6 +354,11 @@ __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restri
             const float dold = (!first && l < Lmax) ? me[(int64_t)l * Dout + ic] : 0.f;
             dn[l] = dold + (dyv[l] - dold) * (1.f - beta1);
         }
+    }
+    float en = 0.f;
+    if (sgl) {
+        const float eold = first ? 0.f : me[(int64_t)Lmax * Dout + ic];
+        en = eold * beta2 + (1.f - beta2) * dyv[0] * dyv[0];
     }
     const int nv = Din >> 2;
     for (int c = sub; c < nv; c += G) {
@@ -339,11 +371,12 @@ __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restri
         } else {
             wv = reinterpret_cast<const float4*>(we)[off];
             if constexpr (!FM) mv = reinterpret_cast<const float4*>(me)[off];
-            vv = reinterpret_cast<const float4*>(ve)[off];
+            vv = sgl ? mv : reinterpret_cast<const float4*>(ve)[off];
             if (clamp_eps >= 0.f) w0v = reinterpret_cast<const float4*>(w0)[off];
         }
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         float mq[4] = {mv.x, mv.y, mv.z, mv.w};
+        const float4 a0v = sgl ? reinterpret_cast<const float4*>(ae)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             if (l < Lmax) {
@@ -367,7 +400,8 @@ __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restri
         for (int k = 0; k < 4; ++k) {
             wq[k] *= decay;
             if constexpr (!FM) mq[k] = mq[k] + (g[k] - mq[k]) * (1.f - beta1);
-            vq[k] = vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
+            const float a0k = k == 0 ? a0v.x : k == 1 ? a0v.y : k == 2 ? a0v.z : a0v.w;
+            vq[k] = sgl ? en * (a0k * a0k) : vq[k] * beta2 + (1.f - beta2) * g[k] * g[k];
             const float denom = sqrtf(vq[k]) / bc2_sqrt + eps;
             wq[k] -= step_size * (mq[k] / denom);
             if (clamp_eps >= 0.f) wq[k] = fminf(fmaxf(wq[k], w0q[k] - clamp_eps), w0q[k] + clamp_eps);
@@ -375,7 +409,7 @@ __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restri
         if (row_ok) {
             reinterpret_cast<float4*>(we)[off] = make_float4(wq[0], wq[1], wq[2], wq[3]);
             if constexpr (!FM) reinterpret_cast<float4*>(me)[off] = make_float4(mq[0], mq[1], mq[2], mq[3]);
-            reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+            if (!sgl) reinterpret_cast<float4*>(ve)[off] = make_float4(vq[0], vq[1], vq[2], vq[3]);
         }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -392,18 +426,21 @@ __global__ __launch_bounds__(256) void ft_adamw_step_wide_kernel(float* __restri
         for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (sub == 0 && row_ok && l < Lmax) {
             y[((int64_t)e * Lmax + l) * Dout + i] = s;
-            if constexpr (FM) me[(int64_t)l * Dout + i] = dn[l];
+            if constexpr (FM) {
+                me[(int64_t)l * Dout + i] = dn[l];
+                if (sgl && l == 0) me[(int64_t)Lmax * Dout + i] = en;
+            }
         }
     }
 }
 
 template <int L, bool FM>
 static int launch_adamw_wide(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
-                             const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din, float lr,
+                             const int32_t* do_update, const int32_t* adam_t, const int32_t* single, int E, int Lmax, int Dout, int Din, float lr,
                              float beta1, float beta2, float eps, float wd, float clamp_eps, int64_t w0_stride_e, hipStream_t st) {
     const int row_blocks = (Dout + 15) / 16;
     const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
-    hipLaunchKernelGGL((ft_adamw_step_wide_kernel<L, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update, adam_t,
+    hipLaunchKernelGGL((ft_adamw_step_wide_kernel<L, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update, adam_t, single,
                        Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
     devqa_prof_end(ph, (FM ? 16.0 : 24.0) * E * (double)Dout * Din, st);
     DEVQA_LAUNCH_CHECK("ft_adamw_step(wide)");
@@ -412,7 +449,7 @@ static int launch_adamw_wide(float* w, float* m, float* v, const float* w0, cons
 
 template <int L, int ROWS, bool FM>
 static int launch_adamw(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
-                        const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din, float lr,
+                        const int32_t* do_update, const int32_t* adam_t, const int32_t* single, int E, int Lmax, int Dout, int Din, float lr,
                         float beta1, float beta2, float eps, float wd, float clamp_eps, int64_t w0_stride_e, hipStream_t st) {
     // column-compacted matrices: lanes per row by issue efficiency nv / (ceil(nv / G) * G); the wave-per-row form when it is >= 0.9 there
     const int nv4 = Din >> 2;
@@ -425,10 +462,10 @@ static int launch_adamw(float* w, float* m, float* v, const float* w0, const flo
         const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
         if (G == 16)
             hipLaunchKernelGGL((ft_adamw_step_grouped_kernel<L, 16, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update,
-                               adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
+                               adam_t, single, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
         else
             hipLaunchKernelGGL((ft_adamw_step_grouped_kernel<L, 8, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y, do_update,
-                               adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
+                               adam_t, single, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
         devqa_prof_end(ph, (FM ? 16.0 : 24.0) * E * (double)Dout * Din, st);
         DEVQA_LAUNCH_CHECK("ft_adamw_step(grouped)");
         return DEVQA_OK;
@@ -437,7 +474,7 @@ static int launch_adamw(float* w, float* m, float* v, const float* w0, const flo
         const int row_blocks = (Dout + 4 * ROWS - 1) / (4 * ROWS);
         const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
         hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS, true, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
-                           do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
+                           do_update, adam_t, single, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
         devqa_prof_end(ph, (FM ? 16.0 : 24.0) * E * (double)Dout * Din, st);
         DEVQA_LAUNCH_CHECK("ft_adamw_step");
         return DEVQA_OK;
@@ -445,7 +482,7 @@ static int launch_adamw(float* w, float* m, float* v, const float* w0, const flo
     const int row_blocks = (Dout + ROWS - 1) / ROWS;
     const int ph = devqa_prof_begin(DEVQA_PROF_FT_ADAMW, st);
     hipLaunchKernelGGL((ft_adamw_step_kernel<L, ROWS, false, FM>), dim3(E * row_blocks), dim3(256), 0, st, w, m, v, w0, a, dy, y,
-                       do_update, adam_t, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
+                       do_update, adam_t, single, Lmax, Dout, Din, lr, beta1, beta2, eps, wd, clamp_eps, row_blocks, w0_stride_e);
     devqa_prof_end(ph, (FM ? 16.0 : 24.0) * E * (double)Dout * Din, st);
     DEVQA_LAUNCH_CHECK("ft_adamw_step");
     return DEVQA_OK;
@@ -453,7 +490,7 @@ static int launch_adamw(float* w, float* m, float* v, const float* w0, const flo
 
 template <bool FM>
 static int ft_adamw_step_impl(float* w, float* m, float* v, const float* w0, const float* a, const float* dy, float* y,
-                              const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
+                              const int32_t* do_update, const int32_t* adam_t, const int32_t* single, int E, int Lmax, int Dout, int Din,
                               float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
                               int64_t w0_stride_e, void* stream) {
     DEVQA_CHECK_ARG(w && m && v && w0 && a && dy && y && do_update && adam_t, "ft_adamw_step: null pointer");
@@ -462,7 +499,7 @@ static int ft_adamw_step_impl(float* w, float* m, float* v, const float* w0, con
     DEVQA_CHECK_SHAPE(Dout > 0 && Din > 0 && Din % 4 == 0, "ft_adamw_step: bad matrix dims %dx%d", Dout, Din);
     DEVQA_CHECK_SHAPE((long)E * ((Dout + 1) / 2) < 2147483647L, "ft_adamw_step: grid too large");
     hipStream_t st = (hipStream_t)stream;
-#define ARGS w, m, v, w0, a, dy, y, do_update, adam_t, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps, w0_stride_e, st
+#define ARGS w, m, v, w0, a, dy, y, do_update, adam_t, single, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps, w0_stride_e, st
     if (Lmax <= 1) return launch_adamw<1, 4, FM>(ARGS);
     if (Lmax <= 2) return launch_adamw<2, 4, FM>(ARGS);
     if (Lmax <= 4) return launch_adamw<4, 2, FM>(ARGS);
@@ -477,15 +514,15 @@ extern "C" int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0
                                    const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
                                    float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
                                    int64_t w0_stride_e, void* stream) {
-    return ft_adamw_step_impl<false>(w, m, v, w0, a, dy, y, do_update, adam_t, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps,
+    return ft_adamw_step_impl<false>(w, m, v, w0, a, dy, y, do_update, adam_t, nullptr, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps,
                                      w0_stride_e, stream);
 }
 
 extern "C" int devqa_ft_adamw_step_fm(float* w, float* dstate, float* v, const float* w0, const float* a, const float* dy, float* y,
-                                      const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
+                                      const int32_t* do_update, const int32_t* adam_t, const int32_t* single, int E, int Lmax, int Dout, int Din,
                                       float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
                                       int64_t w0_stride_e, void* stream) {
-    return ft_adamw_step_impl<true>(w, dstate, v, w0, a, dy, y, do_update, adam_t, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps,
+    return ft_adamw_step_impl<true>(w, dstate, v, w0, a, dy, y, do_update, adam_t, single, E, Lmax, Dout, Din, lr, beta1, beta2, eps, weight_decay, clamp_eps,
                                     w0_stride_e, stream);
 }
 

@@ -653,13 +653,14 @@ extern "C" int devqa_llm_forward_ex(devqa_ctx_t h, float* x, const int32_t* posi
 // =================================================================================================================================
 namespace {
 __global__ void ft_init_kernel(const float* __restrict__ mask, int E, int Lmax, int max_steps, float* coef, int32_t* active, int32_t* do_update,
-                               int32_t* n_steps, int32_t* adam_t, float* losses) {
+                               int32_t* n_steps, int32_t* adam_t, float* losses, int32_t* single) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     float s = 0.f;
     for (int l = 0; l < Lmax; ++l) s += mask[e * Lmax + l];
     for (int l = 0; l < Lmax; ++l) coef[e * Lmax + l] = mask[e * Lmax + l] / s;     // mask / mask.sum (ft_vl.py:191-199)
     active[e] = 1; do_update[e] = 0; n_steps[e] = 0; adam_t[e] = 0;
+    single[e] = (s == 1.f && mask[e * Lmax] == 1.f) ? 1 : 0;        // one loss row, in slot 0: the second moment factors too (devqa_ft_adamw_step_fm)
     for (int t = 0; t < max_steps; ++t) losses[e * max_steps + t] = 0.f;
 }
 // delta[e] = w[e] - w0 (shared or per edit) for edits that took at least one update, else 0 (their w was never written)
@@ -683,7 +684,7 @@ __global__ void ft_delta_kernel(const float* __restrict__ w, const float* __rest
 struct FtPlan {
     float *w, *var, *dstate, *y, *logits, *nll, *coef, *dH, *dy, *skws;
     void *h, *dlog;
-    int32_t *active, *do_update;
+    int32_t *active, *do_update, *single;
     int splits, g0, g1;
 };
 void longk_groups(const Ctx& c, int M, int N, int K, FtPlan& p) {    // the row grouping of lib.gemm_rows_longk (tools/splitk_rows_bench.py)
@@ -700,7 +701,7 @@ int64_t plan_ft(const Ctx& c, int E, int kmax, int npad, Arena& a, FtPlan& p) {
     const int64_t Dout = c.d.t_hidden, V = c.d.t_vocab, R = (int64_t)E * kmax, e = esz(c);
     p.w = (float*)a.take((int64_t)E * Dout * npad * 4);
     p.var = (float*)a.take((int64_t)E * Dout * npad * 4);
-    p.dstate = (float*)a.take(R * Dout * 4);          // EMA of dy: the first moment is dstate^T (x) a_rows (devqa_ft_adamw_step_fm)
+    p.dstate = (float*)a.take((R + E) * Dout * 4);    // EMA of dy (+ one row per edit: EMA of dy[0]^2 of one-row edits): devqa_ft_adamw_step_fm
     p.y = (float*)a.take(R * Dout * 4);
     p.h = a.take(R * Dout * e);
     p.logits = (float*)a.take(R * V * 4);
@@ -711,6 +712,7 @@ int64_t plan_ft(const Ctx& c, int E, int kmax, int npad, Arena& a, FtPlan& p) {
     p.dy = (float*)a.take(R * Dout * 4);
     p.active = (int32_t*)a.take((int64_t)E * 4);
     p.do_update = (int32_t*)a.take((int64_t)E * 4);
+    p.single = (int32_t*)a.take((int64_t)E * 4);
     longk_groups(c, (int)R, (int)Dout, (int)V, p);
     p.skws = p.splits ? (float*)a.take((int64_t)p.splits * (p.g0 > p.g1 ? p.g0 : p.g1) * Dout * 4) : nullptr;
     return al256(a.off);
@@ -744,7 +746,9 @@ extern "C" int devqa_ft_edit(devqa_ctx_t h, const float* w0, int64_t w0_stride_e
     RC(need(c, llama_dec(c) ? "language_model.model.norm.weight" : "language_model.model.decoder.final_layer_norm.weight", &fg, DEVQA_DTYPE_F32));
     if (c.bf16) RC(need(c, "derived.embed_T", &et, DEVQA_DTYPE_BF16));
     hipLaunchKernelGGL(ft_init_kernel, dim3((E + 63) / 64), dim3(64), 0, st, mask, E, kmax, cfg->num_steps, p.coef, p.active, p.do_update, out_steps,
-                       out_updates, out_losses);
+                       out_updates, out_losses, p.single);
+    static const bool one_row_form = !(getenv("DEVQA_FT_SINGLE") && atoi(getenv("DEVQA_FT_SINGLE")) == 0);     // A/B: 0 = every edit keeps its v matrix
+    if (!one_row_form) (void)hipMemsetAsync(p.single, 0, (size_t)E * 4, st);
     DEVQA_LAUNCH_CHECK("ft_init");
     // step-0 fc2 rows with the pristine matrix (the active columns carry all of W.a)
     RC(devqa_rows_matvec_f32(w0, w0_stride_e, a_rows, nullptr, nullptr, p.y, E, kmax, Dout, npad, st));
@@ -768,7 +772,7 @@ extern "C" int devqa_ft_edit(devqa_ctx_t h, const float* w0, int64_t w0_stride_e
         // form with the matrix, in out_delta's storage -- the delta is written there only after the loop)
         static const bool factored = !(getenv("DEVQA_FT_FACTORED") && atoi(getenv("DEVQA_FT_FACTORED")) == 0);
         if (factored)
-            RC(devqa_ft_adamw_step_fm(p.w, p.dstate, p.var, w0, a_rows, p.dy, p.y, p.do_update, out_updates, E, kmax, Dout, npad, cfg->lr, cfg->beta1,
+            RC(devqa_ft_adamw_step_fm(p.w, p.dstate, p.var, w0, a_rows, p.dy, p.y, p.do_update, out_updates, p.single, E, kmax, Dout, npad, cfg->lr, cfg->beta1,
                                       cfg->beta2, cfg->eps, cfg->weight_decay, cfg->clamp_eps, w0_stride_e, st));
         else
             RC(devqa_ft_adamw_step(p.w, out_delta, p.var, w0, a_rows, p.dy, p.y, p.do_update, out_updates, E, kmax, Dout, npad, cfg->lr, cfg->beta1,

@@ -264,7 +264,8 @@ class FTvl(VLLMBaseEditor):
         # one chunk (batch_size >= the number of requests; the shipped configs: 1 request): its rows are the same at every step, so the first
         # moment is kept as the EMA of dy (ft_adamw_step_fm: no [Dout, Din] matrix); several chunks alternate rows on ONE Adam state: dense m
         factored = len(prefixes) == 1 and os.environ.get("DEVQA_FT_FACTORED", "1") != "0"
-        mom = torch.empty((1, prefixes[0][2].numel(), Dout), dtype=torch.float32, device=dev) if factored else torch.empty_like(w)
+        mom = torch.empty((1, prefixes[0][2].numel() + 1, Dout), dtype=torch.float32, device=dev) if factored else torch.empty_like(w)
+        single = torch.full((1,), int(prefixes[0][2].numel() == 1), dtype=torch.int32, device=dev) if factored else None
         var = torch.empty_like(w)
         one = torch.ones(1, dtype=torch.int32, device=dev)
         adam_t = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -295,8 +296,11 @@ class FTvl(VLLMBaseEditor):
                     dy = eng.final_norm_bwd(pre_ln, dH).view(1, k, Dout)
                     adam_t += 1
                     y_next = torch.empty((1, k, Dout), dtype=torch.float32, device=dev)
-                    (lib.ft_adamw_step_fm if factored else lib.ft_adamw_step)(w, mom, var, w0, a_rows, dy.contiguous(), y_next, one, adam_t, cfg.lr,
-                                                                              0.9, 0.999, 1e-8, cfg.weight_decay, clamp)
+                    if factored:
+                        lib.ft_adamw_step_fm(w, mom, var, w0, a_rows, dy.contiguous(), y_next, one, adam_t, cfg.lr, 0.9, 0.999, 1e-8, cfg.weight_decay,
+                                             clamp, single=single)
+                    else:
+                        lib.ft_adamw_step(w, mom, var, w0, a_rows, dy.contiguous(), y_next, one, adam_t, cfg.lr, 0.9, 0.999, 1e-8, cfg.weight_decay, clamp)
                     updated = True
             if loss_sum / cnt < LOSS_FLOOR:
                 break

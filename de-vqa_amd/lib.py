@@ -72,7 +72,7 @@ def load():
     _sig(L.devqa_layernorm_bwd_params, [P, P, P, I, I, F, I, I, P, P, P, P])
     _sig(L.devqa_colsum_f32, [P, I, I, I, P, P])
     _sig(L.devqa_ft_adamw_step, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I64, P])
-    _sig(L.devqa_ft_adamw_step_fm, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I64, P])
+    _sig(L.devqa_ft_adamw_step_fm, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I64, P])
     _sig(L.devqa_active_columns, [P, I, I, I, P, P, P])
     _sig(L.devqa_gather_cols_f32, [P, I64, I64, I, P, I64, P, I, I, P, P])
     _sig(L.devqa_gather_cols_bf16, [P, I64, I64, I, P, I64, P, I, I, P, P])
@@ -536,18 +536,20 @@ def ft_adamw_step(w, m, v, w0, a, dy, y, do_update, adam_t, lr, beta1, beta2, ep
                                     float(clamp_eps), w0_stride, _stream()), "devqa_ft_adamw_step")
 
 
-def ft_adamw_step_fm(w, dstate, v, w0, a, dy, y, do_update, adam_t, lr, beta1, beta2, eps, wd, clamp_eps):
-    """ft_adamw_step without a first-moment matrix (include/devqa.h, devqa_ft_adamw_step_fm): `dstate` fp32 [E, Lmax, Dout] holds the EMA of
-    dy; a[e] must not change between two first updates of edit e."""
+def ft_adamw_step_fm(w, dstate, v, w0, a, dy, y, do_update, adam_t, lr, beta1, beta2, eps, wd, clamp_eps, single=None):
+    """ft_adamw_step without a first-moment matrix (include/devqa.h, devqa_ft_adamw_step_fm): `dstate` fp32 [E, Lmax + 1, Dout] holds the EMA
+    of dy (and, for edits flagged in `single` int32 [E] -- one loss row, in slot 0 -- the EMA of dy[0]^2: their second moment factors too and
+    v is not touched); a[e] must not change between two first updates of edit e."""
     E, Dout, Din = w.shape
     Lmax = a.shape[1]
     for t, n in ((w, "w"), (dstate, "dstate"), (v, "v"), (w0, "w0"), (a, "a"), (dy, "dy"), (y, "y")):
         _need(t, torch.float32, "ft_adamw_step_fm " + n)
     assert a.shape == (E, Lmax, Din) and dy.shape == (E, Lmax, Dout) and y.shape == (E, Lmax, Dout)
-    assert w0.shape in ((Dout, Din), (E, Dout, Din)) and dstate.shape == (E, Lmax, Dout) and v.shape == w.shape
+    assert w0.shape in ((Dout, Din), (E, Dout, Din)) and dstate.shape == (E, Lmax + 1, Dout) and v.shape == w.shape
     assert do_update.dtype == torch.int32 and adam_t.dtype == torch.int32
+    assert single is None or (single.dtype == torch.int32 and single.shape == (E,) and single.is_cuda)
     w0_stride = Dout * Din if w0.dim() == 3 else 0
-    _chk(load().devqa_ft_adamw_step_fm(_p(w), _p(dstate), _p(v), _p(w0), _p(a), _p(dy), _p(y), _p(do_update), _p(adam_t), E, Lmax,
+    _chk(load().devqa_ft_adamw_step_fm(_p(w), _p(dstate), _p(v), _p(w0), _p(a), _p(dy), _p(y), _p(do_update), _p(adam_t), _p(single), E, Lmax,
                                        Dout, Din, float(lr), float(beta1), float(beta2), float(eps), float(wd),
                                        float(clamp_eps), w0_stride, _stream()), "devqa_ft_adamw_step_fm")
 

@@ -327,12 +327,16 @@ int devqa_ft_adamw_step(float* w, float* m, float* v, const float* w0, const flo
  * dy_t^T (x) a and the first moment is m_t = D_t^T (x) a with D_t = lerp(D_{t-1}, dy_t, 1 - beta1): a state of [Lmax][Dout] floats per edit
  * instead of [Dout][Din].  The kernel keeps D in `dstate`, rebuilds m_t per element from D_t and the a-values it holds anyway (L fmas) and
  * streams only w and v: 4*4*Dout*Din bytes per edit-step (first update: read w0, write w, v = 3*4) instead of 6*4.  Exact in exact
- * arithmetic; in fp32 m_t differs from the recurrence by rounding only (the second moment is NOT factored: sums of squares of sums cancel).
+ * arithmetic; in fp32 m_t differs from the recurrence by rounding only.  The second moment is a sum of squares of sums and does NOT factor
+ * safely in fp32 -- except for an edit with ONE loss row (single[e] != 0: dy[e][r] == 0 and a[e][r] == 0 for every r >= 1, at every step):
+ * then v_t[i][j] = e_t[i] * a[e][0][j]^2 with e_t = beta2 e_{t-1} + (1 - beta2) dy_t[0][i]^2, one term, nothing cancels; e is kept in row
+ * Lmax of `dstate`, v[e] is neither read nor written and only w crosses HBM (2*4*Dout*Din bytes per step).
  * CONTRACT: a[e] must hold the same values at every step between two first updates (adam_t[e] == 1) of edit e.
- *   dstate : fp32 [E][Lmax][Dout] (laid out like dy; contents ignored at adam_t[e] == 1), everything else as devqa_ft_adamw_step.
+ *   dstate : fp32 [E][Lmax + 1][Dout] (rows 0..Lmax-1 laid out like dy, row Lmax = e; contents ignored at adam_t[e] == 1)
+ *   single : int32 [E] or NULL (no edit takes the one-row form); everything else as devqa_ft_adamw_step.
  */
 int devqa_ft_adamw_step_fm(float* w, float* dstate, float* v, const float* w0, const float* a, const float* dy, float* y,
-                           const int32_t* do_update, const int32_t* adam_t, int E, int Lmax, int Dout, int Din,
+                           const int32_t* do_update, const int32_t* adam_t, const int32_t* single, int E, int Lmax, int Dout, int Din,
                            float lr, float beta1, float beta2, float eps, float weight_decay, float clamp_eps,
                            int64_t w0_stride_e, void* stream);
 

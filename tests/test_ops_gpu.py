@@ -338,23 +338,35 @@ def test_ft_adamw_step_matches_torch_adamw(L, Lmax, wd, clamp, Din, form):
     lr = 1e-3
     w0 = torch.randn(Dout, Din, generator=g) * 0.05
     a = torch.relu(torch.randn(E, Lmax, Din, generator=g))
+    # factored form: edit 2 is a ONE-ROW edit (only slot 0 carries a loss row): flagged `single`, its second moment is factored as well and
+    # its v matrix is never touched
+    one_row = form == "factored"
+    if one_row:
+        a[2, 1:] = 0
     w = torch.zeros(E, Dout, Din, device="cuda")
-    m = torch.zeros_like(w) if form == "matrix" else torch.full((E, Lmax, Dout), float("nan"), device="cuda")   # (the state is ignored at the first update)
+    m = torch.zeros_like(w) if form == "matrix" else torch.full((E, Lmax + 1, Dout), float("nan"), device="cuda")   # (the state is ignored at the first update)
     v = torch.zeros_like(w)
+    if one_row:
+        v[2] = 7.0
+    single = torch.tensor([0, 0, 1], dtype=torch.int32, device="cuda") if one_row else None
     y = torch.zeros(E, Lmax, Dout, device="cuda")
     do_update = torch.tensor([1, 0, 1], dtype=torch.int32, device="cuda")  # edit 1 never updates
     adam_t = torch.zeros(E, dtype=torch.int32, device="cuda")
     params = [w0.clone().requires_grad_(True) for _ in range(E)]
     opts = [torch.optim.AdamW([p], lr=lr, weight_decay=wd) for p in params]
-    step_fn = L.ft_adamw_step if form == "matrix" else L.ft_adamw_step_fm
     for step in range(5):
         dy = torch.randn(E, Lmax, Dout, generator=g) * 0.1
+        if one_row:
+            dy[2, 1:] = 0
         if step == 3:
             do_update[0] = 0           # a skipped step in the middle (loss under the floor): state and outputs of edit 0 stay
         elif step == 4:
             do_update[0] = 1
         adam_t += do_update
-        step_fn(w, m, v, dev(w0), dev(a), dev(dy), y, do_update, adam_t, lr, 0.9, 0.999, 1e-8, wd, clamp)
+        if form == "matrix":
+            L.ft_adamw_step(w, m, v, dev(w0), dev(a), dev(dy), y, do_update, adam_t, lr, 0.9, 0.999, 1e-8, wd, clamp)
+        else:
+            L.ft_adamw_step_fm(w, m, v, dev(w0), dev(a), dev(dy), y, do_update, adam_t, lr, 0.9, 0.999, 1e-8, wd, clamp, single=single)
         for e in range(E):
             if int(do_update[e]) == 0:
                 continue
@@ -376,9 +388,14 @@ def test_ft_adamw_step_matches_torch_adamw(L, Lmax, wd, clamp, Din, form):
             ref_y = a[e] @ params[e].detach().T
             np.testing.assert_allclose(y[e].cpu().numpy(), ref_y.numpy(), atol=(1e-4 if form == "matrix" else 2e-4) * (Din / 80) ** 0.5, rtol=1e-4)
             ref_m = opts[e].state[params[e]]["exp_avg"]
-            got_m = m[e].cpu() if form == "matrix" else torch.einsum("lo,li->oi", m[e].cpu(), a[e])
+            got_m = m[e].cpu() if form == "matrix" else torch.einsum("lo,li->oi", m[e, :Lmax].cpu(), a[e])
             np.testing.assert_allclose(got_m.numpy(), ref_m.numpy(), atol=1e-6, rtol=1e-4)
-            np.testing.assert_allclose(v[e].cpu().numpy(), opts[e].state[params[e]]["exp_avg_sq"].numpy(), atol=1e-9, rtol=1e-4)
+            ref_v = opts[e].state[params[e]]["exp_avg_sq"]
+            if one_row and e == 2:      # v_t = e_t (x) a[0]^2, the matrix untouched
+                np.testing.assert_allclose(torch.outer(m[e, Lmax].cpu(), a[e, 0] ** 2).numpy(), ref_v.numpy(), atol=1e-9, rtol=1e-4)
+                assert float((v[e] - 7.0).abs().max()) == 0.0
+            else:
+                np.testing.assert_allclose(v[e].cpu().numpy(), ref_v.numpy(), atol=1e-9, rtol=1e-4)
     assert float(y[1].abs().sum()) == 0.0  # inactive edit untouched
 
 
