@@ -641,3 +641,29 @@ def test_layernorm_param_grads_and_colsum(L):
         L.colsum_(dev(dy), cs, True)
         L.colsum_(dev(dy), cs, True)
         np.testing.assert_allclose(cs.cpu().numpy(), 2 * dy.double().sum(0).float().numpy(), rtol=1e-5, atol=1e-5 * M ** 0.5)
+
+
+@pytest.mark.parametrize("dh,H", [(128, 64), (64, 24), (32, 5), (96, 8), (8, 6)])
+def test_rope_bf16_vector_form_is_the_elementwise_form(L, dh, H):
+    """Rotary embedding (HF rotate_half convention) on q | k heads of a fused buffer: the 16-byte form (dh % 32 == 0) against the element-wise
+    kernel -- reached through a row stride that is not a multiple of 8 -- bit for bit, and both against a float64 restatement."""
+    g = torch.Generator().manual_seed(dh)
+    R, theta = 37, 10000.0
+    pos = torch.randint(0, 700, (R,), generator=g).to(torch.int32)
+    x = (torch.randn(R, H * dh, generator=g) * 2).to(torch.bfloat16)
+    a = x.clone().cuda()
+    L.rope_(a, pos.cuda(), H, dh, theta)
+    wide = torch.zeros(R, H * dh + 4, dtype=torch.bfloat16, device="cuda")
+    b = wide[:, :H * dh]
+    b.copy_(x.cuda())
+    L.rope_(b, pos.cuda(), H, dh, theta)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    half = dh // 2
+    inv = theta ** (-torch.arange(half, dtype=torch.float64) * 2 / dh)
+    ang = pos.double()[:, None] * inv[None, :]
+    xd = x.double().view(R, H, dh)
+    ref = torch.cat([xd[..., :half] * ang.cos()[:, None] - xd[..., half:] * ang.sin()[:, None],
+                     xd[..., half:] * ang.cos()[:, None] + xd[..., :half] * ang.sin()[:, None]], -1).view(R, H * dh)
+    np.testing.assert_allclose(a.float().cpu().numpy(), ref.numpy(), atol=6e-2, rtol=1e-2)
+
