@@ -337,20 +337,38 @@ void devqa_launch_splitk_reduce_epilogue(const float* ws, int splits, int M, int
                        st, ws, splits, M, N, bias, alpha, act, residual, out_bf16, out_f32, ldc);
 }
 
+// 1 when a fused-SwiGLU call of this shape takes the 256 x 256 ping-pong kernel under the current mode (the dispatch rule of devqa_gemm_bf16 below)
+extern "C" int devqa_gemm_bf16_swiglu_supported(int M, int N, int K) {
+    const int g_gemm_mode = gemm_mode();
+    if (M <= 64 || N <= 0 || K <= 0 || N % 256 != 0 || K % 64 != 0) return 0;
+    if (g_gemm_mode == 1 || g_gemm_mode == 2 || g_gemm_mode == 3 || (g_gemm_mode >= 10 && g_gemm_mode < 20)) return 0;
+    if (g_gemm_mode >= 20) return 1;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    return (t128 >= 384 && t256 >= 128) ? 1 : 0;
+}
+
 extern "C" int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64_t ldw, const float* bias,
                                int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
                                float* out_f32, int64_t ldc, void* stream) {
     DEVQA_CHECK_ARG(A && W, "gemm: null operand");
     DEVQA_CHECK_ARG(out_bf16 || out_f32, "gemm: no output");
-    DEVQA_CHECK_ARG(act >= 0 && act <= 3, "gemm: bad act %d", act);
+    DEVQA_CHECK_ARG(act >= 0 && act <= DEVQA_ACT_SWIGLU_IL16, "gemm: bad act %d", act);
     if (M == 0 || N == 0) return DEVQA_OK;
     DEVQA_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "gemm: bad dims %d %d %d", M, N, K);
     DEVQA_CHECK_SHAPE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K/lda/ldw must be multiples of 8 (K=%d lda=%lld ldw=%lld)",
                       K, (long long)lda, (long long)ldw);
-    DEVQA_CHECK_SHAPE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dims too small");
+    DEVQA_CHECK_SHAPE(lda >= K && ldw >= K && ldc >= (act == DEVQA_ACT_SWIGLU_IL16 ? N / 2 : N), "gemm: leading dims too small");
     DEVQA_CHECK_SHAPE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int g_gemm_mode = gemm_mode();
+    if (act == DEVQA_ACT_SWIGLU_IL16) {      // fused SwiGLU: the 256 x 256 kernel only (devqa_gemm_bf16_swiglu_supported says when)
+        if (!devqa_gemm_bf16_swiglu_supported(M, N, K)) return devqa_fail(DEVQA_E_SHAPE, "gemm_bf16: fused SwiGLU is not available for M=%d N=%d K=%d in this mode", M, N, K);
+        const int ph = devqa_prof_begin(3, st);
+        const int rc = launch_gemm_pp(g_gemm_mode >= 20 ? g_gemm_mode - 20 : 2, A, lda, W, ldw, bias, M, N, K, alpha, act, residual, out_bf16, out_f32, ldc, st);
+        devqa_prof_end(ph, 2.0 * (double)M * (double)N * (double)K, st);
+        return rc;
+    }
     // Skinny problems are weight streams: with one 64x128 (128x128) tile per 128 output columns a [64 x 10240 x 2560] product runs
     // on 80 workgroups, and the 257-row GEMMs of a single-image ViT pass on 33-165.  When the tiles cover less than half the chip,
     // split K over enough workgroups to fill it (fp32 partials in the per-stream workspace, one reduce + epilogue pass).

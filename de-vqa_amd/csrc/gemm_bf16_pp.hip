@@ -482,6 +482,49 @@ __device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char*
     }
 }
 
+// Fused SwiGLU (DEVQA_ACT_SWIGLU_IL16, include/devqa.h): the weight rows are interleaved in blocks of 16 (gate | up), so the wave tile's column
+// blocks are (gate, up, gate, up) of 32 consecutive output columns: out = silu(acc[.][2 jj]) * acc[.][2 jj + 1] element by element in the MFMA
+// layout, then the half-width bf16 transposition (2 x [64 rows][64 B] per wave, 4 lanes per row) and 16-byte stores into the [M, N / 2] output.
+__device__ __forceinline__ void pp_epilogue_swiglu(const PPArgs& g, unsigned char* smem, int m0, int n0, const float4_t (&acc)[8][4]) {
+    constexpr int RB = 64, LPR = 4, RPI = 16, NIT = 4, SWM = 3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    unsigned char* stg = smem + wave * 16384;
+    const int rrow = lane / LPR, pc = lane % LPR;
+    const int No = g.N >> 1;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        unsigned char* area = stg + half * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + fr;
+            const int sw = (row >> 1) & SWM;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const float4_t ga = acc[half * 4 + i][2 * jj], ua = acc[half * 4 + i][2 * jj + 1];
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ga[e] / (1.f + __expf(-ga[e])) * ua[e];      // (the expression of swiglu_bf16x8_kernel)
+                uint2 p;
+                p.x = pp_pack2(o[0], o[1]);
+                p.y = pp_pack2(o[2], o[3]);
+                *reinterpret_cast<uint2*>(area + row * RB + (((jj * 2 + (fq >> 1)) ^ sw) << 4) + (fq & 1) * 8) = p;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPI + rrow;
+            const uint4 val = *reinterpret_cast<const uint4*>(area + row * RB + (pc << 4));
+            const int gm = m0 + wr * 128 + half * 64 + row;
+            const int gcol = (n0 >> 1) + wc * 32 + ((pc ^ ((row >> 1) & SWM)) << 3);
+            if (gm < g.M && gcol < No) *reinterpret_cast<uint4*>(g.out_bf16 + (int64_t)gm * g.ldc + gcol) = val;
+        }
+    }
+}
+
 // Half-width column tile: K-tiles [0, nk) of rows [m0, m0 + 256) x columns [n0, n0 + 128) -> acc[.][0..1] (wave (wr, wc): rows
 // wr * 128 + 0..127, columns wc * 32 + 0..31).  Same barrier count for every wave.
 __device__ __forceinline__ void pp_mainloop_half(const PPArgs& g, unsigned char* smem, int m0, int n0, int nk, float4_t (&acc)[8][4]) {
@@ -559,7 +602,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
         const int bid = blockIdx.x, nwg = g.dp_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         int tile_m, tile_n;
         pp_tile_coords(g, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx, tile_m, tile_n);
-        if (g.half_n && g.N - tile_n * PP_BN <= PP_BN / 2) {      // uniform: the half-width last column tile
+        if (ACT != DEVQA_ACT_SWIGLU_IL16 && g.half_n && g.N - tile_n * PP_BN <= PP_BN / 2) {      // uniform: the half-width last column tile
             pp_mainloop_half(g, smem, tile_m * PP_BM, tile_n * PP_BN, nk, acc);
             if (g.bf16_fast) pp_epilogue_bf16<ACT, true>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
             else pp_epilogue<ACT, true>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
@@ -567,7 +610,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
         }
         pp_mainloop<BAL>(g, smem, tile_m * PP_BM, tile_n * PP_BN, 0, nk, acc);
         PP_STAMP(2);
-        if (g.bf16_fast) pp_epilogue_bf16<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
+        if constexpr (ACT == DEVQA_ACT_SWIGLU_IL16) pp_epilogue_swiglu(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
+        else if (g.bf16_fast) pp_epilogue_bf16<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
         else pp_epilogue<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_STAMP(3);
@@ -696,6 +740,12 @@ int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_
         case DEVQA_ACT_RELU: return launch_pp<DEVQA_ACT_RELU>(g, st);
         case DEVQA_ACT_GELU: return launch_pp<DEVQA_ACT_GELU>(g, st);
         case DEVQA_ACT_QUICK_GELU: return launch_pp<DEVQA_ACT_QUICK_GELU>(g, st);
+        case DEVQA_ACT_SWIGLU_IL16:
+            if (bias != nullptr || residual != nullptr || out_f32 != nullptr || out_bf16 == nullptr || alpha != 1.f || N % PP_BN != 0 || ldc % 8 != 0 ||
+                (((uintptr_t)out_bf16) & 15) != 0)
+                return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: fused SwiGLU needs a bf16 output only, no bias / residual / alpha, N %% 256 == 0, ldc %% 8 == 0");
+            g.half_n = 0;
+            return launch_pp<DEVQA_ACT_SWIGLU_IL16>(g, st);
     }
     return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown activation %d", act);
 }

@@ -506,12 +506,21 @@ int llama_layers(const Ctx& c, float* x, const int32_t* pos, const int32_t* desc
         RC(attention(c, qkv, 3 * D, qkv + (int64_t)D * e, 3 * D, qkv + (int64_t)2 * D * e, 3 * D, w.att, D, desc, n_seq, max_len, H, dh, 1, st));
         RC(gemm(c, w.att, D, p + "self_attn.o_proj.weight", nullptr, R, D, D, 1.f, DEVQA_ACT_NONE, x, nullptr, x, st));
         RC(rmsnorm(c, x, nullptr, p + "post_attention_layernorm.weight", R, D, d.t_rms_eps, w.h, nullptr, st));
-        snprintf(buf, sizeof(buf), "derived.llama_gu.%d.weight", i);
-        RC(gemm(c, w.h, D, buf, nullptr, R, 2 * F, D, 1.f, DEVQA_ACT_NONE, nullptr, w.gu, nullptr, st));
         const bool last_stop = stop_before_fc2 && i == first + n_layers - 1;
         void* a = last_stop ? a_out : w.a;
-        if (c.bf16) RC(devqa_swiglu_bf16((const devqa_bf16*)w.gu, R, F, (devqa_bf16*)a, st));
-        else RC(devqa_swiglu_f32((const float*)w.gu, R, F, (float*)a, st));
+        // SwiGLU inside the [gate | up] GEMM's epilogue when the host asked for it (t_flags), registered the row-interleaved operand and the
+        // call shape takes the 256 x 256 kernel: no [R, 2F] intermediate, no second pass (2.7 GB per layer at R = 40 k, F = 11008)
+        snprintf(buf, sizeof(buf), "derived.llama_gu_il.%d.weight", i);
+        const Weight* wil = (c.bf16 && (d.t_flags & DEVQA_DESC_FUSE_SWIGLU)) ? find(c, buf) : nullptr;
+        if (wil && wil->dtype == DEVQA_DTYPE_BF16 && devqa_gemm_bf16_swiglu_supported(R, 2 * F, D)) {
+            RC(devqa_gemm_bf16((const devqa_bf16*)w.h, D, (const devqa_bf16*)wil->ptr, D, nullptr, R, 2 * F, D, 1.f, DEVQA_ACT_SWIGLU_IL16, nullptr,
+                               (devqa_bf16*)a, nullptr, F, st));
+        } else {
+            snprintf(buf, sizeof(buf), "derived.llama_gu.%d.weight", i);
+            RC(gemm(c, w.h, D, buf, nullptr, R, 2 * F, D, 1.f, DEVQA_ACT_NONE, nullptr, w.gu, nullptr, st));
+            if (c.bf16) RC(devqa_swiglu_bf16((const devqa_bf16*)w.gu, R, F, (devqa_bf16*)a, st));
+            else RC(devqa_swiglu_f32((const float*)w.gu, R, F, (float*)a, st));
+        }
         if (last_stop) return DEVQA_OK;
         RC(gemm(c, a, F, p + "mlp.down_proj.weight", nullptr, R, D, F, 1.f, DEVQA_ACT_NONE, x, nullptr, x, st));
     }

@@ -135,6 +135,10 @@ class MENDvl(VLLMBaseEditorWithTraining):
         elif for_train:
             self.reinit_train_parameters()
         eng.set_module_deltas({})
+        if any(m["name"].endswith(("gate_proj", "up_proj")) for m in self.modules):
+            # gate / up outputs receive low-rank deltas after an edit (two-pass form): the pre-edit probes must round like the post-edit ones, so
+            # the model does not take the fused-SwiGLU GEMM at all (engine_llava._fuse_swiglu)
+            eng.fuse_swiglu = False
 
     # ---- trained state ------------------------------------------------------------------------------------------
     def load_train_modules(self, tm):

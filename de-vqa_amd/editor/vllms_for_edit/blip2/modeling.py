@@ -280,7 +280,33 @@ class Blip2Native(_NoTorchHooks, nn.Module):
         extra = [ent[1].data_ptr() for ent in self._fp32_masters.values()]
         extra += [w.data_ptr() for w in self.fused_w.values()] + [b.data_ptr() for b in self.fused_b.values()]
         extra += [self.patch_w_gemm.data_ptr(), 0 if self.embed_T is None else self.embed_T.data_ptr()]
+        extra += [w.data_ptr() for w in self.__dict__.get("_gu_il", {}).values()]
         return hash((tuple(d[k].data_ptr() for d, k in slots), tuple(extra)))
+
+    # ---- LLaMA decoders (LLaVA, MiniGPT-4): the fused [gate | up] operand a second time with its rows interleaved in blocks of 16, the layout the
+    # GEMM's fused SwiGLU epilogue wants (include/devqa.h, DEVQA_ACT_SWIGLU_IL16; bf16 compute mode only).  Refreshed IN PLACE when a gate / up
+    # row block is written (the path-level context holds the buffers' addresses) ----
+    def gu_interleaved(self):
+        """{layer: [2F, d] bf16} or {} (fp32 mode, no LLaMA FFN, F % 16 != 0), up to date."""
+        if self.wdtype != torch.bfloat16:
+            return {}
+        il = self.__dict__.setdefault("_gu_il", {})
+        ver = self.__dict__.setdefault("_gu_il_ver", {})
+        for key, w in self.fused_w.items():
+            if not key.startswith("llama_gu.") or (w.shape[0] // 2) % 16 != 0:
+                continue
+            layer = int(key.split(".")[1])
+            v = (w._version, w.data_ptr())
+            if ver.get(layer) == v:
+                continue
+            F = w.shape[0] // 2
+            src = torch.cat([w[:F].view(F // 16, 16, -1), w[F:].view(F // 16, 16, -1)], 1).reshape(2 * F, -1)
+            if layer in il:
+                il[layer].copy_(src)
+            else:
+                il[layer] = src.contiguous()
+            ver[layer] = v
+        return il
 
     def mark_dirty(self, name):
         """Call after writing an fp32 master through a raw pointer (torch's version counter

@@ -49,6 +49,7 @@ class LlavaNative(Blip2Native):
 
     @torch.no_grad()
     def refresh_derived(self, force=False):
+        self.gu_interleaved()          # (keeps the interleaved [gate | up] operands current; no-op when nothing was written)
         pw = self.get("vision_tower.vision_model.embeddings.patch_embedding.weight")
         head = self.get("language_model.lm_head.weight")
         ver = (pw._version, head._version, pw.data_ptr(), head.data_ptr())
@@ -80,6 +81,8 @@ class LlavaNative(Blip2Native):
             t["derived.%s.weight" % key] = w
         for key, b in self.fused_b.items():
             t["derived.%s.bias" % key] = b
+        for layer, w in self.gu_interleaved().items():
+            t["derived.llama_gu_il.%d.weight" % layer] = w
         t["derived.patch_w_gemm"] = self.patch_w_gemm
         t["derived.embed_T"] = self.embed_T
         return t

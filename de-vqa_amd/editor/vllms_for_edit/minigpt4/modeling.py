@@ -57,6 +57,7 @@ class MiniGPT4Native(Blip2Native):
 
     @torch.no_grad()
     def refresh_derived(self, force=False):
+        self.gu_interleaved()          # (keeps the interleaved [gate | up] operands current; no-op when nothing was written)
         pw = self.get("visual_encoder.patch_embed.proj.weight")
         head = self.get("llama_model.lm_head.weight")
         b0 = self.get("visual_encoder.blocks.0.attn.q_bias")
@@ -98,6 +99,8 @@ class MiniGPT4Native(Blip2Native):
             t["vision_model.encoder.layers.%d.self_attn.qkv.bias" % i] = b
         for key, w in self.fused_w.items():
             t["derived.%s.weight" % key] = w
+        for layer, w in self.gu_interleaved().items():
+            t["derived.llama_gu_il.%d.weight" % layer] = w
         t["derived.patch_w_gemm"] = self.patch_w_gemm
         t["derived.embed_T"] = self.embed_T
         return t

@@ -38,7 +38,8 @@ class LlavaEngine:
                              t_hidden=t["hidden_size"], t_layers=t["num_hidden_layers"], t_heads=t["num_attention_heads"],
                              t_ffn=t["intermediate_size"], t_vocab=self._p(self.lm + "lm_head.weight").shape[0],
                              t_max_pos=t.get("max_position_embeddings", 0), v_ln_eps=v["layer_norm_eps"], t_rms_eps=self.eps,
-                             t_rope_theta=self.theta, v_run_layers=v["num_hidden_layers"] - 1)
+                             t_rope_theta=self.theta, v_run_layers=v["num_hidden_layers"] - 1,
+                             t_flags=lib.DESC_FUSE_SWIGLU if self._fuse_swiglu() else 0)
 
     def path_ctx(self):
         """lib.PathContext over this model's weight table (rebuilt when any of its buffers has moved: storage fingerprint), or None
@@ -48,7 +49,7 @@ class LlavaEngine:
         if not hasattr(self.m, "weight_table") or os.environ.get("DEVQA_PATH_ABI", "1") == "0":
             return None
         self.m.refresh_derived()
-        fp = self.m.storage_fingerprint()
+        fp = (self.m.storage_fingerprint(), self._fuse_swiglu())
         if self.__dict__.get("_ctx") is None or self._ctx_fp != fp:
             old = self.__dict__.get("_ctx")
             if old is not None:
@@ -58,6 +59,13 @@ class LlavaEngine:
             self._ctx_fp = fp
         self.m.refresh_shadows()
         return self._ctx
+
+    def _fuse_swiglu(self):
+        """SwiGLU inside the [gate | up] GEMM's epilogue (lib.gemm_swiglu; bf16 mode, layers whose gate / up outputs nobody needs).  An editor that
+        hooks gate_proj / up_proj (MEND_VL on the LLaMA FFN) turns it off for the whole model (`fuse_swiglu = False`): its pre-edit probes must
+        round like its post-edit ones, which run the two-pass form with the deltas.  DEVQA_SWIGLU_FUSED=0: off."""
+        import os
+        return bool(self.__dict__.get("fuse_swiglu", True)) and self.adt == torch.bfloat16 and os.environ.get("DEVQA_SWIGLU_FUSED", "1") != "0"
 
     def _hooks_active(self):
         return bool(getattr(self, "module_deltas", None)) or bool(getattr(self, "extra_neurons", None))
@@ -254,12 +262,17 @@ class LlavaEngine:
             lib.gemm(att, self._w(p + "self_attn.o_proj.weight"), residual=x, out_f32=x)
             h = lib.rmsnorm(x, self._p(p + "post_attention_layernorm.weight"), self.eps, want=self.want)
             dg, du = deltas.get(p + "mlp.gate_proj"), deltas.get(p + "mlp.up_proj")
-            if dg is None and du is None:
-                gu = lib.gemm(h, m.fused_w["llama_gu.%d" % i])
-            else:   # [h | h xt_g^T | h xt_u^T] . [W_gu | dt_g (gate rows) | dt_u (up rows)]^T: one GEMM over the concatenated K
-                parts = [h] + [lib.gemm(h, e["xt"]) for e in (dg, du) if e is not None]
-                gu = lib.gemm(torch.cat(parts, 1), self._gu_cat[i])
-            a = lib.swiglu(gu)
+            gu = None
+            w_il = m.gu_interleaved().get(i) if (rec is None and dg is None and du is None and self._fuse_swiglu()) else None
+            if w_il is not None and lib.gemm_swiglu_supported(h.shape[0], w_il.shape[0], w_il.shape[1]):
+                a = lib.gemm_swiglu(h, w_il)        # silu(gate) * up in the GEMM's epilogue: no [R, 2F] intermediate (same call as the path context's)
+            else:
+                if dg is None and du is None:
+                    gu = lib.gemm(h, m.fused_w["llama_gu.%d" % i])
+                else:   # [h | h xt_g^T | h xt_u^T] . [W_gu | dt_g (gate rows) | dt_u (up rows)]^T: one GEMM over the concatenated K
+                    parts = [h] + [lib.gemm(h, e["xt"]) for e in (dg, du) if e is not None]
+                    gu = lib.gemm(torch.cat(parts, 1), self._gu_cat[i])
+                a = lib.swiglu(gu)
             if rec is not None:
                 rec.update(qkv=qkv, att=att, x_mid=x.clone(), h2=h, gu=gu, a=a)
             if stop_before_fc2 and i == last:

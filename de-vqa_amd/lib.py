@@ -40,6 +40,7 @@ def load():
     _sig(L.devqa_last_error, [], ctypes.c_char_p)
     _sig(L.devqa_abi_version, [])
     _sig(L.devqa_gemm_bf16, [P, I64, P, I64, P, I, I, I, F, I, P, P, P, I64, P])
+    _sig(L.devqa_gemm_bf16_swiglu_supported, [I, I, I])
     _sig(L.devqa_gemm_f32, [P, I64, P, I64, P, I, I, I, F, I, P, P, I64, P])
     _sig(L.devqa_rmsnorm, [P, P, P, I, I, F, P, P, P])
     _sig(L.devqa_rmsnorm_bwd_dx, [P, P, P, P, I, I, F, P, P])
@@ -146,7 +147,7 @@ EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "dev
            "devqa_gemm_bf16_splitk", "devqa_gemm_set_mode", "devqa_active_columns", "devqa_gather_cols_f32", "devqa_gather_cols_bf16", "devqa_scatter_cols_add_f32",
            "devqa_profile_gemm", "devqa_profile_gemm_read", "devqa_last_error", "devqa_abi_version", "devqa_gemm_bf16", "devqa_gemm_f32", "devqa_attention_f32",
            "devqa_im2col_patches_f32", "devqa_embed_rows_f32", "devqa_vocab_rows_f32", "devqa_layernorm", "devqa_attention",
-           "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16", "devqa_split_f32_bf16x2",
+           "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16", "devqa_split_f32_bf16x2", "devqa_gemm_bf16_swiglu_supported",
            "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_layernorm_bwd_params", "devqa_colsum_f32", "devqa_ft_adamw_step", "devqa_ft_adamw_step_fm", "devqa_rows_matvec_f32", "devqa_delta_op",
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk", "devqa_attention_bwd",
            "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_mend_normalize_concat",
@@ -305,6 +306,39 @@ def gemm(a, w, bias=None, alpha=1.0, act=ACT_NONE, residual=None, out_bf16=None,
     if out_bf16 is not None and out_f32 is not None:
         return out_bf16, out_f32
     return out_bf16 if out_bf16 is not None else out_f32
+
+
+ACT_SWIGLU_IL16 = 4
+DESC_FUSE_SWIGLU = 1
+
+
+def interleave_gate_up(w_gu):
+    """[2F, d] fused (gate rows | up rows) -> the row order devqa_gemm_bf16's fused SwiGLU expects: blocks of 16 gate rows followed by the 16
+    matching up rows (include/devqa.h, DEVQA_ACT_SWIGLU_IL16).  F % 16 == 0."""
+    F2, d = w_gu.shape
+    F = F2 // 2
+    assert F2 == 2 * F and F % 16 == 0
+    return torch.cat([w_gu[:F].view(F // 16, 16, d), w_gu[F:].view(F // 16, 16, d)], 1).reshape(F2, d).contiguous()
+
+
+def gemm_swiglu_supported(M, N, K):
+    """True when a fused-SwiGLU call a [M, K] x w_il [N = 2F, K] takes the 256 x 256 kernel (devqa_gemm_bf16_swiglu_supported)."""
+    return bool(load().devqa_gemm_bf16_swiglu_supported(int(M), int(N), int(K)))
+
+
+def gemm_swiglu(a, w_il, out=None):
+    """out [M, F] bf16 = silu(a . gate^T) * (a . up^T) with w_il = interleave_gate_up([gate | up]) -- one GEMM, no [M, 2F] intermediate."""
+    assert a.dtype == torch.bfloat16 and a.is_cuda
+    _need(w_il, torch.bfloat16, "gemm_swiglu w")
+    M, K = a.shape
+    N = w_il.shape[0]
+    assert w_il.shape[1] == K and a.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N // 2), dtype=torch.bfloat16, device=a.device)
+    assert out.shape == (M, N // 2) and out.dtype == torch.bfloat16 and out.stride(1) == 1
+    _chk(load().devqa_gemm_bf16(_p(a), a.stride(0), _p(w_il), w_il.stride(0), None, M, N, K, 1.0, ACT_SWIGLU_IL16, None, _p(out), None,
+                                out.stride(0), _stream()), "devqa_gemm_bf16(swiglu)")
+    return out
 
 
 def _gemm_f32(a, w, bias, alpha, act, residual, out_f32):
@@ -816,7 +850,7 @@ class ModelDesc(ctypes.Structure):
                                              "q_hidden", "q_layers", "q_heads", "q_ffn", "q_cross_freq", "num_query_tokens",
                                              "t_hidden", "t_layers", "t_heads", "t_ffn", "t_vocab", "t_max_pos")] + \
                [(n, ctypes.c_float) for n in ("v_ln_eps", "q_ln_eps", "t_ln_eps", "t_rms_eps", "t_rope_theta")] + \
-               [(n, ctypes.c_int32) for n in ("v_run_layers", "reserved")]
+               [(n, ctypes.c_int32) for n in ("v_run_layers", "t_flags")]
 
 
 class WeightEntry(ctypes.Structure):

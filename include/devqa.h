@@ -59,6 +59,13 @@ int devqa_abi_version(void);
 #define DEVQA_ACT_RELU 1
 #define DEVQA_ACT_GELU 2 /* exact erf GELU (HF "gelu") */
 #define DEVQA_ACT_QUICK_GELU 3 /* x * sigmoid(1.702 x) (HF "quick_gelu", CLIP ViT in LLaVA) */
+/* Fused SwiGLU (LLaMA FFN): W is the [gate | up] projection with its rows INTERLEAVED in blocks of 16 -- rows [32 b, 32 b + 16) = gate rows
+ * [16 b, 16 b + 16), rows [32 b + 16, 32 b + 32) = the matching up rows -- and the output is out_bf16 [M, N / 2], out[m, 16 b + c] =
+ * silu(acc[m, 32 b + c]) * acc[m, 32 b + 16 + c], from the fp32 accumulators (no [M, N] intermediate, no second pass).  bf16 output only,
+ * no bias / residual / alpha; N % 256 == 0, ldc = row stride of the [M, N / 2] output (% 8 == 0); served by the 256 x 256 kernel only:
+ * ask devqa_gemm_bf16_swiglu_supported(M, N, K) first (1 = this call shape takes that kernel under the current mode). */
+#define DEVQA_ACT_SWIGLU_IL16 4
+int devqa_gemm_bf16_swiglu_supported(int M, int N, int K);
 int devqa_gemm_bf16(const devqa_bf16* A, int64_t lda, const devqa_bf16* W, int64_t ldw, const float* bias,
                     int M, int N, int K, float alpha, int act, const float* residual, devqa_bf16* out_bf16,
                     float* out_f32, int64_t ldc, void* stream);
@@ -428,6 +435,7 @@ typedef uint64_t devqa_comm_t;
 #define DEVQA_DTYPE_F32 2
 #define DEVQA_SCORE_COLS 16   /* [sample_id, reliability, text_rephrase, image_rephrase, 9 locality accs, edit_time, steps, final_loss] */
 
+#define DEVQA_DESC_FUSE_SWIGLU 1
 typedef struct devqa_model_desc {
     int32_t family;        /* DEVQA_FAMILY_* */
     int32_t compute_dtype; /* DEVQA_DTYPE_BF16 (bf16 operands, fp32 accumulate / residual stream) or DEVQA_DTYPE_F32 ("faithful") */
@@ -438,7 +446,9 @@ typedef struct devqa_model_desc {
     /* LLaMA-family decoders (DEVQA_FAMILY_LLAVA / _MINIGPT4): RMSNorm epsilon, rotary base; LLAVA: number of CLIP encoder layers that
      * run (HF vision_feature_layer = -2 -> v_layers - 1).  Ignored by DEVQA_FAMILY_BLIP2_OPT. */
     float t_rms_eps, t_rope_theta;
-    int32_t v_run_layers, reserved;
+    int32_t v_run_layers, t_flags;        /* t_flags bit 0 (DEVQA_DESC_FUSE_SWIGLU; LLaMA decoders, bf16): when the weight table holds
+                                             derived.llama_gu_il.<i>.weight (the [gate | up] operand with rows interleaved in blocks of 16) and the call
+                                             shape takes the 256 x 256 kernel, SwiGLU runs inside that GEMM's epilogue (DEVQA_ACT_SWIGLU_IL16) */
 } devqa_model_desc;
 
 /* Weight-table names per family.  The table carries ONE canonical naming; a host whose checkpoint names differ registers its tensors

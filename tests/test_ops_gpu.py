@@ -667,3 +667,26 @@ def test_rope_bf16_vector_form_is_the_elementwise_form(L, dh, H):
                      xd[..., half:] * ang.cos()[:, None] + xd[..., :half] * ang.sin()[:, None]], -1).view(R, H * dh)
     np.testing.assert_allclose(a.float().cpu().numpy(), ref.numpy(), atol=6e-2, rtol=1e-2)
 
+
+@pytest.mark.parametrize("M,F,K", [(4096, 2048, 512), (3000, 2560, 256)])
+def test_gemm_fused_swiglu(L, M, F, K):
+    """silu(a . gate^T) * (a . up^T) in the GEMM's epilogue (interleaved [gate | up] rows, DEVQA_ACT_SWIGLU_IL16) against the two-pass form it
+    replaces (GEMM to a bf16 [M, 2F] buffer, then the SwiGLU kernel) and a float64 restatement.  The fused form multiplies the fp32 accumulators
+    -- it skips the bf16 rounding of gate and up -- so it agrees with the two-pass form to bf16 rounding and is the closer one to float64."""
+    g = torch.Generator().manual_seed(F)
+    a = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(2 * F, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    assert L.gemm_swiglu_supported(M, 2 * F, K) and not L.gemm_swiglu_supported(48, 2 * F, K) and not L.gemm_swiglu_supported(M, 2 * F + 64, K)
+    fused = L.gemm_swiglu(a.cuda(), L.interleave_gate_up(w.cuda()))
+    gu = L.gemm(a.cuda(), w.cuda())
+    two = torch.empty(M, F, dtype=torch.bfloat16, device="cuda")
+    L._chk(L.load().devqa_swiglu_bf16(L._p(gu), M, F, L._p(two), L._stream()), "swiglu")
+    acc = a.double() @ w.double().T
+    ref = torch.nn.functional.silu(acc[:, :F]) * acc[:, F:]
+    e_f = (fused.double().cpu() - ref).abs().max().item()
+    e_t = (two.double().cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print("fused SwiGLU: max |err| %.3g, two-pass %.3g (values up to %.3g)" % (e_f, e_t, scale))
+    assert e_f < 8e-3 * scale and e_f <= e_t * 1.05
+    np.testing.assert_allclose(fused.float().cpu().numpy(), two.float().cpu().numpy(), atol=2e-2 * scale, rtol=2e-2)
+
