@@ -234,6 +234,10 @@ class Blip2Native(_NoTorchHooks, nn.Module):
             from .... import lib
             lib.cast_f32_bf16(master.data, shadow)
             ent[2] = master._version
+            slot = self._fused_slot(name)
+            if slot is not None and slot[0].startswith("llama_gu."):
+                # the shadow is a row block of a fused [gate | up] operand, written through a raw pointer: its interleaved copy is stale now
+                self.__dict__.setdefault("_gu_il_ver", {}).pop(int(slot[0].split(".")[1]), None)
         return shadow
 
     @torch.no_grad()
@@ -292,6 +296,10 @@ class Blip2Native(_NoTorchHooks, nn.Module):
             return {}
         il = self.__dict__.setdefault("_gu_il", {})
         ver = self.__dict__.setdefault("_gu_il_ver", {})
+        for name in self._fp32_masters:         # gate / up masters first: their bf16 row blocks are what gets interleaved
+            slot = self._fused_slot(name)
+            if slot is not None and slot[0].startswith("llama_gu."):
+                self.weight_for_gemm(name)
         for key, w in self.fused_w.items():
             if not key.startswith("llama_gu.") or (w.shape[0] // 2) % 16 != 0:
                 continue

@@ -48,6 +48,7 @@ class LlavaEngine:
         import os
         if not hasattr(self.m, "weight_table") or os.environ.get("DEVQA_PATH_ABI", "1") == "0":
             return None
+        self.m.refresh_shadows()        # before the derived operands: the interleaved [gate | up] copy is made from the refreshed row blocks
         self.m.refresh_derived()
         fp = (self.m.storage_fingerprint(), self._fuse_swiglu())
         if self.__dict__.get("_ctx") is None or self._ctx_fp != fp:

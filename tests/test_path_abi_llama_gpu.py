@@ -138,3 +138,54 @@ def test_llama_context_needs_positions(gold_dir, in_gold_dir):
     rc = L.devqa_llm_layers_ex(ctx.h, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(pos.data_ptr()), ctypes.c_void_p(desc.data_ptr()), 1, 4, 4, 1,
                                ctx.desc.t_layers, 1, 0, None, wp, n, None)
     assert rc == -2
+
+
+def test_fused_swiglu_operand_follows_an_edited_gate_proj(gold_dir, in_gold_dir):
+    """The interleaved [gate | up] copy the fused-SwiGLU GEMM reads (blip2/modeling.py: gu_interleaved) is a DERIVED buffer: when an editor writes
+    a gate_proj / up_proj fp32 master through raw pointers (FT_VL's general form, devqa_adam_step) the bf16 row block of the fused operand is
+    refreshed by a HIP cast, which torch's version counter does not see -- the copy must follow all the same.  Forced onto the 256 x 256 kernel
+    (gemm mode 22) so that a tiny decoder takes the fused epilogue; checked on the buffer itself and on the logits against the two-pass form."""
+    import devqa_amd  # noqa: F401
+    from transformers import AutoTokenizer
+    from devqa_amd import lib, minigpt4_spec as S
+    from devqa_amd.editor.vllms_for_edit.minigpt4.minigpt4 import MiniGPT4ForEdit
+    from devqa_amd.editor.vllms_for_edit.minigpt4.modeling import MiniGPT4Native
+    spec = deepcopy(S.TINY_MINIGPT4)
+    spec["text_config"]["intermediate_size"] = 128          # [gate | up] = 256 rows: one column tile of the fused form
+    model = MiniGPT4Native.from_synth(spec, SEED, "unit", "cuda:0", "bf16")
+    tok = AutoTokenizer.from_pretrained(os.path.join(gold_dir, "tiny_llava"))
+    vllm = MiniGPT4ForEdit(None, "cuda:0", True, model=model, tokenizer=tok, dtype="bf16")
+    eng = vllm.engine
+    rec = json.load(open(os.path.join(gold_dir, "evqa8_records.json")))["records"]
+    reqs = [rec[i]["requests"][0] for i in range(6)]
+    (x, vt), _, _ = vllm.prompts_imgs_target_to_xym([r["prompt"] for r in reqs], [r["image"] for r in reqs], [r["target_new"] for r in reqs])
+    rows = int(x["attention_mask"].sum())
+    lib.gemm_set_mode(22)
+    try:
+        assert eng._fuse_swiglu() and lib.gemm_swiglu_supported(rows, 256, 64), rows
+
+        def logits(fused=True):
+            if not fused:
+                os.environ["DEVQA_SWIGLU_FUSED"] = "0"
+            try:
+                out = vllm.get_llm_outpt(x, vt).logits.float().clone()
+            finally:
+                os.environ.pop("DEVQA_SWIGLU_FUSED", None)
+            msk = x["attention_mask"].bool()
+            return out[msk]
+        a0, b0 = logits(), logits(False)
+        name = "llama_model.model.layers.0.mlp.gate_proj.weight"
+        master = model.promote_to_fp32(name)
+        master.data.mul_(-1.0)                  # as a kernel would: in place behind torch's version counter ...
+        model.mark_dirty(name)                  # ... and announced the way FTvl announces it
+        a1, b1 = logits(), logits(False)
+        torch.cuda.synchronize()
+        assert torch.equal(model.gu_interleaved()[0], lib.interleave_gate_up(model.fused_w["llama_gu.0"]))
+        gate = model.fused_w["llama_gu.0"][:128].float()
+        assert torch.equal(gate, master.data.to(torch.bfloat16).float())
+        tol = 4.0 * float((a0 - b0).abs().max()) + 1e-3          # fused vs two-pass: one bf16 rounding of gate and up apart
+        moved = float((b1 - b0).abs().max())
+        assert moved > 10 * tol, (moved, tol)                        # the edit is visible ...
+        assert float((a1 - b1).abs().max()) <= tol, (float((a1 - b1).abs().max()), tol, moved)     # ... and the fused path sees it too
+    finally:
+        lib.gemm_set_mode(0)
