@@ -555,11 +555,12 @@ def test_attention_is_deterministic_and_variants_agree(L):
     """Multi-chunk causal sequences (> 64 keys: the K/V refill path) several times over, and the opt-in instantiations: bit-identical.
     Guards the software-managed MFMA -> VALU read hazard of the inline-asm max chain (csrc/attention_mfma.hip, am_max16): without its
     wait states the running max was read stale now and then -- results within tolerance but different from run to run.
-    The non-causal case takes the ring kernel by default (9-wave tiles, last key of 65 / 129 / 257 folded into the initial softmax state):
-    deterministic; bit-identical to the other stagings with the fold off; within bf16 rounding of them with it on."""
+    The non-causal case takes the ring kernel by default (9-wave tiles; the last key of 65 / 129 / 257 is processed from LDS after the chunk loop
+    instead of as a chunk of its own): deterministic; bit-identical to the other stagings with the fold off; within bf16 rounding of them with
+    it on.  Sequences of 1, 2 and 63 keys share the launch (no chunk to fold into, a lone key, a short chunk)."""
     import os
     torch.manual_seed(3)
-    lens = [104, 30, 70, 129, 64, 65, 257]
+    lens = [104, 30, 70, 129, 64, 65, 257, 1, 2, 63]
     starts = np.cumsum([0] + lens[:-1]).tolist()
     R = sum(lens)
     for H, dh, causal in ((5, 8, 1), (32, 80, 1), (16, 88, 0), (16, 64, 0)):
