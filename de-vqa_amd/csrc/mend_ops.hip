@@ -17,6 +17,26 @@ __global__ void relu_bwd_kernel(const T* __restrict__ act_out, const T* __restri
         mo_st<T>(grad_in + i, mo_ld<T>(act_out + i) > 0.f ? mo_ld<T>(grad_out + i) : 0.f);
 }
 
+// GELU (erf form, HF "gelu": x * 0.5 * (1 + erf(x / sqrt 2))) on fp32 pre-activations kept for a backward pass, and its derivative
+// Phi(x) + x * phi(x): the Q-Former / ViT FFN activation when FT_VL trains Q-Former parameters (ft_vl.py:_execute_ft_general)
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, bf16_t* __restrict__ out_bf16, float* __restrict__ out_f32, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float y = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        if (out_bf16) out_bf16[i] = f32_to_bf16(y);
+        if (out_f32) out_f32[i] = y;
+    }
+}
+
+__global__ void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ grad_out, float* __restrict__ grad_in, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+        grad_in[i] = grad_out[i] * (cdf + v * pdf);
+    }
+}
+
 // out[r, 0:du] = (u[idx[r], :] - u_mean) / (u_std + eps);  out[r, du:du+dv] = (v[idx[r], :] - v_mean) / (v_std + eps)
 // (mean/std NULL: plain gather-concat, cfg.norm == False)
 __global__ void mend_normalize_concat_kernel(const float* __restrict__ u, const float* __restrict__ v, const int32_t* __restrict__ idx,
@@ -97,6 +117,20 @@ extern "C" int devqa_relu_bwd(const devqa_bf16* act_out, const devqa_bf16* grad_
     DEVQA_CHECK_ARG(act_out && grad_out && grad_in && n > 0, "relu_bwd: bad arguments");
     hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(mo_grid(n)), dim3(256), 0, (hipStream_t)stream, act_out, grad_out, grad_in, n);
     DEVQA_LAUNCH_CHECK("relu_bwd");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_gelu_f32(const float* x, devqa_bf16* out_bf16, float* out_f32, int64_t n, void* stream) {
+    DEVQA_CHECK_ARG(x && (out_bf16 || out_f32) && n > 0, "gelu_f32: bad arguments");
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(mo_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out_bf16, out_f32, n);
+    DEVQA_LAUNCH_CHECK("gelu_f32");
+    return DEVQA_OK;
+}
+
+extern "C" int devqa_gelu_bwd_f32(const float* x, const float* grad_out, float* grad_in, int64_t n, void* stream) {
+    DEVQA_CHECK_ARG(x && grad_out && grad_in && n > 0, "gelu_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(mo_grid(n)), dim3(256), 0, (hipStream_t)stream, x, grad_out, grad_in, n);
+    DEVQA_LAUNCH_CHECK("gelu_bwd_f32");
     return DEVQA_OK;
 }
 

@@ -22,8 +22,12 @@ Two execution forms behind the same `execute_ft`:
     (engine.decoder_backward(grads=...), the machinery of LTE_VL's training) and one Adam(W) step per selected tensor
     (devqa_adam_step) on its fp32 master.  Pinned by the reference's own FTvl on three such selections
     (tools/make_goldens_ft_general.py, tests/test_ft_general_gpu.py).
-Targets outside the language model's decoder layers (vision tower, Q-Former, embeddings, final norm) would need a backward pass
-through those parts and raise NotImplementedError.
+  * Q-FORMER (round 3): every selected name is a Q-Former parameter -- the template "qformer" that R/configs/ft_vl/blip2-opt-2.7b.yaml:9 carries as a
+    comment.  Per step the Q-Former runs with saved activations on the frozen ViT rows, all decoder layers run with saved activations, and the
+    gradient returns through the decoder's inputs, the language projection and the Q-Former (engine.qformer_backward: cross- and
+    self-attention, GELU FFN, post-LayerNorms) into one Adam(W) step per tensor.  Pinned by the reference's own FTvl (case D of the same goldens).
+Targets in the vision tower, the embeddings, the final norm, the language projection or the learned queries would need a backward pass
+through those parts and raise NotImplementedError; so does a selection mixing Q-Former and decoder parameters.
 """
 import os
 from copy import deepcopy
@@ -70,11 +74,21 @@ class FTvl(VLLMBaseEditor):
             self.vllm.model.promote_to_fp32(n)
         self.original_w = {n: p.clone() for n, p in self.vllm.model.named_parameters() if n in names}
         self.last_losses: List[float] = []
+        self._image_path_written()       # (the promoted Parameters are new objects: the wrapper's watch list is rebuilt)
 
     def _selected_names(self):
-        # substring selection rule of the reference (ft_vl.py:31-36)
-        return [n for n, _ in self.vllm.model.named_parameters() for layer in self.cfg.layers
-                if self.cfg.rewrite_module_tmp.format(layer) in n]
+        # substring selection rule of the reference (ft_vl.py:31-36: a dict comprehension, so a name several layers select appears once)
+        return list(dict.fromkeys(n for n, _ in self.vllm.model.named_parameters() for layer in self.cfg.layers
+                                  if self.cfg.rewrite_module_tmp.format(layer) in n))
+
+    def _touches_image_path(self):
+        """True when a selected parameter lies outside the language model: image features cached by the wrapper go stale with every write"""
+        lm = getattr(self.vllm.engine, "LM_MODULE", "language_model") + "."
+        return any(not n.startswith(lm) for n in self.original_w)
+
+    def _image_path_written(self):
+        if self._touches_image_path() and hasattr(self.vllm, "invalidate_image_features"):
+            self.vllm.invalidate_image_features()
 
     def name_of_editor_and_model(self) -> Tuple[str, str]:
         return "ft_vl", self.cfg.edit_model_name
@@ -84,6 +98,7 @@ class FTvl(VLLMBaseEditor):
 
     def restore_to_original_model(self):
         self.vllm.model.load_state_dict(self.original_w, strict=False)
+        self._image_path_written()
 
     def edit_one_piece(self, request: Dict) -> None:
         self.edit_batch([request])
@@ -99,6 +114,7 @@ class FTvl(VLLMBaseEditor):
                     w.data.add_(upd)
                 self.vllm.model.mark_dirty(w_name)  # HIP wrote in place: the bf16 shadow is stale
             self.vllm.model.refresh_shadows()       # (row blocks of fused operands are read through the fused buffer: refresh now)
+        self._image_path_written()
 
     # ---------------------------------------------------------------------------------------
     def _edit_target(self):
@@ -164,9 +180,106 @@ class FTvl(VLLMBaseEditor):
             lo = layer if lo is None else min(lo, layer)
         return lo, plan
 
+    def _execute_ft_qformer(self, requests, names):
+        """Every selected name is a Q-Former parameter (the template "qformer" the reference's yaml carries as a comment): per step the Q-Former
+        runs with saved activations on the frozen ViT rows, its projected query rows take their place in front of the text embeddings, ALL
+        decoder layers run with saved activations, and the gradient of the label rows' NLL comes back through the decoder
+        (engine.decoder_backward, inputs only), the language projection and the Q-Former (engine.qformer_backward) into one Adam(W) step per
+        tensor.  As in the reference's wrapper the LAST image of a chunk serves the whole chunk (blip2.py:54-55)."""
+        vllm, eng, model, cfg = self.vllm, self.vllm.engine, self.vllm.model, self.cfg
+        dev = eng.dev
+        if not hasattr(eng, "qformer_backward"):
+            raise NotImplementedError("native FT_VL: this engine has no Q-Former backward")
+        tp = eng.qformer_train_params()
+        for n in names:
+            if n not in tp:
+                raise NotImplementedError("native FT_VL: no gradient path for %s" % n)
+        n_layers, Q = eng.t["num_hidden_layers"], eng.Q
+        params = {n: nethook.get_parameter(model, n) for n in names}
+        w0 = {n: p_.detach().clone() for n, p_ in params.items()}
+        mom = {n: torch.zeros_like(p_.data) for n, p_ in params.items()}
+        var = {n: torch.zeros_like(p_.data) for n, p_ in params.items()}
+        G = {k: torch.zeros(t_.shape, dtype=torch.float32, device=dev) for k, t_ in tp.items()}
+        bs = cfg.batch_size
+        chunks = [requests[i:i + bs] for i in range(0, len(requests), bs)]
+        clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else None
+        t_adam = 0
+        self.last_losses = []
+        prepared = []
+        for c in chunks:
+            if any(r["image"] is None for r in c):
+                raise NotImplementedError("native FT_VL on Q-Former parameters needs an image in every request")
+            (x, vt), y, m = vllm.prompts_imgs_target_to_xym([r["prompt"] for r in c], [r["image"] for r in c], [r["target_new"] for r in c])
+            emb, msk = x["inputs_embeds"].clone(), x["attention_mask"]
+            last = c[-1]["image"]
+            pix = last.to(dev, torch.float32)[None] if isinstance(last, torch.Tensor) else torch.from_numpy(vllm.load_pixels(last))[None].to(dev)
+            img, _ = eng.vit_rows(pix)                                 # the ViT is frozen: once per chunk
+            B, T = emb.shape[:2]
+            L = y.shape[1]
+            mh, yh = VLLM_HOST(m), VLLM_HOST(y)
+            rows = [b * T + (T - L) + j for b in range(B) for j in range(L) if int(mh[b, j]) != 0]
+            labels = [int(yh[b, j]) for b in range(B) for j in range(L) if int(mh[b, j]) != 0]
+            img_rows = lib.h2d([b * T + j for b in range(B) for j in range(Q)], torch.int32, dev)
+            prepared.append((emb, msk, img, img_rows, lib.h2d(rows, torch.int32, dev), lib.h2d(labels, torch.int32, dev), len(rows), len(c)))
+        for it in range(cfg.num_steps):
+            loss_sum, cnt = 0.0, 0
+            for emb, msk, img, img_rows, idx, labels, k, n_items in prepared:
+                model.refresh_shadows()
+                eng.__dict__.pop("_wt_cache", None)
+                B = emb.shape[0]
+                save_q = {}
+                feats = eng.qformer_rows(img, 1, save_q)               # [1, Q, d_llm] under the current Q-Former
+                emb[:, :Q] = feats
+                ps = eng.pack_from_embeds(emb, msk)
+                save = {"layers": set(range(n_layers))}
+                x_fin, _ = eng.decoder_layers(ps, save=save, first_layer=0)
+                pre_ln = lib.gather_rows(x_fin, idx)
+                logits = eng.lm_head(pre_ln)
+                coef = torch.full((k,), 1.0 / k, dtype=torch.float32, device=dev)
+                _, nll, dlog = lib.vocab_rows(logits, labels, coef, want_argmax=False, want_nll=True, want_dlogits=True, dlogits_dtype=eng.adt)
+                loss = float(nll.mean().item())                      # the reference syncs here too (ft_vl.py:129-131)
+                self.last_losses.append(loss)
+                loss_sum += loss * n_items
+                cnt += n_items
+                if loss >= LOSS_FLOOR:
+                    for g in G.values():
+                        g.zero_()
+                    dH = lib.gemm_rows_longk(dlog, model.embed_T)
+                    dxr = eng.final_norm_bwd(pre_ln, dH)
+                    dx = torch.zeros_like(x_fin)
+                    dx.index_copy_(0, idx.long(), dxr)
+                    _, dx0 = eng.decoder_backward(ps, save, dx, set(), grads=None)
+                    d_img = lib.gather_rows(dx0, img_rows)             # [B * Q, d]: every sample of the chunk shows the same image rows
+                    if B > 1:
+                        d_img = d_img.view(B, Q, -1).sum(0).contiguous()
+                    eng.qformer_backward(save_q, d_img, G)
+                    t_adam += 1
+                    for n, p_ in params.items():
+                        if cfg.weight_decay:
+                            p_.data.mul_(1.0 - cfg.lr * cfg.weight_decay)
+                        lib.adam_step_(p_.data.reshape(-1), G[n].reshape(-1), mom[n].reshape(-1), var[n].reshape(-1), cfg.lr, t_adam)
+                        model.mark_dirty(n)
+                if clamp is not None:
+                    for n, p_ in params.items():
+                        p_.data.copy_(torch.max(torch.min(p_.data, w0[n] + clamp), w0[n] - clamp))
+                        model.mark_dirty(n)
+            if loss_sum / cnt < LOSS_FLOOR:
+                break
+        deltas = {}
+        for n, p_ in params.items():
+            deltas[n] = (p_.data - w0[n])
+            p_.data.copy_(w0[n])
+            model.mark_dirty(n)
+        model.refresh_shadows()
+        eng.__dict__.pop("_wt_cache", None)
+        self._image_path_written()
+        return deltas
+
     def _execute_ft_general(self, requests, names):
         vllm, eng, model, cfg = self.vllm, self.vllm.engine, self.vllm.model, self.cfg
         dev = eng.dev
+        if all(n.startswith("qformer.") for n in names):
+            return self._execute_ft_qformer(requests, names)
         lo, plan = self._general_plan(names)
         n_layers = eng.t["num_hidden_layers"]
         params = {n: nethook.get_parameter(model, n) for n in names}          # fp32 masters (promote_to_fp32 in __init__)

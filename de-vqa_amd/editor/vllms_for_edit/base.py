@@ -130,6 +130,14 @@ class BaseVLLMForEdit(ABC):
             return ("px", img.data_ptr(), img._version, tuple(img.shape))
         return None
 
+    def invalidate_image_features(self):
+        """Drop the cached image features and the watch list behind them: an editor wrote a parameter of the image path through a raw
+        pointer (torch's version counters do not see HIP kernels) or replaced Parameter objects (promote_to_fp32)."""
+        self.__dict__.get("_img_feat_cache", {}).clear()
+        self.__dict__.get("_img_feat_pins", {}).clear()
+        self.__dict__["_img_feat_watched"] = None
+        self.__dict__["_img_feat_stamp"] = None
+
     def image_features(self, imgs):
         """[len(imgs), n_img, d] fp32 features of images given as paths / PIL / arrays.  An image addressed by PATH is
         encoded once and kept (160-entry LRU) for as long as no parameter outside the language model changes: the

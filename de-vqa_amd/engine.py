@@ -149,7 +149,14 @@ class Blip2Engine:
         ctx = self.path_ctx()
         if ctx is not None:
             return ctx.vision_encode(pixels.contiguous())
-        m, v, q = self.m, self.v, self.q
+        img, B = self.vit_rows(pixels)
+        return self.qformer_rows(img, B)
+
+    @torch.no_grad()
+    def vit_rows(self, pixels):
+        """K2-K3 in Python-ordered launches: pixel_values fp32 [B,3,S,S] -> (post-LayerNorm ViT rows [B*N, D] in the operand dtype -- the keys /
+        values of every Q-Former cross-attention --, B)"""
+        m, v = self.m, self.v
         m.refresh_derived()
         B = pixels.shape[0]
         P, D = v["patch_size"], v["hidden_size"]
@@ -173,9 +180,15 @@ class Blip2Engine:
             h = self._ln(x, p + "layer_norm2.weight", p + "layer_norm2.bias", eps)
             f = lib.gemm(h, self._w(p + "mlp.fc1.weight"), self._p(p + "mlp.fc1.bias"), act=lib.ACT_GELU)
             lib.gemm(f, self._w(p + "mlp.fc2.weight"), self._p(p + "mlp.fc2.bias"), residual=x, out_f32=x)
-        img = self._ln(x, "vision_model.post_layernorm.weight", "vision_model.post_layernorm.bias", eps)
-        # [B*N, D] in the operand dtype: keys/values of every cross-attention
-        # ---- Q-Former ----
+        return self._ln(x, "vision_model.post_layernorm.weight", "vision_model.post_layernorm.bias", eps), B
+
+    @torch.no_grad()
+    def qformer_rows(self, img, B, save=None):
+        """K4-K5: ViT rows -> language_projection(Q-Former(queries, img)) fp32 [B, Q, d_llm].  save: a dict that receives what
+        qformer_backward needs (FT_VL on Q-Former parameters): per block its input rows, q / k / v, attention output, the dense output in front of
+        each post-LayerNorm, the FFN's fp32 pre-activations."""
+        q = self.q
+        N = (self.v["image_size"] // self.v["patch_size"]) ** 2 + 1
         dq = q["hidden_size"]
         Hq = q["num_attention_heads"]
         dhq = dq // Hq
@@ -187,22 +200,34 @@ class Blip2Engine:
         h32 = h32.repeat(B, 1)  # [B*Q, dq] (plumbing: the learned queries are shared by every image)
         self_desc = self._full_desc(B, Qn, Qn, self_rows=True)
         cross_desc = self._full_desc(B, Qn, N)
+        if save is not None:
+            save.update(B=B, N=N, img=img, self_desc=self_desc, cross_desc=cross_desc, layers=[])
         for i in range(q["num_hidden_layers"]):
             p = "qformer.encoder.layer.%d." % i
-            h32 = self._bert_attention(p + "attention.", h32, None, self_desc, B, Qn, Hq, dhq, qeps)
+            rec = {} if save is not None else None
+            h32 = self._bert_attention(p + "attention.", h32, None, self_desc, B, Qn, Hq, dhq, qeps, rec, "self")
             if i % q["cross_attention_frequency"] == 0:
-                h32 = self._bert_attention(p + "crossattention.", h32, img, cross_desc, B, Qn, Hq, dhq, qeps)
+                h32 = self._bert_attention(p + "crossattention.", h32, img, cross_desc, B, Qn, Hq, dhq, qeps, rec, "cross")
             hb = self._act(h32)
-            f = lib.gemm(hb, self._w(p + "intermediate_query.dense.weight"), self._p(p + "intermediate_query.dense.bias"),
-                         act=lib.ACT_GELU)
+            if rec is None:
+                f = lib.gemm(hb, self._w(p + "intermediate_query.dense.weight"), self._p(p + "intermediate_query.dense.bias"),
+                             act=lib.ACT_GELU)
+            else:       # the pre-activations are kept: GEMM to fp32, GELU as a pass of its own
+                f_pre = lib.gemm(hb, self._w(p + "intermediate_query.dense.weight"), self._p(p + "intermediate_query.dense.bias"), want="f32")
+                f = lib.gelu(f_pre, want=self.want)
             o = lib.gemm(f, self._w(p + "output_query.dense.weight"), self._p(p + "output_query.dense.bias"), want="f32")
+            if rec is not None:
+                rec["ffn"] = dict(h_in=h32, hb=hb, f_pre=f_pre, f=f, o=o)
+                save["layers"].append(rec)
             h32 = lib.layernorm(o, self._p(p + "output_query.LayerNorm.weight"), self._p(p + "output_query.LayerNorm.bias"),
                                 qeps, add=h32, want="f32")
         hb = self._act(h32)
+        if save is not None:
+            save["h_last"] = hb
         out = lib.gemm(hb, self._w("language_projection.weight"), self._p("language_projection.bias"), want="f32")
         return out.view(B, Qn, -1)
 
-    def _bert_attention(self, p, h32, kv_bf16, desc, B, Qn, H, dh, eps):
+    def _bert_attention(self, p, h32, kv_bf16, desc, B, Qn, H, dh, eps, rec=None, tag=None):
         hb = self._act(h32)
         src = hb if kv_bf16 is None else kv_bf16
         qq = lib.gemm(hb, self._w(p + "attention.query.weight"), self._p(p + "attention.query.bias"))
@@ -210,8 +235,71 @@ class Blip2Engine:
         vv = lib.gemm(src, self._w(p + "attention.value.weight"), self._p(p + "attention.value.bias"))
         att = lib.attention(qq, kk, vv, desc, B, Qn, H, dh, dh ** -0.5, 0)
         o = lib.gemm(att, self._w(p + "output.dense.weight"), self._p(p + "output.dense.bias"), want="f32")
+        if rec is not None:
+            rec[tag] = dict(h_in=h32, hb=hb, q=qq, k=kk, v=vv, att=att, o=o)
         return lib.layernorm(o, self._p(p + "output.LayerNorm.weight"), self._p(p + "output.LayerNorm.bias"), eps,
                              add=h32, want="f32")
+
+    # ---- FT_VL on Q-Former parameters (the substring rule with "qformer": R/editor/vllm_editors/ft_vl/ft_vl.py:31-36, R/configs/ft_vl/blip2-opt-2.7b.yaml:9) ----
+    def qformer_train_params(self):
+        """{name: fp32 storage} of every Q-Former parameter (what the autograd of transformers' Blip2QFormerModel reaches from the image rows)"""
+        return {"qformer." + n: p_.data for n, p_ in self.m.qformer.named_parameters()}
+
+    @torch.no_grad()
+    def qformer_backward(self, save, d_out, grads):
+        """d_out fp32 [B*Q, d_llm]: gradient w.r.t. the projected query rows (qformer_rows' output).  Accumulates into grads[name] (fp32, every
+        Q-Former parameter: attention / cross-attention projections, FFN, every LayerNorm incl. the one on the learned queries); the
+        language projection, the learned queries and the ViT are frozen (their names do not contain "qformer").  Gradient rows are kept in
+        fp32, GEMM operands rounded to the compute dtype -- the convention of decoder_backward."""
+        q = self.q
+        B, N, img = save["B"], save["N"], save["img"]
+        dq_ = q["hidden_size"]
+        Hq = q["num_attention_heads"]
+        dhq = dq_ // Hq
+        eps = q["layer_norm_eps"]
+        Qn = self.Q
+        scale = dhq ** -0.5
+        dh = lib.gemm(self._act(d_out), self._wt("language_projection", lambda: self._w("language_projection.weight")), want="f32")
+        # the backward kernels read a sequence's keys from the OWN-key fields of the descriptor (the forward's cross form names them as a visible prefix)
+        cross_desc = lib.h2d([[b * Qn, Qn, 0, 0, b * N, N] for b in range(B)], torch.int32, self.dev)
+
+        def post_ln_bwd(pfx, o, h_in, dy):
+            """backward of LayerNorm(o + h_in): parameter gradients, -> gradient w.r.t. the sum (= w.r.t. o and w.r.t. h_in)"""
+            lib.layernorm_bwd_params(o, dy, eps, grads[pfx + "LayerNorm.weight"], grads[pfx + "LayerNorm.bias"], add=h_in)
+            return lib.layernorm_bwd_dx(o, self._p(pfx + "LayerNorm.weight"), dy, eps, add=h_in)
+
+        def attention_bwd(p, r, dy, desc, kv_rows, max_len):
+            """p: '...attention.' / '...crossattention.'; dy: gradient w.r.t. the block's output -> gradient w.r.t. its input rows"""
+            dsum = post_ln_bwd(p + "output.", r["o"], r["h_in"], dy)
+            self.acc_linear_grads(grads, p + "output.dense.weight", p + "output.dense.bias", r["att"], dsum)
+            datt = lib.gemm(self._act(dsum), self._wt(p + "output.dense", lambda: self._w(p + "output.dense.weight")))
+            gq, gk, gv = lib.attention_bwd(r["q"], r["k"], r["v"], r["att"], datt, desc, B, max_len, Hq, dhq, scale, 0)
+            self.acc_linear_grads(grads, p + "attention.query.weight", p + "attention.query.bias", r["hb"], gq)
+            self.acc_linear_grads(grads, p + "attention.key.weight", p + "attention.key.bias", kv_rows, gk)
+            self.acc_linear_grads(grads, p + "attention.value.weight", p + "attention.value.bias", kv_rows, gv)
+            d_in = lib.gemm(gq, self._wt(p + "attention.query", lambda: self._w(p + "attention.query.weight")), residual=dsum, want="f32")
+            if kv_rows is r["hb"]:      # self-attention: keys and values come from the same rows
+                d_in = lib.gemm(gk, self._wt(p + "attention.key", lambda: self._w(p + "attention.key.weight")), residual=d_in, want="f32")
+                d_in = lib.gemm(gv, self._wt(p + "attention.value", lambda: self._w(p + "attention.value.weight")), residual=d_in, want="f32")
+            return d_in
+        for i in range(q["num_hidden_layers"] - 1, -1, -1):
+            p = "qformer.encoder.layer.%d." % i
+            rec = save["layers"][i]
+            f = rec["ffn"]
+            dsum = post_ln_bwd(p + "output_query.", f["o"], f["h_in"], dh)
+            self.acc_linear_grads(grads, p + "output_query.dense.weight", p + "output_query.dense.bias", f["f"], dsum)
+            df = lib.gemm(self._act(dsum), self._wt(p + "output_query.dense", lambda: self._w(p + "output_query.dense.weight")), want="f32")
+            dpre = lib.gelu_bwd(f["f_pre"], df)
+            self.acc_linear_grads(grads, p + "intermediate_query.dense.weight", p + "intermediate_query.dense.bias", f["hb"], dpre)
+            dh = lib.gemm(self._act(dpre), self._wt(p + "intermediate_query.dense", lambda: self._w(p + "intermediate_query.dense.weight")),
+                          residual=dsum, want="f32")
+            if "cross" in rec:
+                dh = attention_bwd(p + "crossattention.", rec["cross"], dh, cross_desc, img, max(Qn, N))
+            dh = attention_bwd(p + "attention.", rec["self"], dh, save["self_desc"], rec["self"]["hb"], Qn)
+        # LayerNorm on the learned queries: the same [Q, d] rows for every image of the batch
+        d0 = dh.view(B, Qn, dq_).sum(0).contiguous() if B > 1 else dh
+        qt = self._p("query_tokens").reshape(Qn, dq_).contiguous()
+        lib.layernorm_bwd_params(qt, d0, eps, grads["qformer.layernorm.weight"], grads["qformer.layernorm.bias"])
 
     # ------------------------------------------------------------------------------------------
     # K6: decoder input rows

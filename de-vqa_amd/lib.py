@@ -89,6 +89,8 @@ def load():
         _sig(fn, [P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, P])
     _sig(L.devqa_relu_bwd, [P, P, P, I64, P])
     _sig(L.devqa_relu_bwd_f32, [P, P, P, I64, P])
+    _sig(L.devqa_gelu_f32, [P, P, P, I64, P])
+    _sig(L.devqa_gelu_bwd_f32, [P, P, P, I64, P])
     _sig(L.devqa_mend_normalize_concat, [P, P, P, P, P, P, P, F, I, I, I, P, P])
     _sig(L.devqa_mend_lrlinear_epilogue, [P, P, P, P, P, P, I, I, P])
     _sig(L.devqa_logit_kl_rows, [P, I64, P, I64, I, I, P, P])
@@ -150,7 +152,7 @@ EXPORTS = ["devqa_ctx_create", "devqa_ctx_destroy", "devqa_ctx_set_weight", "dev
            "devqa_im2col_patches", "devqa_vit_assemble", "devqa_embed_rows", "devqa_gather_rows", "devqa_cast_f32_bf16", "devqa_split_f32_bf16x2", "devqa_gemm_bf16_swiglu_supported",
            "devqa_vocab_rows", "devqa_layernorm_bwd_dx", "devqa_layernorm_bwd_params", "devqa_colsum_f32", "devqa_ft_adamw_step", "devqa_ft_adamw_step_fm", "devqa_rows_matvec_f32", "devqa_delta_op",
            "devqa_ft_step_control", "devqa_cosine_topk_workspace", "devqa_cosine_topk", "devqa_attention_bwd",
-           "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_mend_normalize_concat",
+           "devqa_attention_bwd_f32", "devqa_relu_bwd", "devqa_relu_bwd_f32", "devqa_gelu_f32", "devqa_gelu_bwd_f32", "devqa_mend_normalize_concat",
            "devqa_mend_lrlinear_epilogue", "devqa_logit_kl_rows", "devqa_kl_dlogits", "devqa_welford_rows",
            "devqa_mend_lrlinear_bwd", "devqa_sumsq_f32", "devqa_adam_step", "devqa_tp_neuron_fwd", "devqa_tp_neuron_bwd",
            "devqa_tp_gated_neuron_fwd", "devqa_tp_gated_neuron_bwd",
@@ -681,7 +683,8 @@ def attention_bwd(q, k, v, o, d_out, seq_desc, n_seq, max_len, H, dh, scale, cau
         assert t.dtype == q.dtype and t.is_cuda and t.dim() == 2 and t.stride(1) == 1
     assert q.dtype in (torch.bfloat16, torch.float32)
     R = q.shape[0]
-    dq, dk, dv = (torch.zeros((R, H * dh), dtype=q.dtype, device=q.device) for _ in range(3))
+    dq = torch.zeros((R, H * dh), dtype=q.dtype, device=q.device)
+    dk, dv = (torch.zeros((k.shape[0], H * dh), dtype=q.dtype, device=q.device) for _ in range(2))     # (cross-attention: keys are other rows)
     stats = torch.empty((R * H * 2,), dtype=torch.float32, device=q.device)
     fn = load().devqa_attention_bwd if q.dtype == torch.bfloat16 else load().devqa_attention_bwd_f32
     _chk(fn(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0), _p(d_out), d_out.stride(0),
@@ -695,6 +698,24 @@ def relu_bwd(act_out, grad_out):
     out = torch.empty_like(grad_out)
     fn = load().devqa_relu_bwd if act_out.dtype == torch.bfloat16 else load().devqa_relu_bwd_f32
     _chk(fn(_p(act_out), _p(grad_out), _p(out), act_out.numel(), _stream()), "devqa_relu_bwd")
+    return out
+
+
+def gelu(x, want="bf16"):
+    """HF "gelu" of fp32 pre-activations (kept by the caller for gelu_bwd) -> operand dtype"""
+    _need(x, torch.float32, "gelu x")
+    ob = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want == "bf16" else None
+    of = torch.empty_like(x) if want == "f32" else None
+    _chk(load().devqa_gelu_f32(_p(x), _p(ob), _p(of), x.numel(), _stream()), "devqa_gelu_f32")
+    return ob if ob is not None else of
+
+
+def gelu_bwd(x, grad_out):
+    _need(x, torch.float32, "gelu_bwd x")
+    _need(grad_out, torch.float32, "gelu_bwd grad_out")
+    assert x.shape == grad_out.shape
+    out = torch.empty_like(x)
+    _chk(load().devqa_gelu_bwd_f32(_p(x), _p(grad_out), _p(out), x.numel(), _stream()), "devqa_gelu_bwd_f32")
     return out
 
 

@@ -183,6 +183,10 @@ int devqa_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t
 
 /* ---- MEND_VL row-wise pieces --------------------------------------------------------------------
  * relu_bwd: grad_in = grad_out where act_out > 0 else 0 -- the hooked fc1 output gradient (mend_vl.py:68-71).
+ * gelu_f32 / gelu_bwd_f32: HF "gelu" (x * 0.5 * (1 + erf(x / sqrt 2))) of fp32 pre-activations that a backward pass keeps (out_bf16 and / or out_f32)
+ *   and grad_in = grad_out * (Phi(x) + x phi(x)): the Q-Former FFN when FT_VL's substring rule selects Q-Former parameters
+ *   (R/editor/vllm_editors/ft_vl/ft_vl.py:31-36 with the template "qformer", R/configs/ft_vl/blip2-opt-2.7b.yaml:9; autograd of
+ *   transformers' Blip2QFormerIntermediate there).
  * mend_normalize_concat: out[r] = [(u[idx[r]] - u_mean)/(u_std + eps) | (v[idx[r]] - v_mean)/(v_std + eps)]  fp32
  *   [n_rows, du+dv]; idx NULL = identity, mean/std NULL = no normalisation (auxiliary_networks.py:118-148; the caller
  *   builds idx from the nz_mask rule of :118-120).
@@ -191,6 +195,8 @@ int devqa_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t
  */
 int devqa_relu_bwd(const devqa_bf16* act_out, const devqa_bf16* grad_out, devqa_bf16* grad_in, int64_t n, void* stream);
 int devqa_relu_bwd_f32(const float* act_out, const float* grad_out, float* grad_in, int64_t n, void* stream);
+int devqa_gelu_f32(const float* x, devqa_bf16* out_bf16, float* out_f32, int64_t n, void* stream);
+int devqa_gelu_bwd_f32(const float* x, const float* grad_out, float* grad_in, int64_t n, void* stream);
 int devqa_mend_normalize_concat(const float* u, const float* v, const int32_t* idx, const float* u_mean, const float* u_std,
                                 const float* v_mean, const float* v_std, float eps, int n_rows, int du, int dv, float* out,
                                 void* stream);

@@ -1,6 +1,7 @@
 """GPU: FT_VL on edit targets OTHER than the last layer's fc2 matrix (the GENERAL form of editor/vllm_editors/ft_vl/ft_vl.py) against the
 REFERENCE's own FTvl.execute_ft on the same selections (tools/make_goldens_ft_general.py): fc1 of two layers; a q_proj weight + bias (a
-row block of the fused q|k|v operand here); six tensors of one layer incl. a LayerNorm.  Per-step losses, step counts, every delta; then the
+row block of the fused q|k|v operand here); six tensors of one layer incl. a LayerNorm; every Q-Former parameter (the template "qformer" of the
+reference's yaml comment: gradients through the whole decoder, the language projection, cross- and self-attention, GELU FFN, post-LayerNorms).  Per-step losses, step counts, every delta; then the
 plugin contract: edit_one_piece adds the deltas in place, restore_to_original_model brings every tensor (and the GEMM operands) back."""
 import json
 import os
@@ -44,6 +45,11 @@ def test_ft_general_targets_vs_reference(gold_dir, in_gold_dir, mode):
                 gold = z["%s_%d_%s" % (case["tag"], rq["record"], name)]
                 got = deltas[name].float().cpu().numpy()
                 assert got.shape == gold.shape
+                if name.endswith("attention.key.bias"):
+                    # softmax does not see a constant added to every key: the exact gradient of a key bias is ZERO, what autograd and the HIP
+                    # backward compute is rounding noise, and Adam turns noise of any size into steps of ~lr -- nothing to compare but the bound
+                    assert np.abs(got).max() <= 1.001 * 1e-3 * 25 and np.abs(gold).max() <= 1.001 * 1e-3 * 25
+                    continue
                 rel = float(np.linalg.norm(got - gold) / max(np.linalg.norm(gold), 1e-30))
                 worst = max(worst, rel)
                 if tol["delta"] is not None:
@@ -57,9 +63,16 @@ def test_ft_general_targets_vs_reference(gold_dir, in_gold_dir, mode):
                 assert n == rq["steps"]
             # execute_ft leaves the model pristine
             assert torch.equal(vllm.get_llm_outpt(x, vt).logits, base)
-        # plugin contract: the edit is applied in place and restored
+            (x_, vt_), _, _ = vllm.prompts_imgs_target_to_xym([r0["prompt"]], [r0["image"]], [r0["target_new"]])
+            assert torch.equal(x_["inputs_embeds"], x["inputs_embeds"])
+        # plugin contract: the edit is applied in place and restored (inputs rebuilt: a Q-Former edit changes the image rows themselves,
+        # and the wrapper's image-feature cache must not serve the pre-edit ones)
+        def logits_now():
+            (x_, vt_), _, _ = vllm.prompts_imgs_target_to_xym([r0["prompt"]], [r0["image"]], [r0["target_new"]])
+            return vllm.get_llm_outpt(x_, vt_).logits
+        assert torch.equal(logits_now(), base)
         ed.edit_one_piece(deepcopy(case["requests"][0]["request"]))
-        edited = vllm.get_llm_outpt(x, vt).logits
+        edited = logits_now()
         assert float((edited - base).abs().max()) > 1e-3 * float(base.abs().max())
         ed.restore_to_original_model()
-        assert torch.equal(vllm.get_llm_outpt(x, vt).logits, base)
+        assert torch.equal(logits_now(), base)

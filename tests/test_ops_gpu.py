@@ -691,3 +691,55 @@ def test_gemm_fused_swiglu(L, M, F, K):
     assert e_f < 8e-3 * scale and e_f <= e_t * 1.05
     np.testing.assert_allclose(fused.float().cpu().numpy(), two.float().cpu().numpy(), atol=2e-2 * scale, rtol=2e-2)
 
+
+
+def test_gelu_forward_and_backward(L):
+    """devqa_gelu_f32 / devqa_gelu_bwd_f32 (the Q-Former FFN under FT_VL's Q-Former selection) against torch's erf GELU and its autograd"""
+    torch.manual_seed(11)
+    x = (torch.randn(77, 130, device="cuda") * 2.5).contiguous()
+    g = torch.randn_like(x)
+    xr = x.double().requires_grad_(True)
+    yr = torch.nn.functional.gelu(xr)
+    yr.backward(g.double())
+    assert (L.gelu(x, want="f32").double() - yr.detach()).abs().max().item() < 2e-6
+    assert torch.equal(L.gelu(x, want="bf16"), L.gelu(x, want="f32").to(torch.bfloat16))
+    assert (L.gelu_bwd(x, g).double() - xr.grad).abs().max().item() < 5e-6
+
+
+@pytest.mark.parametrize("kind", ["self_causal", "self_full", "cross"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_bwd_vs_autograd(L, kind, dtype):
+    """dq / dk / dv of the packed attention against float64 autograd: causal own keys (the decoders), full own keys and CROSS attention --
+    32 queries over 70 keys of another row set, named through the descriptor's own-key fields (the Q-Former's cross-attention under
+    FT_VL's Q-Former selection)."""
+    torch.manual_seed(5)
+    H, dh = 3, 16
+    d = H * dh
+    if kind == "cross":
+        qn, kn = [32, 32], [70, 70]
+    else:
+        qn = kn = [37, 5, 64]
+    q = torch.randn(sum(qn), d, device="cuda")
+    k = torch.randn(sum(kn), d, device="cuda")
+    v = torch.randn(sum(kn), d, device="cuda")
+    go = torch.randn(sum(qn), d, device="cuda")
+    qs, ks = np.cumsum([0] + qn[:-1]).tolist(), np.cumsum([0] + kn[:-1]).tolist()
+    desc_b = torch.tensor([[a, n, 0, 0, b, m] for a, n, b, m in zip(qs, qn, ks, kn)], dtype=torch.int32, device="cuda")
+    causal = int(kind == "self_causal")
+    qc, kc, vc, gc = (t.to(dtype).contiguous() for t in (q, k, v, go))
+    refs = [t.to(dtype).double().requires_grad_(True) for t in (q, k, v)]
+    outs = []
+    for a, n, b, m in zip(qs, qn, ks, kn):
+        qq, kk, vv = (t[s:s + ln].view(ln, H, dh).transpose(0, 1) for t, s, ln in ((refs[0], a, n), (refs[1], b, m), (refs[2], b, m)))
+        sc = qq @ kk.transpose(1, 2) * dh ** -0.5
+        if causal:
+            sc = sc + torch.full((n, m), float("-inf"), device="cuda", dtype=torch.float64).triu(1)
+        outs.append((torch.softmax(sc, -1) @ vv).transpose(0, 1).reshape(n, d))
+    o = torch.cat(outs, 0)
+    o.backward(gc.double())
+    dq, dk, dv = L.attention_bwd(qc, kc, vc, o.detach().to(dtype).contiguous(), gc, desc_b, len(qn), max(max(qn), max(kn)), H, dh, dh ** -0.5, causal)
+    assert dk.shape == k.shape and dv.shape == v.shape
+    tol = 2e-5 if dtype == torch.float32 else 6e-2
+    for got, ref in zip((dq, dk, dv), refs):
+        err = (got.double() - ref.grad).abs().max().item() / max(ref.grad.abs().max().item(), 1e-9)
+        assert err < tol, (kind, dtype, err)

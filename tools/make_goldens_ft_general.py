@@ -5,6 +5,8 @@ name contains rewrite_module_tmp.format(layer) for a layer of `layers`), on the 
   A  fc1.weight of decoder layers 0 and 1
   B  "self_attn.q_proj" of layer 1 (weight AND bias: a row block of the fused q|k|v operand on the HIP side)
   C  "final_layer_norm" + "fc2" of layer 0 via the template "layers.{}.f" (fc1, fc2, final_layer_norm: weights and biases)
+  D  "qformer" -- the alternative the reference's own yaml carries as a comment (R/configs/ft_vl/blip2-opt-2.7b.yaml:9): every Q-Former
+     parameter (self- and cross-attention, query FFN, every LayerNorm), gradients through the whole decoder and the language projection
 Stores per case and request: per-step losses, step count, the delta of every selected parameter.  DATA only."""
 import json
 import os
@@ -18,7 +20,8 @@ import torch  # noqa: E402
 
 CASES = [("A", "language_model.model.decoder.layers.{}.fc1.weight", [0, 1]),
          ("B", "language_model.model.decoder.layers.{}.self_attn.q_proj", [1]),
-         ("C", "language_model.model.decoder.layers.{}.f", [0])]
+         ("C", "language_model.model.decoder.layers.{}.f", [0]),
+         ("D", "qformer", [0])]
 
 
 def main():
