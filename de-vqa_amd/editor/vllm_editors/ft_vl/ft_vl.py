@@ -22,12 +22,13 @@ Two execution forms behind the same `execute_ft`:
     (engine.decoder_backward(grads=...), the machinery of LTE_VL's training) and one Adam(W) step per selected tensor
     (devqa_adam_step) on its fp32 master.  Pinned by the reference's own FTvl on three such selections
     (tools/make_goldens_ft_general.py, tests/test_ft_general_gpu.py).
-  * Q-FORMER (round 3): every selected name is a Q-Former parameter -- the template "qformer" that R/configs/ft_vl/blip2-opt-2.7b.yaml:9 carries as a
-    comment.  Per step the Q-Former runs with saved activations on the frozen ViT rows, all decoder layers run with saved activations, and the
-    gradient returns through the decoder's inputs, the language projection and the Q-Former (engine.qformer_backward: cross- and
-    self-attention, GELU FFN, post-LayerNorms) into one Adam(W) step per tensor.  Pinned by the reference's own FTvl (case D of the same goldens).
-Targets in the vision tower, the embeddings, the final norm, the language projection or the learned queries would need a backward pass
-through those parts and raise NotImplementedError; so does a selection mixing Q-Former and decoder parameters.
+  * IMAGE PATH (round 3, BLIP-2): every selected name is a Q-Former parameter -- the template "qformer" that R/configs/ft_vl/blip2-opt-2.7b.yaml:9
+    carries as a comment -- or a ViT encoder-layer / post-LayerNorm parameter.  Per step the trained part of the image path runs with saved
+    activations, all decoder layers run with saved activations, and the gradient returns through the decoder's inputs, the language projection,
+    the Q-Former (engine.qformer_backward: cross- and self-attention, GELU FFN, post-LayerNorms) and, for a vision selection, the ViT
+    (engine.vit_backward) into one Adam(W) step per tensor.  Pinned by the reference's own FTvl (cases D, E, F of the same goldens).
+The ViT's patch / class / position embeddings, the LM's embeddings and final norm, the language projection and the learned queries have no
+gradient path here and raise NotImplementedError; so does a selection mixing image-path and decoder parameters.
 """
 import os
 from copy import deepcopy
@@ -180,20 +181,29 @@ class FTvl(VLLMBaseEditor):
             lo = layer if lo is None else min(lo, layer)
         return lo, plan
 
-    def _execute_ft_qformer(self, requests, names):
-        """Every selected name is a Q-Former parameter (the template "qformer" the reference's yaml carries as a comment): per step the Q-Former
-        runs with saved activations on the frozen ViT rows, its projected query rows take their place in front of the text embeddings, ALL
-        decoder layers run with saved activations, and the gradient of the label rows' NLL comes back through the decoder
-        (engine.decoder_backward, inputs only), the language projection and the Q-Former (engine.qformer_backward) into one Adam(W) step per
-        tensor.  As in the reference's wrapper the LAST image of a chunk serves the whole chunk (blip2.py:54-55)."""
+    def _execute_ft_image_path(self, requests, names):
+        """Every selected name is a Q-Former parameter (the template "qformer" the reference's yaml carries as a comment) or a ViT encoder-layer /
+        post-LayerNorm parameter: per step the trained part of the image path runs with saved activations (ViT layers from the lowest selected
+        one on the rows the frozen layers below it produced once; the Q-Former on the ViT rows), its projected query rows take their place in
+        front of the text embeddings, ALL decoder layers run with saved activations, and the gradient of the label rows' NLL comes back
+        through the decoder (engine.decoder_backward, inputs only), the language projection, the Q-Former (engine.qformer_backward) and --
+        for a vision selection -- the cross-attention keys / values into the ViT (engine.vit_backward), into one Adam(W) step per tensor.
+        As in the reference's wrapper the LAST image of a chunk serves the whole chunk (blip2.py:54-55)."""
+        import re
         vllm, eng, model, cfg = self.vllm, self.vllm.engine, self.vllm.model, self.cfg
         dev = eng.dev
         if not hasattr(eng, "qformer_backward"):
-            raise NotImplementedError("native FT_VL: this engine has no Q-Former backward")
-        tp = eng.qformer_train_params()
+            raise NotImplementedError("native FT_VL: this engine has no backward through the image path")
+        tq, tv = eng.qformer_train_params(), eng.vit_train_params()
         for n in names:
-            if n not in tp:
+            if n not in tq and n not in tv:
                 raise NotImplementedError("native FT_VL: no gradient path for %s" % n)
+        q_sel = any(n in tq for n in names)
+        v_sel = any(n in tv for n in names)
+        n_vit = eng.v["num_hidden_layers"]
+        lo_v = min([int(re.search(r"encoder\.layers\.(\d+)\.", n).group(1)) for n in names if n in tv and ".encoder.layers." in n] + [n_vit])
+        tp = dict(tq if q_sel else {}, **({k: t_ for k, t_ in tv.items() if ".encoder.layers." not in k or
+                                           int(k.split(".encoder.layers.")[1].split(".")[0]) >= lo_v} if v_sel else {}))
         n_layers, Q = eng.t["num_hidden_layers"], eng.Q
         params = {n: nethook.get_parameter(model, n) for n in names}
         w0 = {n: p_.detach().clone() for n, p_ in params.items()}
@@ -208,12 +218,16 @@ class FTvl(VLLMBaseEditor):
         prepared = []
         for c in chunks:
             if any(r["image"] is None for r in c):
-                raise NotImplementedError("native FT_VL on Q-Former parameters needs an image in every request")
+                raise NotImplementedError("native FT_VL on image-path parameters needs an image in every request")
             (x, vt), y, m = vllm.prompts_imgs_target_to_xym([r["prompt"] for r in c], [r["image"] for r in c], [r["target_new"] for r in c])
             emb, msk = x["inputs_embeds"].clone(), x["attention_mask"]
             last = c[-1]["image"]
             pix = last.to(dev, torch.float32)[None] if isinstance(last, torch.Tensor) else torch.from_numpy(vllm.load_pixels(last))[None].to(dev)
-            img, _ = eng.vit_rows(pix)                                 # the ViT is frozen: once per chunk
+            if v_sel:       # the layers below the lowest selected one are frozen: their rows once per chunk
+                x0, _ = eng.vit_embed(pix)
+                img = eng.vit_layers(x0, 1, 0, None, lo_v)
+            else:
+                img, _ = eng.vit_rows(pix)                             # the whole ViT is frozen
             B, T = emb.shape[:2]
             L = y.shape[1]
             mh, yh = VLLM_HOST(m), VLLM_HOST(y)
@@ -227,8 +241,12 @@ class FTvl(VLLMBaseEditor):
                 model.refresh_shadows()
                 eng.__dict__.pop("_wt_cache", None)
                 B = emb.shape[0]
-                save_q = {}
-                feats = eng.qformer_rows(img, 1, save_q)               # [1, Q, d_llm] under the current Q-Former
+                save_q, save_v = {}, {}
+                if v_sel:
+                    img_rows_now = eng.vit_post(eng.vit_layers(img.clone(), 1, lo_v, save_v))
+                else:
+                    img_rows_now = img
+                feats = eng.qformer_rows(img_rows_now, 1, save_q)      # [1, Q, d_llm] under the current image path
                 emb[:, :Q] = feats
                 ps = eng.pack_from_embeds(emb, msk)
                 save = {"layers": set(range(n_layers))}
@@ -252,7 +270,9 @@ class FTvl(VLLMBaseEditor):
                     d_img = lib.gather_rows(dx0, img_rows)             # [B * Q, d]: every sample of the chunk shows the same image rows
                     if B > 1:
                         d_img = d_img.view(B, Q, -1).sum(0).contiguous()
-                    eng.qformer_backward(save_q, d_img, G)
+                    d_vit = eng.qformer_backward(save_q, d_img, G if q_sel else None, want_d_img=v_sel)
+                    if v_sel:
+                        eng.vit_backward(save_v, d_vit, G)
                     t_adam += 1
                     for n, p_ in params.items():
                         if cfg.weight_decay:
@@ -278,8 +298,8 @@ class FTvl(VLLMBaseEditor):
     def _execute_ft_general(self, requests, names):
         vllm, eng, model, cfg = self.vllm, self.vllm.engine, self.vllm.model, self.cfg
         dev = eng.dev
-        if all(n.startswith("qformer.") for n in names):
-            return self._execute_ft_qformer(requests, names)
+        if all(n.startswith("qformer.") or n.startswith("vision_model.") for n in names):
+            return self._execute_ft_image_path(requests, names)
         lo, plan = self._general_plan(names)
         n_layers = eng.t["num_hidden_layers"]
         params = {n: nethook.get_parameter(model, n) for n in names}          # fp32 masters (promote_to_fp32 in __init__)

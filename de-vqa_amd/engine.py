@@ -156,31 +156,104 @@ class Blip2Engine:
     def vit_rows(self, pixels):
         """K2-K3 in Python-ordered launches: pixel_values fp32 [B,3,S,S] -> (post-LayerNorm ViT rows [B*N, D] in the operand dtype -- the keys /
         values of every Q-Former cross-attention --, B)"""
+        x, B = self.vit_embed(pixels)
+        return self.vit_post(self.vit_layers(x, B)), B
+
+    @torch.no_grad()
+    def vit_embed(self, pixels):
+        """patch embedding + class token + positions -> (fp32 residual stream [B*N, D], B)"""
         m, v = self.m, self.v
         m.refresh_derived()
         B = pixels.shape[0]
         P, D = v["patch_size"], v["hidden_size"]
         G = v["image_size"] // P
-        N = G * G + 1
-        H = v["num_attention_heads"]
-        dh = D // H
-        eps = v["layer_norm_eps"]
         cols = lib.im2col_patches(pixels.contiguous(), P, m.patch_kpad, self.adt)
         patches = lib.gemm(cols, m.patch_w_gemm, self._p("vision_model.embeddings.patch_embedding.bias"), want="f32")
         x = lib.vit_assemble(patches, self._p("vision_model.embeddings.class_embedding"),
                              self._p("vision_model.embeddings.position_embedding"), B, G * G, D)
+        return x, B
+
+    @torch.no_grad()
+    def vit_layers(self, x, B, first_layer=0, save=None, end_layer=None):
+        """encoder layers [first_layer, end_layer or all) in place on the fp32 residual stream x.  save: dict that receives what vit_backward
+        needs per layer"""
+        v = self.v
+        D = v["hidden_size"]
+        N = (v["image_size"] // v["patch_size"]) ** 2 + 1
+        H = v["num_attention_heads"]
+        dh = D // H
+        eps = v["layer_norm_eps"]
         desc = self._full_desc(B, N, N, self_rows=True)
-        for i in range(v["num_hidden_layers"]):
+        if save is not None:
+            save.update(B=B, N=N, desc=desc, first=first_layer, layers={})
+        for i in range(first_layer, v["num_hidden_layers"] if end_layer is None else end_layer):
             p = "vision_model.encoder.layers.%d." % i
+            rec = None
+            if save is not None:
+                rec = save["layers"][i] = {"x_in": x.clone()}
             h = self._ln(x, p + "layer_norm1.weight", p + "layer_norm1.bias", eps)
             qkv = lib.gemm(h, self._w(p + "self_attn.qkv.weight"), self._p(p + "self_attn.qkv.bias"))
             att = lib.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], desc, B, N, H, dh, dh ** -0.5, 0, self_full=True)
             lib.gemm(att, self._w(p + "self_attn.projection.weight"), self._p(p + "self_attn.projection.bias"),
                      residual=x, out_f32=x)
-            h = self._ln(x, p + "layer_norm2.weight", p + "layer_norm2.bias", eps)
-            f = lib.gemm(h, self._w(p + "mlp.fc1.weight"), self._p(p + "mlp.fc1.bias"), act=lib.ACT_GELU)
+            h2 = self._ln(x, p + "layer_norm2.weight", p + "layer_norm2.bias", eps)
+            if rec is None:
+                f = lib.gemm(h2, self._w(p + "mlp.fc1.weight"), self._p(p + "mlp.fc1.bias"), act=lib.ACT_GELU)
+            else:
+                f_pre = lib.gemm(h2, self._w(p + "mlp.fc1.weight"), self._p(p + "mlp.fc1.bias"), want="f32")
+                f = lib.gelu(f_pre, want=self.want)
+                rec.update(h1=h, qkv=qkv, att=att, x_mid=x.clone(), h2=h2, f_pre=f_pre, f=f)
             lib.gemm(f, self._w(p + "mlp.fc2.weight"), self._p(p + "mlp.fc2.bias"), residual=x, out_f32=x)
-        return self._ln(x, "vision_model.post_layernorm.weight", "vision_model.post_layernorm.bias", eps), B
+        if save is not None:
+            save["x_last"] = x.clone()
+        return x
+
+    def vit_post(self, x):
+        return self._ln(x, "vision_model.post_layernorm.weight", "vision_model.post_layernorm.bias", self.v["layer_norm_eps"])
+
+    def vit_train_params(self):
+        """{name: fp32 storage} of the ViT parameters vit_backward reaches: every encoder-layer parameter and the post-LayerNorm (the patch /
+        class / position embeddings are not: a selection naming them raises)"""
+        out = {}
+        for n, p_ in self.m.vision_model.named_parameters():
+            if n.startswith("encoder.layers.") or n.startswith("post_layernorm."):
+                out["vision_model." + n] = p_.data
+        return out
+
+    @torch.no_grad()
+    def vit_backward(self, save, d_img, grads):
+        """d_img fp32 [B*N, D]: gradient w.r.t. the post-LayerNorm ViT rows.  Accumulates into grads[name] for the encoder layers [save.first, end)
+        and the post-LayerNorm (FT_VL with a vision-tower selection); fp32 gradient rows, GEMM operands in the compute dtype."""
+        v = self.v
+        D = v["hidden_size"]
+        H = v["num_attention_heads"]
+        dhd = D // H
+        eps = v["layer_norm_eps"]
+        B, N, desc = save["B"], save["N"], save["desc"]
+        lib.layernorm_bwd_params(save["x_last"], d_img, eps, grads["vision_model.post_layernorm.weight"], grads["vision_model.post_layernorm.bias"])
+        dx = lib.layernorm_bwd_dx(save["x_last"], self._p("vision_model.post_layernorm.weight"), d_img, eps)
+        for i in sorted(save["layers"], reverse=True):
+            p = "vision_model.encoder.layers.%d." % i
+            r = save["layers"][i]
+            self.acc_linear_grads(grads, p + "mlp.fc2.weight", p + "mlp.fc2.bias", r["f"], dx)
+            df = lib.gemm(self._act(dx), self._wt(p + "mlp.fc2", lambda: self._w(p + "mlp.fc2.weight")), want="f32")
+            dpre = lib.gelu_bwd(r["f_pre"], df)
+            self.acc_linear_grads(grads, p + "mlp.fc1.weight", p + "mlp.fc1.bias", r["h2"], dpre)
+            dh2 = lib.gemm(self._act(dpre), self._wt(p + "mlp.fc1", lambda: self._w(p + "mlp.fc1.weight")), want="f32")
+            lib.layernorm_bwd_params(r["x_mid"], dh2, eps, grads[p + "layer_norm2.weight"], grads[p + "layer_norm2.bias"])
+            dmid = lib.layernorm_bwd_dx(r["x_mid"], self._p(p + "layer_norm2.weight"), dh2, eps)
+            lib.delta_op(1, dmid, None, dx)            # + the residual branch
+            self.acc_linear_grads(grads, p + "self_attn.projection.weight", p + "self_attn.projection.bias", r["att"], dmid)
+            datt = lib.gemm(self._act(dmid), self._wt(p + "self_attn.projection", lambda: self._w(p + "self_attn.projection.weight")))
+            qkv = r["qkv"]
+            gq, gk, gv = lib.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], r["att"], datt, desc, B, N, H, dhd, dhd ** -0.5, 0)
+            dqkv = torch.cat([gq, gk, gv], 1)
+            self.acc_linear_grads(grads, p + "self_attn.qkv.weight", p + "self_attn.qkv.bias", r["h1"], dqkv)
+            dh1 = lib.gemm(dqkv, self._wt(p + "self_attn.qkv", lambda: self._w(p + "self_attn.qkv.weight")), want="f32")
+            lib.layernorm_bwd_params(r["x_in"], dh1, eps, grads[p + "layer_norm1.weight"], grads[p + "layer_norm1.bias"])
+            dx = lib.layernorm_bwd_dx(r["x_in"], self._p(p + "layer_norm1.weight"), dh1, eps)
+            lib.delta_op(1, dx, None, dmid)
+        return dx
 
     @torch.no_grad()
     def qformer_rows(self, img, B, save=None):
@@ -246,11 +319,13 @@ class Blip2Engine:
         return {"qformer." + n: p_.data for n, p_ in self.m.qformer.named_parameters()}
 
     @torch.no_grad()
-    def qformer_backward(self, save, d_out, grads):
+    def qformer_backward(self, save, d_out, grads, want_d_img=False):
         """d_out fp32 [B*Q, d_llm]: gradient w.r.t. the projected query rows (qformer_rows' output).  Accumulates into grads[name] (fp32, every
-        Q-Former parameter: attention / cross-attention projections, FFN, every LayerNorm incl. the one on the learned queries); the
-        language projection, the learned queries and the ViT are frozen (their names do not contain "qformer").  Gradient rows are kept in
-        fp32, GEMM operands rounded to the compute dtype -- the convention of decoder_backward."""
+        Q-Former parameter: attention / cross-attention projections, FFN, every LayerNorm incl. the one on the learned queries; grads None:
+        the Q-Former is frozen, only gradient rows pass through); the language projection and the learned queries are always frozen.
+        want_d_img: also return the gradient w.r.t. the ViT rows [B*N, D_vit] (through the cross-attention keys and values) for a
+        vision-tower selection.  Gradient rows are kept in fp32, GEMM operands rounded to the compute dtype -- the convention of
+        decoder_backward."""
         q = self.q
         B, N, img = save["B"], save["N"], save["img"]
         dq_ = q["hidden_size"]
@@ -263,43 +338,58 @@ class Blip2Engine:
         # the backward kernels read a sequence's keys from the OWN-key fields of the descriptor (the forward's cross form names them as a visible prefix)
         cross_desc = lib.h2d([[b * Qn, Qn, 0, 0, b * N, N] for b in range(B)], torch.int32, self.dev)
 
+        d_img = None
+
+        def acc(wname, bname, x_rows, d_rows):
+            if grads is not None:
+                self.acc_linear_grads(grads, wname, bname, x_rows, d_rows)
+
         def post_ln_bwd(pfx, o, h_in, dy):
             """backward of LayerNorm(o + h_in): parameter gradients, -> gradient w.r.t. the sum (= w.r.t. o and w.r.t. h_in)"""
-            lib.layernorm_bwd_params(o, dy, eps, grads[pfx + "LayerNorm.weight"], grads[pfx + "LayerNorm.bias"], add=h_in)
+            if grads is not None:
+                lib.layernorm_bwd_params(o, dy, eps, grads[pfx + "LayerNorm.weight"], grads[pfx + "LayerNorm.bias"], add=h_in)
             return lib.layernorm_bwd_dx(o, self._p(pfx + "LayerNorm.weight"), dy, eps, add=h_in)
 
         def attention_bwd(p, r, dy, desc, kv_rows, max_len):
             """p: '...attention.' / '...crossattention.'; dy: gradient w.r.t. the block's output -> gradient w.r.t. its input rows"""
+            nonlocal d_img
             dsum = post_ln_bwd(p + "output.", r["o"], r["h_in"], dy)
-            self.acc_linear_grads(grads, p + "output.dense.weight", p + "output.dense.bias", r["att"], dsum)
+            acc(p + "output.dense.weight", p + "output.dense.bias", r["att"], dsum)
             datt = lib.gemm(self._act(dsum), self._wt(p + "output.dense", lambda: self._w(p + "output.dense.weight")))
             gq, gk, gv = lib.attention_bwd(r["q"], r["k"], r["v"], r["att"], datt, desc, B, max_len, Hq, dhq, scale, 0)
-            self.acc_linear_grads(grads, p + "attention.query.weight", p + "attention.query.bias", r["hb"], gq)
-            self.acc_linear_grads(grads, p + "attention.key.weight", p + "attention.key.bias", kv_rows, gk)
-            self.acc_linear_grads(grads, p + "attention.value.weight", p + "attention.value.bias", kv_rows, gv)
+            acc(p + "attention.query.weight", p + "attention.query.bias", r["hb"], gq)
+            acc(p + "attention.key.weight", p + "attention.key.bias", kv_rows, gk)
+            acc(p + "attention.value.weight", p + "attention.value.bias", kv_rows, gv)
             d_in = lib.gemm(gq, self._wt(p + "attention.query", lambda: self._w(p + "attention.query.weight")), residual=dsum, want="f32")
+            wk = self._wt(p + "attention.key", lambda: self._w(p + "attention.key.weight"))
+            wv = self._wt(p + "attention.value", lambda: self._w(p + "attention.value.weight"))
             if kv_rows is r["hb"]:      # self-attention: keys and values come from the same rows
-                d_in = lib.gemm(gk, self._wt(p + "attention.key", lambda: self._w(p + "attention.key.weight")), residual=d_in, want="f32")
-                d_in = lib.gemm(gv, self._wt(p + "attention.value", lambda: self._w(p + "attention.value.weight")), residual=d_in, want="f32")
+                d_in = lib.gemm(gk, wk, residual=d_in, want="f32")
+                d_in = lib.gemm(gv, wv, residual=d_in, want="f32")
+            elif want_d_img:            # cross-attention: keys and values are projections of the ViT rows
+                d_img = lib.gemm(gk, wk, residual=d_img, want="f32")
+                d_img = lib.gemm(gv, wv, residual=d_img, want="f32")
             return d_in
         for i in range(q["num_hidden_layers"] - 1, -1, -1):
             p = "qformer.encoder.layer.%d." % i
             rec = save["layers"][i]
             f = rec["ffn"]
             dsum = post_ln_bwd(p + "output_query.", f["o"], f["h_in"], dh)
-            self.acc_linear_grads(grads, p + "output_query.dense.weight", p + "output_query.dense.bias", f["f"], dsum)
+            acc(p + "output_query.dense.weight", p + "output_query.dense.bias", f["f"], dsum)
             df = lib.gemm(self._act(dsum), self._wt(p + "output_query.dense", lambda: self._w(p + "output_query.dense.weight")), want="f32")
             dpre = lib.gelu_bwd(f["f_pre"], df)
-            self.acc_linear_grads(grads, p + "intermediate_query.dense.weight", p + "intermediate_query.dense.bias", f["hb"], dpre)
+            acc(p + "intermediate_query.dense.weight", p + "intermediate_query.dense.bias", f["hb"], dpre)
             dh = lib.gemm(self._act(dpre), self._wt(p + "intermediate_query.dense", lambda: self._w(p + "intermediate_query.dense.weight")),
                           residual=dsum, want="f32")
             if "cross" in rec:
                 dh = attention_bwd(p + "crossattention.", rec["cross"], dh, cross_desc, img, max(Qn, N))
             dh = attention_bwd(p + "attention.", rec["self"], dh, save["self_desc"], rec["self"]["hb"], Qn)
         # LayerNorm on the learned queries: the same [Q, d] rows for every image of the batch
-        d0 = dh.view(B, Qn, dq_).sum(0).contiguous() if B > 1 else dh
-        qt = self._p("query_tokens").reshape(Qn, dq_).contiguous()
-        lib.layernorm_bwd_params(qt, d0, eps, grads["qformer.layernorm.weight"], grads["qformer.layernorm.bias"])
+        if grads is not None:
+            d0 = dh.view(B, Qn, dq_).sum(0).contiguous() if B > 1 else dh
+            qt = self._p("query_tokens").reshape(Qn, dq_).contiguous()
+            lib.layernorm_bwd_params(qt, d0, eps, grads["qformer.layernorm.weight"], grads["qformer.layernorm.bias"])
+        return d_img
 
     # ------------------------------------------------------------------------------------------
     # K6: decoder input rows

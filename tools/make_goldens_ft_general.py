@@ -7,6 +7,9 @@ name contains rewrite_module_tmp.format(layer) for a layer of `layers`), on the 
   C  "final_layer_norm" + "fc2" of layer 0 via the template "layers.{}.f" (fc1, fc2, final_layer_norm: weights and biases)
   D  "qformer" -- the alternative the reference's own yaml carries as a comment (R/configs/ft_vl/blip2-opt-2.7b.yaml:9): every Q-Former
      parameter (self- and cross-attention, query FFN, every LayerNorm), gradients through the whole decoder and the language projection
+  E  every parameter of ViT encoder layer 0 ("vision_model.encoder.layers.{}."): gradients additionally through the Q-Former's cross-attention
+     keys / values, the ViT's post-LayerNorm and both encoder layers
+  F  "post_layernorm" (the ViT's last LayerNorm alone: no encoder layer is trained)
 Stores per case and request: per-step losses, step count, the delta of every selected parameter.  DATA only."""
 import json
 import os
@@ -21,7 +24,9 @@ import torch  # noqa: E402
 CASES = [("A", "language_model.model.decoder.layers.{}.fc1.weight", [0, 1]),
          ("B", "language_model.model.decoder.layers.{}.self_attn.q_proj", [1]),
          ("C", "language_model.model.decoder.layers.{}.f", [0]),
-         ("D", "qformer", [0])]
+         ("D", "qformer", [0]),
+         ("E", "vision_model.encoder.layers.{}.", [0]),
+         ("F", "post_layernorm", [0])]
 
 
 def main():
