@@ -23,12 +23,13 @@ Two execution forms behind the same `execute_ft`:
     (devqa_adam_step) on its fp32 master.  Pinned by the reference's own FTvl on three such selections
     (tools/make_goldens_ft_general.py, tests/test_ft_general_gpu.py).
   * IMAGE PATH (round 3, BLIP-2): every selected name is a Q-Former parameter -- the template "qformer" that R/configs/ft_vl/blip2-opt-2.7b.yaml:9
-    carries as a comment -- or a ViT encoder-layer / post-LayerNorm parameter.  Per step the trained part of the image path runs with saved
+    carries as a comment --, the learned queries, the language projection or a vision-tower parameter (encoder layers, post-LayerNorm, patch
+    convolution, class / position embeddings).  Per step the trained part of the image path runs with saved
     activations, all decoder layers run with saved activations, and the gradient returns through the decoder's inputs, the language projection,
     the Q-Former (engine.qformer_backward: cross- and self-attention, GELU FFN, post-LayerNorms) and, for a vision selection, the ViT
-    (engine.vit_backward) into one Adam(W) step per tensor.  Pinned by the reference's own FTvl (cases D, E, F of the same goldens).
-The ViT's patch / class / position embeddings, the LM's embeddings and final norm, the language projection and the learned queries have no
-gradient path here and raise NotImplementedError; so does a selection mixing image-path and decoder parameters.
+    (engine.vit_backward, vit_embed_backward) into one Adam(W) step per tensor.  Pinned by the reference's own FTvl (cases D - I of the same goldens).
+The LM's token / position embeddings and final norm have no gradient path in this loop and raise NotImplementedError; so does a selection
+mixing image-path and decoder parameters.
 """
 import os
 from copy import deepcopy
@@ -88,8 +89,11 @@ class FTvl(VLLMBaseEditor):
         return any(not n.startswith(lm) for n in self.original_w)
 
     def _image_path_written(self):
-        if self._touches_image_path() and hasattr(self.vllm, "invalidate_image_features"):
-            self.vllm.invalidate_image_features()
+        if self._touches_image_path():
+            if any("patch_embedding" in n for n in self.original_w):
+                self.vllm.model.refresh_derived(force=True)      # the patch convolution's GEMM operand is a derived buffer
+            if hasattr(self.vllm, "invalidate_image_features"):
+                self.vllm.invalidate_image_features()
 
     def name_of_editor_and_model(self) -> Tuple[str, str]:
         return "ft_vl", self.cfg.edit_model_name
@@ -202,6 +206,9 @@ class FTvl(VLLMBaseEditor):
         v_sel = any(n in tv for n in names)
         n_vit = eng.v["num_hidden_layers"]
         lo_v = min([int(re.search(r"encoder\.layers\.(\d+)\.", n).group(1)) for n in names if n in tv and ".encoder.layers." in n] + [n_vit])
+        emb_sel = any(".embeddings." in n for n in names if n in tv)       # patch / class / position embeddings: the ViT runs from the pixels every step
+        if emb_sel:
+            lo_v = 0
         tp = dict(tq if q_sel else {}, **({k: t_ for k, t_ in tv.items() if ".encoder.layers." not in k or
                                            int(k.split(".encoder.layers.")[1].split(".")[0]) >= lo_v} if v_sel else {}))
         n_layers, Q = eng.t["num_hidden_layers"], eng.Q
@@ -223,7 +230,9 @@ class FTvl(VLLMBaseEditor):
             emb, msk = x["inputs_embeds"].clone(), x["attention_mask"]
             last = c[-1]["image"]
             pix = last.to(dev, torch.float32)[None] if isinstance(last, torch.Tensor) else torch.from_numpy(vllm.load_pixels(last))[None].to(dev)
-            if v_sel:       # the layers below the lowest selected one are frozen: their rows once per chunk
+            if emb_sel:
+                img = pix                                              # nothing of the ViT is frozen
+            elif v_sel:     # the layers below the lowest selected one are frozen: their rows once per chunk
                 x0, _ = eng.vit_embed(pix)
                 img = eng.vit_layers(x0, 1, 0, None, lo_v)
             else:
@@ -241,8 +250,12 @@ class FTvl(VLLMBaseEditor):
                 model.refresh_shadows()
                 eng.__dict__.pop("_wt_cache", None)
                 B = emb.shape[0]
-                save_q, save_v = {}, {}
-                if v_sel:
+                save_q, save_v, save_e = {}, {}, {}
+                if emb_sel:
+                    model.refresh_derived(force=True)                  # the patch weight's GEMM operand follows the raw-pointer Adam writes
+                    x0, _ = eng.vit_embed(img, save_e)
+                    img_rows_now = eng.vit_post(eng.vit_layers(x0, 1, 0, save_v))
+                elif v_sel:
                     img_rows_now = eng.vit_post(eng.vit_layers(img.clone(), 1, lo_v, save_v))
                 else:
                     img_rows_now = img
@@ -272,7 +285,9 @@ class FTvl(VLLMBaseEditor):
                         d_img = d_img.view(B, Q, -1).sum(0).contiguous()
                     d_vit = eng.qformer_backward(save_q, d_img, G if q_sel else None, want_d_img=v_sel)
                     if v_sel:
-                        eng.vit_backward(save_v, d_vit, G)
+                        dx_vit = eng.vit_backward(save_v, d_vit, G)
+                        if emb_sel:
+                            eng.vit_embed_backward(save_e, dx_vit, G)
                     t_adam += 1
                     for n, p_ in params.items():
                         if cfg.weight_decay:
@@ -298,7 +313,7 @@ class FTvl(VLLMBaseEditor):
     def _execute_ft_general(self, requests, names):
         vllm, eng, model, cfg = self.vllm, self.vllm.engine, self.vllm.model, self.cfg
         dev = eng.dev
-        if all(n.startswith("qformer.") or n.startswith("vision_model.") for n in names):
+        if all(n.startswith(("qformer.", "vision_model.", "language_projection.")) or n == "query_tokens" for n in names):
             return self._execute_ft_image_path(requests, names)
         lo, plan = self._general_plan(names)
         n_layers = eng.t["num_hidden_layers"]

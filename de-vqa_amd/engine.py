@@ -160,7 +160,7 @@ class Blip2Engine:
         return self.vit_post(self.vit_layers(x, B)), B
 
     @torch.no_grad()
-    def vit_embed(self, pixels):
+    def vit_embed(self, pixels, save=None):
         """patch embedding + class token + positions -> (fp32 residual stream [B*N, D], B)"""
         m, v = self.m, self.v
         m.refresh_derived()
@@ -171,7 +171,25 @@ class Blip2Engine:
         patches = lib.gemm(cols, m.patch_w_gemm, self._p("vision_model.embeddings.patch_embedding.bias"), want="f32")
         x = lib.vit_assemble(patches, self._p("vision_model.embeddings.class_embedding"),
                              self._p("vision_model.embeddings.position_embedding"), B, G * G, D)
+        if save is not None:
+            save.update(cols=cols, B=B, n_patches=G * G)
         return x, B
+
+    @torch.no_grad()
+    def vit_embed_backward(self, save, dx, grads):
+        """dx fp32 [B*N, D]: gradient w.r.t. the assembled ViT input rows -> position / class embeddings (sums over the images), the patch
+        convolution as the GEMM it runs as (dW = dPatches^T . im2col rows, bias = column sums)"""
+        B, Np = save["B"], save["n_patches"]
+        D = dx.shape[1]
+        e = "vision_model.embeddings."
+        dxv = dx.view(B, Np + 1, D)
+        grads[e + "position_embedding"].add_(dxv.sum(0).view_as(grads[e + "position_embedding"]))
+        grads[e + "class_embedding"].add_(dxv[:, 0].sum(0).view_as(grads[e + "class_embedding"]))
+        dP = dxv[:, 1:].reshape(B * Np, D).contiguous()
+        lib.colsum_(dP, grads[e + "patch_embedding.bias"], True)
+        gw = torch.zeros((D, self.m.patch_kpad), dtype=torch.float32, device=dx.device)
+        lib.gemm(self._padk(dP.t()), self._padk(save["cols"].to(torch.float32).t()), residual=gw, out_f32=gw)
+        grads[e + "patch_embedding.weight"].add_(gw[:, :self.m.patch_kreal].reshape(grads[e + "patch_embedding.weight"].shape))
 
     @torch.no_grad()
     def vit_layers(self, x, B, first_layer=0, save=None, end_layer=None):
@@ -212,13 +230,9 @@ class Blip2Engine:
         return self._ln(x, "vision_model.post_layernorm.weight", "vision_model.post_layernorm.bias", self.v["layer_norm_eps"])
 
     def vit_train_params(self):
-        """{name: fp32 storage} of the ViT parameters vit_backward reaches: every encoder-layer parameter and the post-LayerNorm (the patch /
-        class / position embeddings are not: a selection naming them raises)"""
-        out = {}
-        for n, p_ in self.m.vision_model.named_parameters():
-            if n.startswith("encoder.layers.") or n.startswith("post_layernorm."):
-                out["vision_model." + n] = p_.data
-        return out
+        """{name: fp32 storage} of the ViT parameters vit_backward / vit_embed_backward reach: every encoder-layer parameter, the post-LayerNorm,
+        the patch convolution, the class and position embeddings"""
+        return {"vision_model." + n: p_.data for n, p_ in self.m.vision_model.named_parameters()}
 
     @torch.no_grad()
     def vit_backward(self, save, d_img, grads):
@@ -315,8 +329,12 @@ class Blip2Engine:
 
     # ---- FT_VL on Q-Former parameters (the substring rule with "qformer": R/editor/vllm_editors/ft_vl/ft_vl.py:31-36, R/configs/ft_vl/blip2-opt-2.7b.yaml:9) ----
     def qformer_train_params(self):
-        """{name: fp32 storage} of every Q-Former parameter (what the autograd of transformers' Blip2QFormerModel reaches from the image rows)"""
-        return {"qformer." + n: p_.data for n, p_ in self.m.qformer.named_parameters()}
+        """{name: fp32 storage} of every Q-Former parameter, the learned queries and the language projection (what autograd reaches between the
+        ViT rows and the decoder's input rows)"""
+        out = {"qformer." + n: p_.data for n, p_ in self.m.qformer.named_parameters()}
+        for n in ("query_tokens", "language_projection.weight", "language_projection.bias"):
+            out[n] = self.m.get(n).data
+        return out
 
     @torch.no_grad()
     def qformer_backward(self, save, d_out, grads, want_d_img=False):
@@ -334,6 +352,8 @@ class Blip2Engine:
         eps = q["layer_norm_eps"]
         Qn = self.Q
         scale = dhq ** -0.5
+        if grads is not None:
+            self.acc_linear_grads(grads, "language_projection.weight", "language_projection.bias", save["h_last"], d_out)
         dh = lib.gemm(self._act(d_out), self._wt("language_projection", lambda: self._w("language_projection.weight")), want="f32")
         # the backward kernels read a sequence's keys from the OWN-key fields of the descriptor (the forward's cross form names them as a visible prefix)
         cross_desc = lib.h2d([[b * Qn, Qn, 0, 0, b * N, N] for b in range(B)], torch.int32, self.dev)
@@ -389,6 +409,7 @@ class Blip2Engine:
             d0 = dh.view(B, Qn, dq_).sum(0).contiguous() if B > 1 else dh
             qt = self._p("query_tokens").reshape(Qn, dq_).contiguous()
             lib.layernorm_bwd_params(qt, d0, eps, grads["qformer.layernorm.weight"], grads["qformer.layernorm.bias"])
+            grads["query_tokens"].add_(lib.layernorm_bwd_dx(qt, self._p("qformer.layernorm.weight"), d0, eps).view_as(grads["query_tokens"]))
         return d_img
 
     # ------------------------------------------------------------------------------------------

@@ -10,6 +10,8 @@ name contains rewrite_module_tmp.format(layer) for a layer of `layers`), on the 
   E  every parameter of ViT encoder layer 0 ("vision_model.encoder.layers.{}."): gradients additionally through the Q-Former's cross-attention
      keys / values, the ViT's post-LayerNorm and both encoder layers
   F  "post_layernorm" (the ViT's last LayerNorm alone: no encoder layer is trained)
+  G  "vision_model": the whole tower incl. the patch convolution, the class and position embeddings
+  H  "language_projection" (weight + bias)      I  "query_tokens" (the learned queries)
 Stores per case and request: per-step losses, step count, the delta of every selected parameter.  DATA only."""
 import json
 import os
@@ -26,7 +28,10 @@ CASES = [("A", "language_model.model.decoder.layers.{}.fc1.weight", [0, 1]),
          ("C", "language_model.model.decoder.layers.{}.f", [0]),
          ("D", "qformer", [0]),
          ("E", "vision_model.encoder.layers.{}.", [0]),
-         ("F", "post_layernorm", [0])]
+         ("F", "post_layernorm", [0]),
+         ("G", "vision_model", [0]),
+         ("H", "language_projection", [0]),
+         ("I", "query_tokens", [0])]
 
 
 def main():
