@@ -64,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs #3-#5 legs (LLaVA + FT_VL, BLIP-2 + MEND_VL, MiniGPT-4 + IKE_VL)")
     ap.add_argument("--config-cycles", type=str, default="32,64,16", help="cycles of the three configs legs (llava_ft, blip2_mend, minigpt4_ike)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the two stages of every batch back to back on one stream")
+    ap.add_argument("--host-pixels", action="store_true",
+                    help="measurement only (never `value`): the pre-processed pixel values stay in pinned HOST memory and cross PCIe inside the timed "
+                         "region -- the rate a caller sees who hands over host buffers (DESIGN 7)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--selftest-cpu", action="store_true")
     return ap.parse_args(argv)
@@ -416,7 +419,8 @@ class Leg:
             def image_of(s, tag):
                 key = (offset + s, tag)
                 if key not in self._img_cache:
-                    self._img_cache[key] = torch.from_numpy(proc(self._synth_image_u8(offset + s, tag, size, a.seed))).to(self.dev)
+                    px = torch.from_numpy(proc(self._synth_image_u8(offset + s, tag, size, a.seed)))
+                    self._img_cache[key] = px.pin_memory() if getattr(a, "host_pixels", False) else px.to(self.dev)
                 return self._img_cache[key]
             return image_of
         if scaling == "weak":
@@ -696,7 +700,8 @@ def main():
         out = {
             "metric": "edit+eval cycles/sec, BLIP-2 FT_VL EVQA", "value": round(value, 3), "unit": "cycles/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 2),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic" if not args.host_pixels else "synthetic; MEASUREMENT RUN, not the metric: pixel values cross PCIe inside the timed region",
             "rccl_ranks": ranks,
             "config": {"workload": "BLIP-2-OPT-2.7B + FT_VL, %d synthetic EVQA-shaped edit+eval cycles %s (%d per step), bf16 "
                                    "weights/activations, fp32 master + AdamW state for the edited fc2 matrix, early stop enabled; "

@@ -318,7 +318,12 @@ class BatchedEditEval:
         pix = None
         if img_list:
             if all(isinstance(p, torch.Tensor) for p in img_list):
-                pix = torch.stack(img_list)   # already-preprocessed pixel_values resident in HBM
+                if img_list[0].is_cuda:
+                    pix = torch.stack(img_list)   # already-preprocessed pixel_values resident in HBM
+                else:                             # pre-processed pixel values handed over in host memory: one pinned staging buffer, one H2D copy
+                    stage = torch.empty((len(img_list),) + tuple(img_list[0].shape), dtype=torch.float32, pin_memory=True)
+                    torch.stack([p.to(torch.float32) for p in img_list], out=stage)
+                    pix = stage.to(dev, non_blocking=True)
             else:
                 pix = np.stack([vllm.load_pixels(p) for p in img_list])
                 pix = torch.from_numpy(pix).to(dev, non_blocking=True)
