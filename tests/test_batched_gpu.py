@@ -163,6 +163,39 @@ def test_pipelined_batches_equal_sequential(gold_dir, in_gold_dir, dtype):
                 assert r1["reliability"][0]["acc"] == r2["reliability"][0]["acc"]
 
 
+def test_pixel_tensors_in_hbm_or_host_memory_equal_image_paths(gold_dir, in_gold_dir):
+    """Images handed over as pre-processed pixel values -- resident in HBM (the benchmark's form) or in pinned host memory (`bench.py
+    --host-pixels`: gathered into one staging buffer, one asynchronous H2D copy per batch) -- give the results of the image paths."""
+    from devqa_amd.batched import BatchedEditEval
+    vllm, ed, data = _setup(gold_dir, "fp32")
+    be = BatchedEditEval(ed, cycles_per_batch=3)
+
+    def batch(convert):
+        seen = {}
+
+        def conv(e):
+            if e.get("image") is not None:
+                key = e["image"]
+                if key not in seen:
+                    seen[key] = convert(torch.from_numpy(vllm.load_pixels(key)))
+                e["image"] = seen[key]
+        eds = [deepcopy(r) for r in data.data_with_img[:3]]
+        if convert is not None:
+            for ed_ in eds:
+                for e in ed_["requests"] + [x for g in ed_["generality"].values() for x in g] + [x for g in ed_["locality"].values() for x in g]:
+                    conv(e)
+        return [deepcopy(r) for r in data.data_with_img_path[:3]], eds
+    base = be.run_batch(*batch(None))
+    for convert in (lambda t: t.cuda(), lambda t: t.pin_memory()):
+        got = be.run_batch(*batch(convert))
+        for r1, r2 in zip(base[0], got[0]):
+            for sec in ("generality", "locality"):
+                for sub in r1[sec]:
+                    a, b = r1[sec][sub][0], r2[sec][sub][0]
+                    assert a["acc"] == b["acc"] and a["predict_after_edit"] == b["predict_after_edit"]
+            assert r1["reliability"][0]["acc"] == r2["reliability"][0]["acc"]
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_batched_chained_edits_match_reference_and_generic(gold_dir, in_gold_dir, tmp_path, dtype):
     """`-sen N` with N > 1 (R/evaluation/vllm_editor_eval.py:114-122: a split's edits accumulate on the same matrix, then every sample of
