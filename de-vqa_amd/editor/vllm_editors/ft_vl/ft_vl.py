@@ -28,8 +28,12 @@ Two execution forms behind the same `execute_ft`:
     activations, all decoder layers run with saved activations, and the gradient returns through the decoder's inputs, the language projection,
     the Q-Former (engine.qformer_backward: cross- and self-attention, GELU FFN, post-LayerNorms) and, for a vision selection, the ViT
     (engine.vit_backward, vit_embed_backward) into one Adam(W) step per tensor.  Pinned by the reference's own FTvl (cases D - I of the same goldens).
-The LM's token / position embeddings and final norm have no gradient path in this loop and raise NotImplementedError; so does a selection
-mixing image-path and decoder parameters.
+  * WHOLE MODEL (round 3, BLIP-2): the three forms above are ONE loop (`_execute_ft_general`), so a selection may mix them and may name the
+    language model's parameters outside the decoder layers: the final LayerNorm, the learned positions, and the token embedding -- tied to the
+    head, so its gradient is the head side (dlogits^T . normalised rows) plus the lookup side (a scatter of the decoder's input gradient onto
+    the text rows' ids).  The templates "language_model", "layer_norm" and the EMPTY template (every parameter of the model: 240 tensors on the
+    tiny model) are cases J, K, L of the same goldens.
+On the LLaVA / MiniGPT-4 engines the general form reaches decoder-layer parameters; anything else raises NotImplementedError there.
 """
 import os
 from copy import deepcopy
@@ -157,19 +161,28 @@ class FTvl(VLLMBaseEditor):
     # GENERAL form: any decoder-layer parameters (see the module docstring)
     # ---------------------------------------------------------------------------------------
     def _general_plan(self, names):
-        """-> (lowest selected layer, {selected name: (gradient key, row slice or None)}); raises NotImplementedError for a selection the
-        explicit backward does not reach."""
+        """Sorts the selected names into what the explicit backward has to reach.  -> dict with
+             plan     {name: (gradient key, row slice or None)} -- q / k / v (gate / up) projections are row blocks of a fused operand's gradient
+             lo       lowest selected decoder layer (None: none selected)
+             extras   selected language-model parameters outside the decoder layers (final norm, token / position embeddings)
+             image    selected parameters of the image path (ViT, Q-Former, learned queries, language projection)
+        raises NotImplementedError for a name no gradient path reaches on this engine."""
         import re
         eng, model = self.vllm.engine, self.vllm.model
         if not hasattr(eng, "train_params") or not hasattr(eng, "decoder_backward"):
             raise NotImplementedError("native FT_VL: this engine has no parameter-gradient backward")
         keys = eng.train_params()
+        img_ok = hasattr(eng, "qformer_backward")          # BLIP-2: Q-Former / ViT backward, head and embedding gradients wired into this loop
+        tq, tv = (eng.qformer_train_params(), eng.vit_train_params()) if img_ok else ({}, {})
         lm = eng.LM_MODULE + "."
-        plan, lo = {}, None
+        plan, lo, extras, image = {}, None, [], []
         for n in names:
-            m = re.search(r"\.layers\.(\d+)\.", n)
-            if not n.startswith(lm) or m is None:
-                raise NotImplementedError("native FT_VL edits decoder-layer parameters of the language model; config selects %s" % n)
+            if n in tq or n in tv:
+                plan[n] = (n, None)
+                image.append(n)
+                continue
+            if not n.startswith(lm):
+                raise NotImplementedError("native FT_VL: no gradient path for %s" % n)
             fs = model._fused_slot(n)
             if fs is not None:          # a row block of a fused operand (q / k / v, gate / up)
                 group, slot, _n = fs
@@ -181,178 +194,138 @@ class FTvl(VLLMBaseEditor):
                 plan[n] = (key, None)
             if key not in keys:
                 raise NotImplementedError("native FT_VL: no gradient path for %s" % n)
-            layer = int(m.group(1))
-            lo = layer if lo is None else min(lo, layer)
-        return lo, plan
+            m = re.search(r"\.layers\.(\d+)\.", n)
+            if m is not None:
+                layer = int(m.group(1))
+                lo = layer if lo is None else min(lo, layer)
+            elif img_ok:
+                extras.append(n)
+            else:
+                raise NotImplementedError("native FT_VL edits decoder-layer parameters of the language model on this engine; config selects %s" % n)
+        return dict(plan=plan, lo=lo, extras=extras, image=image, tq=tq, tv=tv, keys=keys)
 
-    def _execute_ft_image_path(self, requests, names):
-        """Every selected name is a Q-Former parameter (the template "qformer" the reference's yaml carries as a comment) or a ViT encoder-layer /
-        post-LayerNorm parameter: per step the trained part of the image path runs with saved activations (ViT layers from the lowest selected
-        one on the rows the frozen layers below it produced once; the Q-Former on the ViT rows), its projected query rows take their place in
-        front of the text embeddings, ALL decoder layers run with saved activations, and the gradient of the label rows' NLL comes back
-        through the decoder (engine.decoder_backward, inputs only), the language projection, the Q-Former (engine.qformer_backward) and --
-        for a vision selection -- the cross-attention keys / values into the ViT (engine.vit_backward), into one Adam(W) step per tensor.
+    def _execute_ft_general(self, requests, names):
+        """ANY selection of the substring rule (ft_vl.py:31-36) that the explicit backward reaches.  Frozen work is done once per chunk where the
+        selection allows it (decoder layers below the lowest selected one when nothing in front of the decoder is trained; ViT layers below the
+        lowest selected ViT layer); every step then runs, with saved activations, the trained part of the image path (ViT from the lowest
+        selected layer or from the pixels, Q-Former, language projection), the decoder layers, the head on the label rows, and the backward:
+        head (tied embedding, final norm when selected), decoder layers (parameter gradients from the lowest selected layer up, inputs
+        only below it), learned positions and the embedding lookup, language projection, Q-Former, ViT -- then one Adam(W) step per tensor.
         As in the reference's wrapper the LAST image of a chunk serves the whole chunk (blip2.py:54-55)."""
         import re
         vllm, eng, model, cfg = self.vllm, self.vllm.engine, self.vllm.model, self.cfg
         dev = eng.dev
-        if not hasattr(eng, "qformer_backward"):
-            raise NotImplementedError("native FT_VL: this engine has no backward through the image path")
-        tq, tv = eng.qformer_train_params(), eng.vit_train_params()
-        for n in names:
-            if n not in tq and n not in tv:
-                raise NotImplementedError("native FT_VL: no gradient path for %s" % n)
-        q_sel = any(n in tq for n in names)
-        v_sel = any(n in tv for n in names)
-        n_vit = eng.v["num_hidden_layers"]
-        lo_v = min([int(re.search(r"encoder\.layers\.(\d+)\.", n).group(1)) for n in names if n in tv and ".encoder.layers." in n] + [n_vit])
-        emb_sel = any(".embeddings." in n for n in names if n in tv)       # patch / class / position embeddings: the ViT runs from the pixels every step
-        if emb_sel:
-            lo_v = 0
-        tp = dict(tq if q_sel else {}, **({k: t_ for k, t_ in tv.items() if ".encoder.layers." not in k or
-                                           int(k.split(".encoder.layers.")[1].split(".")[0]) >= lo_v} if v_sel else {}))
-        n_layers, Q = eng.t["num_hidden_layers"], eng.Q
-        params = {n: nethook.get_parameter(model, n) for n in names}
+        gp = self._general_plan(names)
+        plan, lo, extras, image, tq, tv, keys = (gp[k] for k in ("plan", "lo", "extras", "image", "tq", "tv", "keys"))
+        n_layers = eng.t["num_hidden_layers"]
+        lo_grad = n_layers if lo is None else lo                     # decoder layers [lo_grad, end) receive parameter gradients
+        q_sel = any(n in tq for n in image)
+        v_sel = any(n in tv for n in image)
+        emb_sel = any(".embeddings." in n for n in image if n in tv)  # patch / class / position embeddings: the ViT runs from the pixels every step
+        n_vit = eng.v["num_hidden_layers"] if v_sel else 0
+        lo_v = 0 if emb_sel else min([int(re.search(r"encoder\.layers\.(\d+)\.", n).group(1)) for n in image if n in tv and ".encoder.layers." in n] + [n_vit])
+        tok_name = pos_name = None
+        for n in extras:
+            if n.endswith("embed_tokens.weight"):
+                tok_name = n
+            elif n.endswith("embed_positions.weight"):
+                pos_name = n
+        need_dx0 = bool(image) or tok_name is not None or pos_name is not None      # gradient w.r.t. the decoder's input rows
+        lo_dec = 0 if need_dx0 else lo_grad                          # decoder layers [lo_dec, end) run every step with saved activations
+        layer_of = lambda k: int(k.split(".")[2]) if k.startswith("derived.") else int(k.split(".layers.")[1].split(".")[0])   # noqa: E731
+        is_layer = lambda k: ".layers." in k or k.startswith("derived.")                                                       # noqa: E731
+        tp = {k: t_ for k, t_ in keys.items() if (is_layer(k) and layer_of(k) >= lo_grad) or (extras and not is_layer(k))}
+        if q_sel:
+            tp.update(tq)
+        if v_sel:
+            tp.update({k: t_ for k, t_ in tv.items() if ".encoder.layers." not in k or int(k.split(".encoder.layers.")[1].split(".")[0]) >= lo_v})
+        params = {n: nethook.get_parameter(model, n) for n in names}          # fp32 masters (promote_to_fp32 in __init__)
         w0 = {n: p_.detach().clone() for n, p_ in params.items()}
         mom = {n: torch.zeros_like(p_.data) for n, p_ in params.items()}
         var = {n: torch.zeros_like(p_.data) for n, p_ in params.items()}
         G = {k: torch.zeros(t_.shape, dtype=torch.float32, device=dev) for k, t_ in tp.items()}
+        Q = getattr(eng, "Q", 0)
         bs = cfg.batch_size
         chunks = [requests[i:i + bs] for i in range(0, len(requests), bs)]
         clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else None
         t_adam = 0
         self.last_losses = []
+
+        def build_inputs(c):
+            return vllm.prompts_imgs_target_to_xym([r["prompt"] for r in c], [r["image"] for r in c], [r["target_new"] for r in c])
         prepared = []
         for c in chunks:
-            if any(r["image"] is None for r in c):
-                raise NotImplementedError("native FT_VL on image-path parameters needs an image in every request")
-            (x, vt), y, m = vllm.prompts_imgs_target_to_xym([r["prompt"] for r in c], [r["image"] for r in c], [r["target_new"] for r in c])
-            emb, msk = x["inputs_embeds"].clone(), x["attention_mask"]
-            last = c[-1]["image"]
-            pix = last.to(dev, torch.float32)[None] if isinstance(last, torch.Tensor) else torch.from_numpy(vllm.load_pixels(last))[None].to(dev)
-            if emb_sel:
-                img = pix                                              # nothing of the ViT is frozen
-            elif v_sel:     # the layers below the lowest selected one are frozen: their rows once per chunk
-                x0, _ = eng.vit_embed(pix)
-                img = eng.vit_layers(x0, 1, 0, None, lo_v)
-            else:
-                img, _ = eng.vit_rows(pix)                             # the whole ViT is frozen
+            (x, vt), y, m = build_inputs(c)
+            emb, msk = x["inputs_embeds"], x["attention_mask"]
             B, T = emb.shape[:2]
             L = y.shape[1]
             mh, yh = VLLM_HOST(m), VLLM_HOST(y)
             rows = [b * T + (T - L) + j for b in range(B) for j in range(L) if int(mh[b, j]) != 0]
             labels = [int(yh[b, j]) for b in range(B) for j in range(L) if int(mh[b, j]) != 0]
-            img_rows = lib.h2d([b * T + j for b in range(B) for j in range(Q)], torch.int32, dev)
-            prepared.append((emb, msk, img, img_rows, lib.h2d(rows, torch.int32, dev), lib.h2d(labels, torch.int32, dev), len(rows), len(c)))
-        for it in range(cfg.num_steps):
-            loss_sum, cnt = 0.0, 0
-            for emb, msk, img, img_rows, idx, labels, k, n_items in prepared:
-                model.refresh_shadows()
-                eng.__dict__.pop("_wt_cache", None)
-                B = emb.shape[0]
-                save_q, save_v, save_e = {}, {}, {}
+            ent = dict(chunk=c, emb=emb.clone(), msk=msk, idx=lib.h2d(rows, torch.int32, dev), labels=lib.h2d(labels, torch.int32, dev), k=len(rows),
+                       n_items=len(c), n_img=0)
+            if image:
+                if any(r["image"] is None for r in c):
+                    raise NotImplementedError("native FT_VL on image-path parameters needs an image in every request")
+                last = c[-1]["image"]
+                pix = last.to(dev, torch.float32)[None] if isinstance(last, torch.Tensor) else torch.from_numpy(vllm.load_pixels(last))[None].to(dev)
                 if emb_sel:
-                    model.refresh_derived(force=True)                  # the patch weight's GEMM operand follows the raw-pointer Adam writes
-                    x0, _ = eng.vit_embed(img, save_e)
-                    img_rows_now = eng.vit_post(eng.vit_layers(x0, 1, 0, save_v))
-                elif v_sel:
-                    img_rows_now = eng.vit_post(eng.vit_layers(img.clone(), 1, lo_v, save_v))
+                    ent["img"] = pix                                   # nothing of the ViT is frozen
+                elif v_sel:     # the ViT layers below the lowest selected one are frozen: their rows once per chunk
+                    x0, _ = eng.vit_embed(pix)
+                    ent["img"] = eng.vit_layers(x0, 1, 0, None, lo_v)
                 else:
-                    img_rows_now = img
-                feats = eng.qformer_rows(img_rows_now, 1, save_q)      # [1, Q, d_llm] under the current image path
-                emb[:, :Q] = feats
+                    ent["img"] = eng.vit_rows(pix)[0]                  # the whole ViT is frozen
+                ent["img_rows"] = lib.h2d([b * T + j for b in range(B) for j in range(Q)], torch.int32, dev)
+            if tok_name is not None:
+                if "input_ids" not in x:
+                    raise NotImplementedError("native FT_VL on the token embedding needs the wrapper's input_ids")
+                ids = x["input_ids"].reshape(-1).to(torch.int64)       # [B * T_txt]: the text rows of every sample, padding included
+                Tt = x["input_ids"].shape[1]
+                ent["n_img"] = T - Tt                                  # image rows in front of the text rows (0 without an image)
+                ent["tok_ids"] = ids
+                ent["txt_rows"] = torch.tensor([b * T + ent["n_img"] + j for b in range(B) for j in range(Tt)], dtype=torch.int64, device=dev)
+                ent["txt_mask"] = msk[:, ent["n_img"]:].reshape(-1).to(torch.float32)
+            if not need_dx0:      # the decoder layers below the lowest selected one are frozen: their output rows once per chunk
                 ps = eng.pack_from_embeds(emb, msk)
-                save = {"layers": set(range(n_layers))}
-                x_fin, _ = eng.decoder_layers(ps, save=save, first_layer=0)
-                pre_ln = lib.gather_rows(x_fin, idx)
-                logits = eng.lm_head(pre_ln)
-                coef = torch.full((k,), 1.0 / k, dtype=torch.float32, device=dev)
-                _, nll, dlog = lib.vocab_rows(logits, labels, coef, want_argmax=False, want_nll=True, want_dlogits=True, dlogits_dtype=eng.adt)
-                loss = float(nll.mean().item())                      # the reference syncs here too (ft_vl.py:129-131)
-                self.last_losses.append(loss)
-                loss_sum += loss * n_items
-                cnt += n_items
-                if loss >= LOSS_FLOOR:
-                    for g in G.values():
-                        g.zero_()
-                    dH = lib.gemm_rows_longk(dlog, model.embed_T)
-                    dxr = eng.final_norm_bwd(pre_ln, dH)
-                    dx = torch.zeros_like(x_fin)
-                    dx.index_copy_(0, idx.long(), dxr)
-                    _, dx0 = eng.decoder_backward(ps, save, dx, set(), grads=None)
-                    d_img = lib.gather_rows(dx0, img_rows)             # [B * Q, d]: every sample of the chunk shows the same image rows
-                    if B > 1:
-                        d_img = d_img.view(B, Q, -1).sum(0).contiguous()
-                    d_vit = eng.qformer_backward(save_q, d_img, G if q_sel else None, want_d_img=v_sel)
-                    if v_sel:
-                        dx_vit = eng.vit_backward(save_v, d_vit, G)
-                        if emb_sel:
-                            eng.vit_embed_backward(save_e, dx_vit, G)
-                    t_adam += 1
-                    for n, p_ in params.items():
-                        if cfg.weight_decay:
-                            p_.data.mul_(1.0 - cfg.lr * cfg.weight_decay)
-                        lib.adam_step_(p_.data.reshape(-1), G[n].reshape(-1), mom[n].reshape(-1), var[n].reshape(-1), cfg.lr, t_adam)
-                        model.mark_dirty(n)
-                if clamp is not None:
-                    for n, p_ in params.items():
-                        p_.data.copy_(torch.max(torch.min(p_.data, w0[n] + clamp), w0[n] - clamp))
-                        model.mark_dirty(n)
-            if loss_sum / cnt < LOSS_FLOOR:
-                break
-        deltas = {}
-        for n, p_ in params.items():
-            deltas[n] = (p_.data - w0[n])
-            p_.data.copy_(w0[n])
-            model.mark_dirty(n)
-        model.refresh_shadows()
-        eng.__dict__.pop("_wt_cache", None)
-        self._image_path_written()
-        return deltas
-
-    def _execute_ft_general(self, requests, names):
-        vllm, eng, model, cfg = self.vllm, self.vllm.engine, self.vllm.model, self.cfg
-        dev = eng.dev
-        if all(n.startswith(("qformer.", "vision_model.", "language_projection.")) or n == "query_tokens" for n in names):
-            return self._execute_ft_image_path(requests, names)
-        lo, plan = self._general_plan(names)
-        n_layers = eng.t["num_hidden_layers"]
-        params = {n: nethook.get_parameter(model, n) for n in names}          # fp32 masters (promote_to_fp32 in __init__)
-        w0 = {n: p_.detach().clone() for n, p_ in params.items()}
-        mom = {n: torch.zeros_like(p_.data) for n, p_ in params.items()}
-        var = {n: torch.zeros_like(p_.data) for n, p_ in params.items()}
-        tp = eng.train_params()
-        layer_of = lambda k: int(k.split(".")[2]) if k.startswith("derived.") else int(k.split(".layers.")[1].split(".")[0])   # noqa: E731
-        G = {k: torch.zeros(t_.shape, dtype=torch.float32, device=dev) for k, t_ in tp.items()
-             if (".layers." in k or k.startswith("derived.")) and layer_of(k) >= lo}
-        bs = cfg.batch_size
-        chunks = [requests[i:i + bs] for i in range(0, len(requests), bs)]
-        clamp = float(cfg.norm_constraint) if type(cfg.norm_constraint) is float else None
-        t_adam = 0
-        self.last_losses = []
-        # the layers below the lowest selected one are frozen: their output rows are computed once per chunk
-        prepared = []
-        for c in chunks:
-            (x, vt), y, m = vllm.prompts_imgs_target_to_xym([r["prompt"] for r in c], [r["image"] for r in c], [r["target_new"] for r in c])
-            ps = eng.pack_from_embeds(x["inputs_embeds"], x["attention_mask"])
-            if lo > 0:
-                eng.decoder_layers(ps, upto_layer=lo - 1)
-            B, T = x["inputs_embeds"].shape[:2]
-            L = y.shape[1]
-            mh, yh = VLLM_HOST(m), VLLM_HOST(y)
-            rows = [b * T + (T - L) + j for b in range(B) for j in range(L) if int(mh[b, j]) != 0]
-            labels = [int(yh[b, j]) for b in range(B) for j in range(L) if int(mh[b, j]) != 0]
-            prepared.append((ps, ps.x.clone(), lib.h2d(rows, torch.int32, dev), lib.h2d(labels, torch.int32, dev), len(rows), len(c)))
+                if lo_dec > 0:
+                    eng.decoder_layers(ps, upto_layer=lo_dec - 1)
+                ent["ps"], ent["x_lo"] = ps, ps.x.clone()
+            prepared.append(ent)
         for it in range(cfg.num_steps):
             loss_sum, cnt = 0.0, 0
-            for ps, x_lo, idx, labels, k, n_items in prepared:
+            for ent in prepared:
                 model.refresh_shadows()                              # compute-dtype copies of the masters (incl. row blocks of fused operands)
                 eng.__dict__.pop("_wt_cache", None)                  # transposed operands of the backward follow the weights
-                ps.x = x_lo.clone()
-                save = {"layers": set(range(lo, n_layers))}
-                x_fin, _ = eng.decoder_layers(ps, save=save, first_layer=lo)
+                if tok_name is not None or emb_sel:
+                    model.refresh_derived(force=True)                # the tied head's transposed table / the patch convolution's GEMM operand
+                idx, labels, k, n_items = ent["idx"], ent["labels"], ent["k"], ent["n_items"]
+                save_q, save_v, save_e = {}, {}, {}
+                if need_dx0:
+                    emb, msk = ent["emb"], ent["msk"]
+                    if tok_name is not None:                         # the text rows follow the trained embedding table
+                        table = nethook.get_parameter(model, tok_name).data
+                        emb[:, ent["n_img"]:] = table[ent["tok_ids"]].to(torch.float32).view(emb.shape[0], -1, emb.shape[2])
+                    if image:
+                        if emb_sel:
+                            x0, _ = eng.vit_embed(ent["img"], save_e)
+                            img_now = eng.vit_post(eng.vit_layers(x0, 1, 0, save_v))
+                        elif v_sel:
+                            img_now = eng.vit_post(eng.vit_layers(ent["img"].clone(), 1, lo_v, save_v))
+                        else:
+                            img_now = ent["img"]
+                        emb[:, :Q] = eng.qformer_rows(img_now, 1, save_q)      # [1, Q, d_llm] under the current image path
+                    ps = eng.pack_from_embeds(emb, msk)
+                else:
+                    ps = ent["ps"]
+                    ps.x = ent["x_lo"].clone()
+                save = {"layers": set(range(lo_dec, n_layers))}
+                x_fin, _ = eng.decoder_layers(ps, save=save, first_layer=lo_dec)
                 pre_ln = lib.gather_rows(x_fin, idx)
-                logits = eng.lm_head(pre_ln)
+                if extras:
+                    hn, logits = eng.head_fwd(pre_ln)
+                else:
+                    logits = eng.lm_head(pre_ln)
                 coef = torch.full((k,), 1.0 / k, dtype=torch.float32, device=dev)
                 _, nll, dlog = lib.vocab_rows(logits, labels, coef, want_argmax=False, want_nll=True, want_dlogits=True, dlogits_dtype=eng.adt)
                 loss = float(nll.mean().item())                      # the reference syncs here too (ft_vl.py:129-131)
@@ -362,11 +335,38 @@ class FTvl(VLLMBaseEditor):
                 if loss >= LOSS_FLOOR:
                     for g in G.values():
                         g.zero_()
-                    dH = lib.gemm_rows_longk(dlog, model.embed_T)
-                    dxr = eng.final_norm_bwd(pre_ln, dH)
+                    if extras:
+                        dxr = eng.head_bwd(pre_ln, hn, dlog, G)      # + the tied embedding's head-side gradient, the final norm's parameters
+                    else:
+                        dxr = eng.final_norm_bwd(pre_ln, lib.gemm_rows_longk(dlog, model.embed_T))
                     dx = torch.zeros_like(x_fin)
                     dx.index_copy_(0, idx.long(), dxr)
-                    eng.decoder_backward(ps, save, dx, set(), grads=G)
+                    hi = {"layers": {i for i in save["layers"] if i >= lo_grad}}
+                    below = {"layers": save["layers"] - hi["layers"]}
+                    for part in (hi, below):
+                        part.update({i: save[i] for i in part["layers"]})
+                    if hi["layers"]:
+                        _, dx = eng.decoder_backward(ps, hi, dx, set(), grads=G)
+                    if below["layers"]:                              # inputs only: nothing is trained in these layers
+                        _, dx = eng.decoder_backward(ps, below, dx, set(), grads=None)
+                    if need_dx0:
+                        if extras:
+                            eng.embed_bwd(ent["msk"], dx, G)         # learned positions
+                        if tok_name is not None:                     # the embedding lookup of the text rows: one-hot^T . dx on the GEMM
+                            ids, trow = ent["tok_ids"], ent["txt_rows"]
+                            onehot = torch.zeros((ids.numel(), G[tok_name].shape[0]), dtype=torch.float32, device=dev)
+                            onehot[torch.arange(ids.numel(), device=dev), ids] = ent["txt_mask"]
+                            eng.acc_linear_grads(G, tok_name, None, dx.index_select(0, trow), onehot)
+                        if image:
+                            d_q = lib.gather_rows(dx, ent["img_rows"])     # [B * Q, d]: every sample of the chunk shows the same image rows
+                            Bc = ent["emb"].shape[0]
+                            if Bc > 1:
+                                d_q = d_q.view(Bc, Q, -1).sum(0).contiguous()
+                            d_vit = eng.qformer_backward(save_q, d_q, G if q_sel else None, want_d_img=v_sel)
+                            if v_sel:
+                                dx_vit = eng.vit_backward(save_v, d_vit, G)
+                                if emb_sel:
+                                    eng.vit_embed_backward(save_e, dx_vit, G)
                     t_adam += 1
                     for n, p_ in params.items():
                         key, sl = plan[n]
@@ -388,6 +388,9 @@ class FTvl(VLLMBaseEditor):
             model.mark_dirty(n)
         model.refresh_shadows()
         eng.__dict__.pop("_wt_cache", None)
+        if tok_name is not None or emb_sel:
+            model.refresh_derived(force=True)
+        self._image_path_written()
         return deltas
 
     def execute_ft(self, requests: List[Dict]) -> Dict[str, torch.Tensor]:

@@ -90,7 +90,7 @@ class BLIP2OPTForEdit(BaseVLLMForEdit):
         # host original of the mask (consumers that only need the sequence lengths read it without a device -> host sync)
         mh = tk["attention_mask"].to(torch.int64)
         msk._devqa_host = mh if imgs is None else torch.cat([torch.ones((B, self.model.cfg["num_query_tokens"]), dtype=torch.int64), mh], 1)
-        llm_inpt = {"attention_mask": msk, "inputs_embeds": emb}
+        llm_inpt = {"attention_mask": msk, "inputs_embeds": emb, "input_ids": ids.view(B, T)}   # (input_ids: FT_VL on the embedding table scatters into it)
         if B == 1:   # hashable identity of every input row (image rows: (path, j); text rows: token id) -- lets the evaluator's
             # batched probe path compute a prefix that several probes share only once (same mathematics: attention is causal)
             ik = self.image_key(imgs)

@@ -645,7 +645,7 @@ class Blip2Engine:
         """rows before the final LayerNorm -> (normalised rows, fp32 logits)"""
         hn = self._ln(pre_ln, "language_model.model.decoder.final_layer_norm.weight", "language_model.model.decoder.final_layer_norm.bias",
                       LN_EPS_OPT)
-        return hn, lib.gemm(hn, self._p("language_model.model.decoder.embed_tokens.weight"), want="f32")
+        return hn, lib.gemm(hn, self._w("language_model.model.decoder.embed_tokens.weight"), want="f32")     # (_w: the compute-dtype operand of an fp32 master)
 
     @torch.no_grad()
     def head_bwd(self, pre_ln, hn, dlog, grads):

@@ -46,7 +46,7 @@ def test_ft_general_targets_vs_reference(gold_dir, in_gold_dir, mode):
                 gold = z["%s_%d_%s" % (case["tag"], rq["record"], name)]
                 got = deltas[name].float().cpu().numpy()
                 assert got.shape == gold.shape
-                if name.endswith("attention.key.bias"):
+                if name.endswith(("attention.key.bias", "self_attn.k_proj.bias")):
                     # softmax does not see a constant added to every key: the exact gradient of a key bias is ZERO, what autograd and the HIP
                     # backward compute is rounding noise, and Adam turns noise of any size into steps of ~lr -- nothing to compare but the bound
                     assert np.abs(got).max() <= 1.001 * 1e-3 * 25 and np.abs(gold).max() <= 1.001 * 1e-3 * 25

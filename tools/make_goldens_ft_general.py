@@ -12,6 +12,8 @@ name contains rewrite_module_tmp.format(layer) for a layer of `layers`), on the 
   F  "post_layernorm" (the ViT's last LayerNorm alone: no encoder layer is trained)
   G  "vision_model": the whole tower incl. the patch convolution, the class and position embeddings
   H  "language_projection" (weight + bias)      I  "query_tokens" (the learned queries)
+  J  "language_model": the whole decoder incl. the tied token embedding (head side and lookup side), the learned positions, the final norm
+  K  "" -- the empty template selects EVERY parameter of the model      L  "layer_norm": LayerNorms of the ViT and of the decoder together
 Stores per case and request: per-step losses, step count, the delta of every selected parameter.  DATA only."""
 import json
 import os
@@ -31,7 +33,10 @@ CASES = [("A", "language_model.model.decoder.layers.{}.fc1.weight", [0, 1]),
          ("F", "post_layernorm", [0]),
          ("G", "vision_model", [0]),
          ("H", "language_projection", [0]),
-         ("I", "query_tokens", [0])]
+         ("I", "query_tokens", [0]),
+         ("J", "language_model", [0]),
+         ("K", "", [0]),
+         ("L", "layer_norm", [0])]
 
 
 def main():
