@@ -1,0 +1,121 @@
+"""Depth-compounded bf16 drift of BASELINE config #4, bounded inside the suite: BLIP-2-OPT-2.7B at FULL depth (39 ViT + 12 Q-Former +
+32 OPT layers, synthetic weights of bench.py's headline recipe) + MEND_VL on decoder layers 29-31 (hyper-network 12800 -> rank 1920,
+the synthetic hyper-network of tools/bench_configs.py), two EVQA-shaped cycles through BatchedMendEval in the engine's fp32
+("faithful") mode and in its bf16 (benchmark) mode.
+
+A SELF-comparison (the same engine in two compute modes), not a parity claim against the reference: the fp32 mode is held to the
+reference's own MENDvl by the tiny and the true-layer-dim goldens (tests/test_mend_gpu.py, tests/test_mend_batched_gpu.py); what this
+file adds is the depth (29 frozen decoder layers + the whole image path under the three edited layers, their backward and the
+hyper-network), which no reference-made fixture reaches (the reference's MENDvl at full depth needs the 130-s-per-cycle CPU path)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOC = ["text_loc", "t3i3", "t1i4", "t2i4", "t1i2", "t1i3", "t2i1", "t2i2", "t3i1"]
+
+
+def _aux(seed=11):
+    from concurrent.futures import ThreadPoolExecutor
+    from devqa_amd.synth import mend_aux_init
+    D = 2560 + 10240
+    shapes = {}
+    for du, dv in ((2560, 10240), (10240, 2560)):
+        key = "(%d, %d)" % (du, dv)
+        shapes.update({key + ".u_mean": (du,), key + ".u_std": (du,), key + ".v_mean": (dv,), key + ".v_std": (dv,)})
+        for l in range(2):
+            q = key + ".mlp.layers.%d." % l
+            shapes.update({q + "u": (D, 1920), q + "v": (1920, D), q + "bias": (D,), q + "mode_shift.weight": (3, D),
+                           q + "mode_scale.weight": (3, D)})
+    with ThreadPoolExecutor(8) as ex:
+        return dict(zip(shapes, ex.map(lambda kv: torch.from_numpy(mend_aux_init("aux_models." + kv[0], kv[1], seed)), shapes.items())))
+
+
+@pytest.fixture(scope="module")
+def runs():
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    import devqa_amd  # noqa: F401
+    from devqa_amd import blip2_spec
+    from devqa_amd.batched import copy_sample
+    from devqa_amd.batched_mend import BatchedMendEval
+    from devqa_amd.editor.vllm_editors.mend_vl.mend_vl import MENDvl, MENDvlConfig
+    from devqa_amd.editor.vllms_for_edit.blip2.blip2 import BLIP2OPTForEdit
+    from devqa_amd.editor.vllms_for_edit.blip2.modeling import Blip2Native
+    from devqa_amd.synth import IdTokenizer, evqa_cycles, param_init, synth_image_u8
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg, dev, seed = blip2_spec.BLIP2_OPT_2_7B, "cuda:0", 20251121
+    aux = _aux()
+    out = {}
+    for mode in ("fp32", "bf16"):          # one model at a time: the fp32 masters of the three edited layers come on top of the weights
+        model = Blip2Native(cfg, dev, mode)
+        names = list(model._shapes.keys())
+        with ThreadPoolExecutor(16) as ex:
+            futs = {n: ex.submit(param_init, n, model._shapes[n], seed, "opt") for n in names}
+            for n in names:
+                arr = torch.from_numpy(futs.pop(n).result())
+                model.load_named_tensors(lambda _n, a=arr: a, names=[n], refresh=False)
+        model.refresh_derived(force=True)
+        vllm = BLIP2OPTForEdit(None, dev, model=model, tokenizer=IdTokenizer())
+        proc = vllm.image_processor
+        cyc = evqa_cycles(2, cfg["text_config"]["vocab_size"], seed + 1,
+                          lambda s, tag: torch.from_numpy(proc(synth_image_u8(s, tag, 224, seed))).to(dev))
+        mc = MENDvlConfig.from_yaml(os.path.join(root, "de-vqa_amd", "configs", "mend_vl", "blip2-opt-2.7b.yaml"))
+        tm = {"aux_models": {k: v.clone() for k, v in aux.items()}, "edit_lrs": {str(i): torch.tensor(1e-4) for i in range(6)}}
+        ed = MENDvl(vllm, mc, dev, train_modules=tm)
+        assert BatchedMendEval.supports(ed, [[c] for c in cyc], 1)
+        be = BatchedMendEval(ed, cycles_per_batch=2)
+        be.keep_debug = True
+        res, _ = be.run_batch([copy_sample(c) for c in cyc], cyc)
+        torch.cuda.synchronize()
+        out[mode] = dict(rows=be.debug["rows"], pre=be.debug["pre_logits"].float().cpu(), post=be.debug["post_logits"].float().cpu(),
+                         losses=np.array(be.last_losses, dtype=np.float64), res=res)
+        del be, ed, vllm, model
+        torch.cuda.empty_cache()
+    return out
+
+
+def test_fulldepth_mend_bf16_vs_fp32_mode(runs):
+    a, b = runs["fp32"], runs["bf16"]
+    assert a["rows"] == b["rows"]
+    worst = {"pre": 0.0, "post": 0.0}
+    moved = 0.0
+    n_dec = n_dec_ok = 0
+    for plist in a["rows"]:
+        for kind, name, row0, L in plist:
+            for phase in (("pre", "post") if kind == "loc" else ("post",)):
+                ref, got = a[phase][row0:row0 + L], b[phase][row0:row0 + L]
+                scale = float(ref.abs().max())
+                worst[phase] = max(worst[phase], float((got - ref).abs().max()) / scale)
+                top2 = ref.topk(2, dim=1).values
+                dec = (top2[:, 0] - top2[:, 1]) > 2e-2 * scale
+                ok = got.argmax(1) == ref.argmax(1)
+                n_dec += int(dec.sum())
+                n_dec_ok += int((ok & dec).sum())
+            if kind == "loc":
+                moved = max(moved, float((a["post"][row0:row0 + L] - a["pre"][row0:row0 + L]).abs().max()) / float(a["pre"][row0:row0 + L].abs().max()))
+    loss_err = float((np.abs(b["losses"] - a["losses"]) / np.maximum(a["losses"], 1.0)).max())
+    print("full depth 39/12/32 + MEND_VL (layers 29-31), bf16 mode vs fp32 mode: label-row logits rel err pre %.3g post %.3g; edit loss err %.3g "
+          "(fp32 %s); the edit moved the locality logits by %.3g of their scale; argmax %d/%d where the fp32 margin > 2e-2 x scale"
+          % (worst["pre"], worst["post"], loss_err, a["losses"].tolist(), moved, n_dec_ok, n_dec))
+    # the same random walk of independent bf16 roundings as FT_VL's full-depth test (tests/test_fulldepth_gpu.py: 1.1e-2 on the logits);
+    # the post-edit rows add the rounding of the low-rank deltas' operands
+    assert worst["pre"] < 1.5e-2
+    assert worst["post"] < 2e-2
+    assert loss_err < 2.5e-2
+    assert n_dec_ok == n_dec
+
+
+def test_fulldepth_mend_results_agree(runs):
+    def flat(res):
+        out = []
+        for r in res:
+            out.append(round(r["reliability"][0]["acc"], 4))
+            out += [round(r["generality"][k][0]["acc"], 4) for k in ("text_rephrase", "image_rephrase")]
+            out += [round(r["locality"][k][0]["acc"], 4) for k in LOC]
+        return out
+    fa, fb = flat(runs["fp32"]["res"]), flat(runs["bf16"]["res"])
+    same = sum(x == y for x, y in zip(fa, fb))
+    print("full depth MEND_VL: probes with equal acc in both modes: %d/24" % same)
+    assert same >= 23
