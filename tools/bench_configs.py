@@ -280,15 +280,14 @@ def _hash_encode(sentences, dim=384):
     return out
 
 
-def minigpt4_ike(n=4):
-    """config #5 on one GPU: MiniGPT-4 (EVA ViT-g + Q-Former + Vicuna-7B dims) + IKE_VL, k = 32 over a 15000 x 384 corpus"""
+def _ike_editor(mode="bf16"):
+    """MiniGPT-4 (EVA ViT-g + Q-Former + Vicuna-7B dims, synthetic weights) + IKE_VL over a synthetic 15000 x 384 corpus -> (editor, tokenizer, config)"""
     from transformers import AutoTokenizer
     from devqa_amd.minigpt4_spec import MINIGPT4_VICUNA_7B
     from devqa_amd.editor.vllms_for_edit.minigpt4.modeling import MiniGPT4Native
     from devqa_amd.editor.vllms_for_edit.minigpt4.minigpt4 import MiniGPT4ForEdit
     from devqa_amd.editor.vllm_editors.ike_vl.ike_vl import IKEvl, IKEvlConfig
-    t0 = time.time()
-    model = MiniGPT4Native(MINIGPT4_VICUNA_7B, DEV, "bf16")
+    model = MiniGPT4Native(MINIGPT4_VICUNA_7B, DEV, mode)
     fill(model, 5, "llava")
     tok = AutoTokenizer.from_pretrained(os.path.join(GOLD, "tiny_llava"))
     vllm = MiniGPT4ForEdit(None, DEV, True, model=model, tokenizer=tok)
@@ -296,7 +295,13 @@ def minigpt4_ike(n=4):
     sents = ["New Fact: fact %d is %d\nPrompt: fact %d is %d\n\n" % (i, i * 7 % 13, i, i * 7 % 13) for i in range(N)]
     corpus = {"sentences": sents, "embeddings": np.random.default_rng(1).standard_normal((N, 384), dtype=np.float32)}
     cfg = IKEvlConfig.from_yaml(os.path.join(ROOT, "de-vqa_amd", "configs", "ike_vl", "minigpt-4-vicuna-7b.yaml"))
-    ed = IKEvl(vllm, cfg, DEV, corpus, _hash_encode)
+    return IKEvl(vllm, cfg, DEV, corpus, _hash_encode), tok, cfg
+
+
+def minigpt4_ike(n=4):
+    """config #5 on one GPU: MiniGPT-4 (EVA ViT-g + Q-Former + Vicuna-7B dims) + IKE_VL, k = 32 over a 15000 x 384 corpus"""
+    t0 = time.time()
+    ed, tok, cfg = _ike_editor()
     build_s = time.time() - t0
     cps, dt, res = run_eval(ed, n, None, distinct_image_size=224)
     # the in-context prefix (k = 32 retrieved demonstrations + the new fact, `demo_rows` token rows) stands BEHIND the image rows of a probe
