@@ -225,7 +225,7 @@ static int gemm_mode() {
     if (m < 0) {
         const char* e = getenv("DEVQA_GEMM");
         int want = e ? atoi(e) : 0;
-        if (want < 0 || (want > 3 && (want < 10 || want > 26))) want = 0;
+        if (want < 0 || (want > 3 && (want < 10 || want > 28))) want = 0;
         int expect = -1;
         g_gemm_mode_a.compare_exchange_strong(expect, want);
         m = g_gemm_mode_a.load(std::memory_order_relaxed);
@@ -233,7 +233,7 @@ static int gemm_mode() {
     return m;
 }
 extern "C" int devqa_gemm_set_mode(int mode) {
-    if (mode < 0 || (mode > 3 && (mode < 10 || mode > 27))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
+    if (mode < 0 || (mode > 3 && (mode < 10 || mode > 28))) return devqa_fail(DEVQA_E_ARG, "gemm_set_mode: bad mode %d", mode);
     g_gemm_mode_a.store(mode);
     return DEVQA_OK;
 }

@@ -32,6 +32,15 @@ constexpr int PP_HALF = 16384;         // bytes of one half-tile
 constexpr int PP_BUF = 4 * PP_HALF;    // bytes of one K-tile buffer
 enum { R_A0 = 0, R_A1 = 1, R_B0 = 2, R_B1 = 3 };
 
+// threadIdx.x behind an asm the optimiser cannot look through: inside the persistent form's tile loop every per-lane quantity (staging offsets,
+// fragment addresses, epilogue rows) is then computed per tile instead of being hoisted out of the loop, where it would live across the K loop
+// beside 128 accumulator registers (measured: 52-64 VGPRs spilled without this)
+__device__ __forceinline__ int pp_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 struct PPState {
     const char* gA;            // uniform base pointers (K-tile 0)
     const char* gW;
@@ -130,6 +139,51 @@ __device__ __forceinline__ void pp_tile(const PPState& s, int t, float4_t (&acc)
     __builtin_amdgcn_s_barrier();
 }
 
+
+// K-tile 0 of a tile whose four half-tiles were staged BEFORE the previous tile's epilogue (persistent form) and are known to have landed: the phases
+// stage as always (slots 0-3), but phases 0-2 do not wait -- the epilogue's stores are still in flight, they count in vmcnt like the loads, and a wait
+// for "all but the 8 youngest" would wait for them.  Nothing read in this K-tile depends on a wait; phase 3 has the usual one (what K-tile 1's
+// phase 0 reads -- A0, B0 of K-tile 1, staged just before this K-tile -- is older than the 8 youngest loads by then).
+__device__ __forceinline__ void pp_tile_pre0(const PPState& s, float4_t (&acc)[8][4], short8_t (&a)[4][2], short8_t (&b0)[2][2], short8_t (&b1)[2][2]) {
+    const unsigned char* base = s.smem;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        b0[j][0] = *reinterpret_cast<const short8_t*>(base + R_B0 * PP_HALF + j * 2048 + s.lb0);
+        b0[j][1] = *reinterpret_cast<const short8_t*>(base + R_B0 * PP_HALF + j * 2048 + s.lb1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i][0] = *reinterpret_cast<const short8_t*>(base + R_A0 * PP_HALF + i * 2048 + s.la0);
+        a[i][1] = *reinterpret_cast<const short8_t*>(base + R_A0 * PP_HALF + i * 2048 + s.la1);
+    }
+    pp_stage<R_B1>(s, 1);
+    __builtin_amdgcn_s_barrier();
+    pp_mfma_block(acc, a, b0, 0, 0);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        b1[j][0] = *reinterpret_cast<const short8_t*>(base + R_B1 * PP_HALF + j * 2048 + s.lb0);
+        b1[j][1] = *reinterpret_cast<const short8_t*>(base + R_B1 * PP_HALF + j * 2048 + s.lb1);
+    }
+    pp_stage<R_A1>(s, 1);
+    __builtin_amdgcn_s_barrier();
+    pp_mfma_block(acc, a, b1, 0, 2);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i][0] = *reinterpret_cast<const short8_t*>(base + R_A1 * PP_HALF + i * 2048 + s.la0);
+        a[i][1] = *reinterpret_cast<const short8_t*>(base + R_A1 * PP_HALF + i * 2048 + s.la1);
+    }
+    pp_stage<R_A0>(s, 2);
+    __builtin_amdgcn_s_barrier();
+    pp_mfma_block(acc, a, b1, 4, 2);
+    __builtin_amdgcn_s_barrier();
+    pp_stage<R_B0>(s, 2);
+    pp_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    pp_mfma_block(acc, a, b0, 4, 0);
+    __builtin_amdgcn_s_barrier();
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // HALF-WIDTH COLUMN TILE (the last column tile when N - n0 <= 128: N = 1408 is 5.5 tiles, 4224 is 16.5).  The same 2 x 4 wave
@@ -256,6 +310,8 @@ struct PPArgs {
     int bf16_fast;      // bf16-only output that qualifies for pp_epilogue_bf16
     int gelu_poly;      // bf16-stored GELU on the packed polynomial (variant 4; default 0: the erf form)
     int half_n;         // the last column tile runs the half-width schedule when N - n0 <= 128 (DEVQA_GEMM_HALFN=0 turns it off)
+    int persist;        // one workgroup per CU walks its XCD's tile list with stride (workgroups per XCD) instead of one workgroup per tile; 2: early staging
+    int persist_wgs;
 };
 
 // tile id -> (tile_m, tile_n): grouped order (group_m row-tiles of one column-tile, then the next column-tile), so the
@@ -269,10 +325,12 @@ __device__ __forceinline__ void pp_tile_coords(const PPArgs& g, int id, int& til
 }
 
 // K-tiles [k0, k0 + nk) of tile (tile_m, tile_n) -> acc.  Every wave executes the same number of barriers.
+// drain: the workgroup has stores of a previous tile's epilogue in flight (persistent form) -- they count in vmcnt beside the LDS-DMA loads and the two
+// kinds retire out of order, so the prologue waits for everything instead of for all but its 4 youngest half-tiles (the waits of the K loop only get laxer)
 template <bool BAL = false>
 __device__ __forceinline__ void pp_mainloop(const PPArgs& g, unsigned char* smem, int m0, int n0, int k0, int nk,
-                                            float4_t (&acc)[8][4]) {
-    const int tid = threadIdx.x;
+                                            float4_t (&acc)[8][4], const bool drain = false) {
+    const int tid = pp_tid();
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -314,9 +372,9 @@ __device__ __forceinline__ void pp_mainloop(const PPArgs& g, unsigned char* smem
     if (nk > 1) {
         pp_stage<BAL ? R_B0 : R_A0>(s, 1);
         pp_stage<BAL ? R_A0 : R_B0>(s, 1);
-        pp_vmcnt<8>();
+        if (drain) pp_vmcnt<0>(); else pp_vmcnt<8>();
     } else {
-        pp_vmcnt<4>();
+        if (drain) pp_vmcnt<0>(); else pp_vmcnt<4>();
     }
     __builtin_amdgcn_s_barrier();
     PP_STAMP(1);
@@ -338,6 +396,69 @@ __device__ __forceinline__ void pp_mainloop(const PPArgs& g, unsigned char* smem
     if (wr == 0) __builtin_amdgcn_s_barrier();   // match the extra barrier of waves 4-7
 }
 
+// ---- persistent form with the next tile's K-tile 0 staged under the current tile's epilogue -------------------------------------------------------
+// per-lane staging offsets and fragment addresses of tile (m0, n0), K-tiles from 0 (the set-up of pp_mainloop)
+__device__ __forceinline__ void pp_make_state(const PPArgs& g, unsigned char* smem, int m0, int n0, PPState& s) {
+    const int tid = pp_tid();
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    s.smem = smem;
+    s.gA = reinterpret_cast<const char*>(g.A);
+    s.gW = reinterpret_cast<const char*>(g.W);
+    s.dst = wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3);
+        const int sc = (lane & 7) ^ ((r >> 1) & 7);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int grow = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), g.M - 1);
+            const int gcol = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), g.N - 1);
+            s.off[h][i] = (unsigned)(((int64_t)grow * g.lda + sc * 8) * 2);
+            s.off[2 + h][i] = (unsigned)(((int64_t)gcol * g.ldw + sc * 8) * 2);
+        }
+    }
+    const int c0 = (fq ^ ((fr >> 1) & 7)) << 4;
+    s.la0 = wr * 8192 + fr * 128 + c0;
+    s.la1 = wr * 8192 + fr * 128 + (c0 ^ 64);
+    s.lb0 = wc * 4096 + fr * 128 + c0;
+    s.lb1 = wc * 4096 + fr * 128 + (c0 ^ 64);
+}
+
+// the four half-tiles of K-tile 0 -> buffer 0 ([0, 64 KiB)); the caller's epilogue stages through [64 KiB, 128 KiB)
+__device__ __forceinline__ void pp_stage_k0(const PPState& s) {
+    pp_stage<R_A0>(s, 0);
+    pp_stage<R_B0>(s, 0);
+    pp_stage<R_B1>(s, 0);
+    pp_stage<R_A1>(s, 0);
+}
+
+// K loop of a tile whose K-tile 0 is staged and has landed for THIS wave's pieces (waited for in the epilogue, in front of its first store); nk >= 3
+__device__ __forceinline__ void pp_mainloop_pre(const PPState& s, int nk, float4_t (&acc)[8][4]) {
+    const int wr = __builtin_amdgcn_readfirstlane(pp_tid() >> 6) >> 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    short8_t a[4][2], b0[2][2], b1[2][2], b0n[2][2];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // every wave: its epilogue staging reads are done (buffer 1 is free) and its pieces of K-tile 0 have landed
+    pp_stage<R_A0>(s, 1);
+    pp_stage<R_B0>(s, 1);
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier interval behind waves 0-3
+    pp_tile_pre0(s, acc, a, b0, b1);
+    int t = 1;
+    for (; t + 2 < nk; ++t) pp_tile<0>(s, t, acc, a, b0, b1, b0n);
+    if (t + 1 < nk) {
+        pp_tile<1>(s, t, acc, a, b0, b1, b0n);
+        ++t;
+    }
+    pp_tile<2>(s, t, acc, a, b0, b1, b0n);
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // match the extra barrier of waves 4-7
+}
+
 // Epilogue.  All LDS traffic of the K loop is over (last ds_read in phase 2 of the last tile, all LDS-DMA retired by the
 // vmcnt(0) of its phases 1-3, and every wave is past two more barriers).  Each wave transposes its 128x64 accumulator
 // tile through a PRIVATE 16-KiB LDS region, 64 rows at a time, so that global accesses are row-contiguous: a lane owns
@@ -351,7 +472,7 @@ __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem
     constexpr int RPI = 64 / LPR;           // rows per step
     constexpr int NIT = 64 / RPI;           // steps per 64-row half
     constexpr int RB = NJ * 64;             // staging row bytes
-    const int tid = threadIdx.x;
+    const int tid = pp_tid();
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -424,20 +545,24 @@ __device__ __forceinline__ void pp_epilogue(const PPArgs& g, unsigned char* smem
 // 16-byte global stores (8 lanes cover the wave's 128-byte row segment).  Staging: per wave 2 x [64 rows][128 B], the 16-byte
 // chunk index XOR-swizzled with (row >> 1) & 7: the b64 writes of 16 rows x 2 lanes and the b128 reads of 2 rows x 8 lanes are
 // both bank-conflict-free.  Needs N % 8 == 0, ldc % 8 == 0 and a 16-byte aligned output (checked on the host: g.bf16_fast).
-template <int ACT, bool HALF = false>
-__device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char* smem, int m0, int n0, const float4_t (&acc)[8][4]) {
+// PRE (persistent form): the next tile's K-tile 0 is in flight into [0, 64 KiB): one 8-KiB staging area per wave in [64 KiB, 128 KiB) serves both
+// 64-row halves (a wave's LDS operations execute in order), and the wave waits for its pieces of that K-tile in front of its first global store --
+// from there on its vmcnt counts stores, which the next tile's first phases must not wait for (pp_tile_pre0).
+template <int ACT, bool HALF = false, bool PRE = false>
+__device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char* smem, int m0, int n0, const float4_t (&acc)[8][4],
+                                                 const PPState* next = nullptr) {
     constexpr int NJ = HALF ? 2 : 4;        // 16-column blocks of the wave tile (HALF: 128 x 32, a row is 64 B = 4 lanes)
     constexpr int RB = NJ * 32;             // staging row bytes
     constexpr int LPR = NJ * 2;             // lanes per row (16 B each)
     constexpr int RPI = 64 / LPR;           // rows per step
     constexpr int NIT = 64 / RPI;           // steps per 64-row half
     constexpr int SWM = LPR - 1;            // chunk swizzle mask
-    const int tid = threadIdx.x;
+    const int tid = pp_tid();
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
-    unsigned char* stg = smem + wave * 16384;
+    unsigned char* stg = PRE ? smem + 65536 + wave * 8192 : smem + wave * 16384;
     const float alpha = g.alpha;
     float4 bj[NJ];
 #pragma unroll
@@ -446,9 +571,14 @@ __device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char*
         bj[j] = (g.bias != nullptr && col < g.N) ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int rrow = lane / LPR, pc = lane % LPR;
+    if constexpr (PRE) {     // the bias values are in registers BEFORE the successor's K-tile 0 is staged: a wait for them behind the LDS-DMA would wait for it too
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(bj[j].x), "+v"(bj[j].y), "+v"(bj[j].z), "+v"(bj[j].w));
+        pp_stage_k0(*next);
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        unsigned char* area = stg + half * 8192;
+        unsigned char* area = PRE ? stg : stg + half * 8192;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = i * 16 + fr;
@@ -468,13 +598,29 @@ __device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char*
                 uint2 p;
                 p.x = pp_pack2(v0, v1);
                 p.y = pp_pack2(v2, v3);
-                *reinterpret_cast<uint2*>(area + row * RB + (((j * 2 + (fq >> 1)) ^ sw) << 4) + (fq & 1) * 8) = p;
+                if constexpr (PRE) {     // an asm write: behind an LDS-DMA the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS store it can see
+                                         // (it cannot tell that the staging area and the DMA's buffer 0 are disjoint) -- the wait for the K-tile in flight
+                    const uint32_t la = (uint32_t)reinterpret_cast<uintptr_t>((lptr_t)(area + row * RB + (((j * 2 + (fq >> 1)) ^ sw) << 4) + (fq & 1) * 8));
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(la), "v"(p) : "memory");
+                } else {
+                    *reinterpret_cast<uint2*>(area + row * RB + (((j * 2 + (fq >> 1)) ^ sw) << 4) + (fq & 1) * 8) = p;
+                }
             }
+        }
+        if constexpr (PRE) {
+            if (half == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's pieces of the next tile's K-tile 0 (+ the asm LDS writes)
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int row = it * RPI + rrow;
-            const uint4 val = *reinterpret_cast<const uint4*>(area + row * RB + (pc << 4));
+            uint4 val;
+            if constexpr (PRE) {     // (asm for the same reason as the writes: a visible LDS read behind the DMA gets a vmcnt(0), i.e. waits for the previous store)
+                const uint32_t la = (uint32_t)reinterpret_cast<uintptr_t>((lptr_t)(area + row * RB + (pc << 4)));
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(val) : "v"(la) : "memory");
+            } else {
+                val = *reinterpret_cast<const uint4*>(area + row * RB + (pc << 4));
+            }
             const int gm = m0 + wr * 128 + half * 64 + row;
             const int gcol = n0 + wc * (NJ * 16) + ((pc ^ ((row >> 1) & SWM)) << 3);
             if (gm < g.M && gcol < g.N) *reinterpret_cast<uint4*>(g.out_bf16 + (int64_t)gm * g.ldc + gcol) = val;
@@ -487,7 +633,7 @@ __device__ __forceinline__ void pp_epilogue_bf16(const PPArgs& g, unsigned char*
 // layout, then the half-width bf16 transposition (2 x [64 rows][64 B] per wave, 4 lanes per row) and 16-byte stores into the [M, N / 2] output.
 __device__ __forceinline__ void pp_epilogue_swiglu(const PPArgs& g, unsigned char* smem, int m0, int n0, const float4_t (&acc)[8][4]) {
     constexpr int RB = 64, LPR = 4, RPI = 16, NIT = 4, SWM = 3;
-    const int tid = threadIdx.x;
+    const int tid = pp_tid();
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -527,8 +673,9 @@ __device__ __forceinline__ void pp_epilogue_swiglu(const PPArgs& g, unsigned cha
 
 // Half-width column tile: K-tiles [0, nk) of rows [m0, m0 + 256) x columns [n0, n0 + 128) -> acc[.][0..1] (wave (wr, wc): rows
 // wr * 128 + 0..127, columns wc * 32 + 0..31).  Same barrier count for every wave.
-__device__ __forceinline__ void pp_mainloop_half(const PPArgs& g, unsigned char* smem, int m0, int n0, int nk, float4_t (&acc)[8][4]) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void pp_mainloop_half(const PPArgs& g, unsigned char* smem, int m0, int n0, int nk, float4_t (&acc)[8][4],
+                                                 const bool drain = false) {
+    const int tid = pp_tid();
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -570,9 +717,9 @@ __device__ __forceinline__ void pp_mainloop_half(const PPArgs& g, unsigned char*
         pph_stage<H_A0>(s, 1, 1);
         pph_stage<H_B0>(s, 1, 1);
         pph_stage<H_A1>(s, 1, 1);
-        pp_vmcnt<8>();
+        if (drain) pp_vmcnt<0>(); else pp_vmcnt<8>();
     } else {
-        pp_vmcnt<2>();
+        if (drain) pp_vmcnt<0>(); else pp_vmcnt<2>();
     }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier interval behind waves 0-3
@@ -591,14 +738,19 @@ __device__ __forceinline__ void pp_mainloop_half(const PPArgs& g, unsigned char*
     if (wr == 0) __builtin_amdgcn_s_barrier();   // match the extra barrier of waves 4-7
 }
 
-template <int ACT, bool SK, bool BAL = false>
+template <int ACT, bool SK, bool BAL = false, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4_t acc[8][4];
     const int nk = g.K / PP_BK;
     const int tid = threadIdx.x;
     PP_STAMP(0);
-    if constexpr (!SK) {   // one whole tile per workgroup: the default
+#ifdef PP_TIMING
+    if (threadIdx.x == 0)      // which CU ran this workgroup: XCC_ID (hwreg 20) and the SE / SH / CU fields of HW_ID (hwreg 4)
+        reinterpret_cast<unsigned long long*>(g.ws)[blockIdx.x * 8 + 4] =
+            ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xff00);
+#endif
+    if constexpr (!SK && !PERSIST) {   // one whole tile per workgroup: the default
         const int bid = blockIdx.x, nwg = g.dp_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         int tile_m, tile_n;
         pp_tile_coords(g, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx, tile_m, tile_n);
@@ -615,6 +767,57 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
         else pp_epilogue<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_STAMP(3);
+        return;
+    }
+    if constexpr (!SK && PERSIST) {
+        // Persistent form (A/B: id 8): one workgroup per CU walks its XCD's contiguous tile list with stride (workgroups per XCD).  When a tile and
+        // its successor are both full-width and the output takes the packed-bf16 epilogue (g.persist == 2), the successor's K-tile 0 is staged into
+        // buffer 0 BEFORE the epilogue, which then stages through buffer 1 (PRE forms above); otherwise the tiles simply follow each other.
+        const int bid = blockIdx.x, nwg = g.dp_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx0 = bid >> 3;
+        const int cnt = q + (xcd < r ? 1 : 0), base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int step = (int)(gridDim.x >> 3);
+        const bool can_pre = ACT != DEVQA_ACT_SWIGLU_IL16 && g.bf16_fast && g.persist == 2 && nk >= 3;
+        PPState sn;
+        bool pre = false;                  // this tile's K-tile 0 was staged under the previous tile's epilogue (its state is sn)
+        for (int idx = idx0; idx < cnt; idx += step) {
+            int tile_m, tile_n;
+            pp_tile_coords(g, base + idx, tile_m, tile_n);
+            const int m0 = tile_m * PP_BM, n0 = tile_n * PP_BN;
+            const bool half = ACT != DEVQA_ACT_SWIGLU_IL16 && g.half_n && g.N - n0 <= PP_BN / 2;
+            if (pre) {
+                pp_mainloop_pre(sn, nk, acc);
+            } else {
+                const bool drain = idx != idx0;
+                if (drain) {     // every wave is done reading its epilogue staging (the stores that consumed those reads are issued): the prologue's
+                                 // LDS-DMA restages all of it.  NOT __syncthreads(): its fence would wait for the stores to be acknowledged
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (half) pp_mainloop_half(g, smem, m0, n0, nk, acc, drain);
+                else pp_mainloop<BAL>(g, smem, m0, n0, 0, nk, acc, drain);
+            }
+            // the successor, if it can be staged early
+            pre = false;
+            if (can_pre && idx + step < cnt) {
+                int nm, nn;
+                pp_tile_coords(g, base + idx + step, nm, nn);
+                if (!(g.half_n && g.N - nn * PP_BN <= PP_BN / 2)) {
+                    pp_make_state(g, smem, nm * PP_BM, nn * PP_BN, sn);      // (staged inside the PRE epilogue, behind its bias loads)
+                    pre = true;
+                }
+            }
+            if (half) {
+                if (g.bf16_fast) { if (pre) pp_epilogue_bf16<ACT, true, true>(g, smem, m0, n0, acc, &sn); else pp_epilogue_bf16<ACT, true>(g, smem, m0, n0, acc); }
+                else pp_epilogue<ACT, true>(g, smem, m0, n0, acc);
+            } else if constexpr (ACT == DEVQA_ACT_SWIGLU_IL16) {
+                pp_epilogue_swiglu(g, smem, m0, n0, acc);
+            } else if (g.bf16_fast) {
+                if (pre) pp_epilogue_bf16<ACT, false, true>(g, smem, m0, n0, acc, &sn); else pp_epilogue_bf16<ACT>(g, smem, m0, n0, acc);
+            } else {
+                pp_epilogue<ACT>(g, smem, m0, n0, acc);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
     // Every workgroup walks a range [it, it1) of the (tile, K-tile) iteration space.  A data-parallel workgroup owns
@@ -685,13 +888,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
     }
 }
 
-template <int ACT, bool SK, bool BAL = false>
+template <int ACT, bool SK, bool BAL = false, bool PERSIST = false>
 static int launch_pp_k(const PPArgs& g, hipStream_t st) {
     const size_t smem = g.half_n ? 3 * PPH_BUF : 2 * PP_BUF;      // 144 KiB when the launch has a half-width column tile, else 128 KiB
-    auto kern = gemm_bf16_pp_kernel<ACT, SK, BAL>;
+    auto kern = gemm_bf16_pp_kernel<ACT, SK, BAL, PERSIST>;
     static std::atomic<unsigned> attr_done{0};
     devqa_set_max_smem(kern, 3 * PPH_BUF, attr_done);
-    hipLaunchKernelGGL(kern, dim3(g.dp_tiles + g.sk_wgs), dim3(512), smem, st, g);
+    hipLaunchKernelGGL(kern, dim3(g.persist ? g.persist_wgs : g.dp_tiles + g.sk_wgs), dim3(512), smem, st, g);
     DEVQA_LAUNCH_CHECK("gemm_bf16_pp");
     return DEVQA_OK;
 }
@@ -703,11 +906,13 @@ static int launch_pp(const PPArgs& g, hipStream_t st) {
         h.group_m = -g.group_m;
         return launch_pp_k<ACT, false, true>(h, st);
     }
+    if (g.persist) return launch_pp_k<ACT, false, false, true>(g, st);
     return launch_pp_k<ACT, false>(g, st);
 }
 
 // id 6: group_m 4 with the fp32 LDS transposition for every output kind (A/B of pp_epilogue_bf16).
 // id 7: group_m 4 with a full-width schedule on every column tile (A/B of the half-width last column tile).
+// id 8: group_m 4, persistent form (one workgroup per CU walks its XCD's tile list).
 // id: 0 group_m 8, 1 group_m 1 (plain column-major tile order), 2 group_m 4 (default), 3 group_m 16,
 //     4 = 2 (was: group_m 4 + a stream-K tail.  The partial-tile hand-off -- 256 KiB per segment through HBM/L2 plus an
 //       agent-scope acq_rel RMW whose release/acquire writes back / invalidates the XCD's L2 -- cost more than the partial round it
@@ -716,8 +921,8 @@ static int launch_pp(const PPArgs& g, hipStream_t st) {
 //       is kept but no longer instantiated.)
 int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, int M, int N, int K, float alpha,
                    int act, const float* residual, bf16_t* out_bf16, float* out_f32, int64_t ldc, hipStream_t st) {
-    static const int gms[8] = {8, 1, 4, 16, 4, -4, 4, 4};
-    if (id < 0 || id > 7) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
+    static const int gms[9] = {8, 1, 4, 16, 4, -4, 4, 4, 4};
+    if (id < 0 || id > 8) return devqa_fail(DEVQA_E_ARG, "gemm_pp: unknown variant %d", id);
     if (K % PP_BK != 0 || K < PP_BK) return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: K=%d must be a positive multiple of 64", K);
     if ((int64_t)M * lda * 2 >= (1ll << 32) || (int64_t)N * ldw * 2 >= (1ll << 32))
         return devqa_fail(DEVQA_E_SHAPE, "gemm_pp: operands must span < 4 GiB (32-bit lane offsets)");
@@ -735,6 +940,11 @@ int launch_gemm_pp(int id, const bf16_t* A, int64_t lda, const bf16_t* W, int64_
     g.gelu_poly = id == 4;              // variant 4 (DEVQA_GEMM=24): bf16-stored GELU on the packed polynomial
     static const int halfn_env = getenv("DEVQA_GEMM_HALFN") ? atoi(getenv("DEVQA_GEMM_HALFN")) : 1;
     g.half_n = halfn_env && id != 7 && g.group_m > 0 && N - (g.tiles_n - 1) * PP_BN <= PP_BN / 2;     // id 7: A/B without it
+    // persistent form (DEVQA_GEMM_PERSIST=1): as many workgroups as CUs (a workgroup's 128-144 KiB of LDS leave room for one per CU), multiple of 8
+    static const int persist_env = getenv("DEVQA_GEMM_PERSIST") ? atoi(getenv("DEVQA_GEMM_PERSIST")) : 0;
+    static const int n_cu = [] { int dev = 0, n = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n & ~7; }();
+    g.persist = ((persist_env || id == 8) && id != 5 && n_cu >= 8 && T > n_cu) ? (id == 8 ? 2 : persist_env) : 0;      // id 8 (DEVQA_GEMM=28): A/B of the persistent form
+    g.persist_wgs = n_cu;
     switch (act) {
         case DEVQA_ACT_NONE: return launch_pp<DEVQA_ACT_NONE>(g, st);
         case DEVQA_ACT_RELU: return launch_pp<DEVQA_ACT_RELU>(g, st);
@@ -779,6 +989,7 @@ int main() {
         g.tiles_m = (sh.M + 255) / 256; g.tiles_n = (sh.N + 255) / 256; g.group_m = 4; g.dp_tiles = T; g.sk_wgs = 0; g.sk_per = 1; g.sk_max_seg = 1;
         g.ws = (float*)st; g.counters = nullptr; g.bf16_fast = !sh.resid; g.gelu_poly = 0;
         g.half_n = sh.N - (g.tiles_n - 1) * 256 <= 128;
+        g.persist = 0; g.persist_wgs = 0;
         for (int rep = 0; rep < 5; ++rep) launch_pp_k<DEVQA_ACT_NONE, false>(g, nullptr);
         hipDeviceSynchronize();
         std::vector<unsigned long long> hs((size_t)T * 8);
@@ -791,6 +1002,19 @@ int main() {
             epi.push_back((double)(hs[t * 8 + 3] - hs[t * 8 + 2]));
         }
         auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        // the gap a CU leaves between the end of one workgroup and the start of the next one it runs (same counter: one XCD)
+        std::vector<double> gap;
+        {
+            std::vector<std::pair<unsigned long long, int>> order;
+            for (int t = 0; t < T; ++t) order.push_back({(hs[t * 8 + 4] << 44) | (hs[t * 8 + 0] & ((1ull << 44) - 1)), t});
+            std::sort(order.begin(), order.end());
+            for (size_t i = 1; i < order.size(); ++i) {
+                const int a = order[i - 1].second, b = order[i].second;
+                if (hs[a * 8 + 4] == hs[b * 8 + 4]) gap.push_back((double)hs[b * 8 + 0] - (double)hs[a * 8 + 3]);
+            }
+        }
+        const double gp = gap.empty() ? 0.0 : med(gap);
+        printf("%-8s CU hand-over gap (end of a workgroup -> start of the next on the same CU): median %.0f cycles over %zu pairs\n", sh.name, gp, gap.size());
         const double p = med(pro), l = med(loop), e = med(epi);
         printf("%-8s M=%d N=%d K=%d: median shader cycles per tile: prologue %.0f (%.1f%%)  main loop %.0f (%.1f%%)  epilogue %.0f (%.1f%%)  | MFMA issue floor %d\n",
                sh.name, sh.M, sh.N, sh.K, p, 100 * p / (p + l + e), l, 100 * l / (p + l + e), e, 100 * e / (p + l + e), sh.K / 64 * 2048);

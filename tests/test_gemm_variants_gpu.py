@@ -16,7 +16,7 @@ def L():
     lib.gemm_set_mode(0)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28])
 @pytest.mark.parametrize("M,N,K,act,res", [
     (4099, 4224, 1408, 0, False),     # 128x128 (mode 0/1) or 256x128 (mode 2); ragged M
     (16448, 1408, 6144, 0, True),     # ViT fc2 shape, in-place residual
@@ -57,8 +57,9 @@ def test_gemm_variants(L, mode, M, N, K, act, res):
     (1030, 1408, 1408, 0, True, "f32"),     # ViT projection
     (600, 200, 320, 3, True, "both"),       # both outputs + residual, quick-GELU, ragged half tile (72 columns)
 ])
-def test_gemm_half_width_column_tile(L, M, N, K, act, res, want):
-    L.gemm_set_mode(22)
+@pytest.mark.parametrize("mode", [22, 28])
+def test_gemm_half_width_column_tile(L, M, N, K, act, res, want, mode):
+    L.gemm_set_mode(mode)
     g = torch.Generator().manual_seed(M + 3 * N + K)
     a = torch.randn(M, K, generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
@@ -137,7 +138,7 @@ def test_gemm_bf16_output_epilogues(L, M, N, K, act, bias, alpha):
     ref = ref * alpha
     ref = {0: lambda t: t, 1: torch.relu, 2: torch.nn.functional.gelu, 3: lambda t: t * torch.sigmoid(1.702 * t)}[act](ref)
     outs = {}
-    for mode in (22, 24, 26):
+    for mode in (22, 24, 26, 28):
         L.gemm_set_mode(mode)
         guard = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device="cuda")      # rows before / after must stay untouched
         o = guard[1:M + 1]
@@ -149,6 +150,7 @@ def test_gemm_bf16_output_epilogues(L, M, N, K, act, bias, alpha):
     # 22 = production (packed bf16 epilogue), 26 = fp32 transposition epilogue: bit-identical.  24 = the opt-in packed-polynomial GELU
     # (|Phi error| <= 1.3e-5, csrc/gemm_bf16_pp.hip): equal up to one bf16 rounding step of the stored value, on < 2 % of the values
     assert torch.equal(outs[22], outs[26])
+    assert torch.equal(outs[22], outs[28])      # 28 = the persistent form (a workgroup per CU, the successor's K-tile 0 staged under the epilogue)
     if act == 2:
         d = (outs[24].float() - outs[26].float()).abs()
         assert float((d - 2.0 ** -7 * outs[26].float().abs()).max()) <= 6e-5, float(d.max())
