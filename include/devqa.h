@@ -78,7 +78,7 @@ int devqa_gemm_bf16_splitk(const devqa_bf16* A, int64_t lda, const devqa_bf16* W
 
 /* Kernel selection for A/B measurements: 0 = default (LDS-DMA staged tiles when K % 64 == 0 -- 256x256 for
  * large problems, 128x128 / 64x128 below -- register-staged otherwise), 1 = always register-staged,
- * 2 = LDS-DMA staged without the 256x256 tile, 10..17 = experimental ring variants (csrc/gemm_bf16_pipe.hip), 20..27 = the 256x256
+ * 2 = LDS-DMA staged without the 256x256 tile, 10..17 = experimental ring variants (csrc/gemm_bf16_pipe.hip), 20..28 = the 256x256
  * ping-pong kernel forced, with its tile orders / epilogue A/B switches (csrc/gemm_bf16_pp.hip: launch_gemm_pp).
  * Every variant issues the same MFMA sequence per output element, so results are bit-identical. */
 int devqa_gemm_set_mode(int mode);
