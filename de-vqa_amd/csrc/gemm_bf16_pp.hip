@@ -18,8 +18,10 @@
 
 #ifdef PP_TIMING   /* hipcc -DPP_TIMING gemm_bf16_pp.hip -o build/pp_timing: where a tile's time goes (debug builds only) */
 #define PP_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(g.ws)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PP_STAMP_RT(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(g.ws)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PP_STAMP(i) do { } while (0)
+#define PP_STAMP_RT(i) do { } while (0)
 #endif
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -745,6 +747,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
     const int nk = g.K / PP_BK;
     const int tid = threadIdx.x;
     PP_STAMP(0);
+    PP_STAMP_RT(5);
 #ifdef PP_TIMING
     if (threadIdx.x == 0)      // which CU ran this workgroup: XCC_ID (hwreg 20) and the SE / SH / CU fields of HW_ID (hwreg 4)
         reinterpret_cast<unsigned long long*>(g.ws)[blockIdx.x * 8 + 4] =
@@ -767,6 +770,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
         else pp_epilogue<ACT>(g, smem, tile_m * PP_BM, tile_n * PP_BN, acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_STAMP(3);
+        PP_STAMP_RT(6);
         return;
     }
     if constexpr (!SK && PERSIST) {
@@ -818,6 +822,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const PPArgs g) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_STAMP(3);
+        PP_STAMP_RT(6);
         return;
     }
     // Every workgroup walks a range [it, it1) of the (tile, K-tile) iteration space.  A data-parallel workgroup owns
@@ -1018,6 +1024,35 @@ int main() {
         const double p = med(pro), l = med(loop), e = med(epi);
         printf("%-8s M=%d N=%d K=%d: median shader cycles per tile: prologue %.0f (%.1f%%)  main loop %.0f (%.1f%%)  epilogue %.0f (%.1f%%)  | MFMA issue floor %d\n",
                sh.name, sh.M, sh.N, sh.K, p, 100 * p / (p + l + e), l, 100 * l / (p + l + e), e, 100 * e / (p + l + e), sh.K / 64 * 2048);
+        // in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): shader cycles per 100-MHz real-time tick, per workgroup, and the launch time by
+        // HIP events -- the one-tile-per-workgroup form against the persistent form (bf16 outputs: with the successor's K-tile 0 staged under the epilogue)
+        for (int form = 0; form < 2; ++form) {
+            int ncu = 0;
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
+            g.persist = form ? 2 : 0;
+            g.persist_wgs = ncu & ~7;
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            auto run = [&] { if (form) launch_pp_k<DEVQA_ACT_NONE, false, false, true>(g, nullptr); else launch_pp_k<DEVQA_ACT_NONE, false>(g, nullptr); };
+            for (int rep = 0; rep < 200; ++rep) run();          // ~0.2 s of back-to-back launches before the measured ones
+            hipEventRecord(e0, nullptr);
+            for (int rep = 0; rep < 20; ++rep) run();
+            hipEventRecord(e1, nullptr);
+            hipDeviceSynchronize();
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            const int nw = form ? g.persist_wgs : T;
+            std::vector<unsigned long long> h2((size_t)nw * 8);
+            hipMemcpy(h2.data(), st, h2.size() * 8, hipMemcpyDeviceToHost);
+            std::vector<double> clk, cyc;
+            for (int w = 0; w < nw; ++w) {
+                const double c = (double)(h2[w * 8 + 3] - h2[w * 8 + 0]), rt = (double)(h2[w * 8 + 6] - h2[w * 8 + 5]);
+                if (rt > 0) { clk.push_back(c / rt * 0.1); cyc.push_back(c); }
+            }
+            printf("%-8s %s: %.1f us per launch; in-kernel clock %.3f GHz (median over workgroups); shader cycles per workgroup %.0f (%s)\n", sh.name,
+                   form ? "persistent form" : "one tile per workgroup", ms * 1e3 / 20, med(clk), med(cyc), form ? "all its tiles" : "one tile");
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
         hipFree(A); hipFree(W); hipFree(ob); hipFree(of); hipFree(bias); hipFree(st);
     }
     return 0;
