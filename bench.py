@@ -500,7 +500,7 @@ def timed_leg(leg, K, W, barrier, use_dist, rank, world, dev, scaling=None, tota
         leg.run(warm, not a.no_pipeline)
     leg.reset_stats()
     barrier()
-    lib.profile(1)
+    lib.profile(0 if os.environ.get("DEVQA_BENCH_NOPROF") else 1)      # (DEVQA_BENCH_NOPROF=1: A/B of what the per-launch event pairs cost)
     t0 = time.time()
     outs, metas = leg.run(timed, not a.no_pipeline)
     barrier()
