@@ -41,6 +41,9 @@ SPARSE_RECIPE = ("synthetic weights, numpy recipe 'opt' (devqa_amd/synth.py): de
 DENSE_RECIPE = "SURVEY 8(d) recipe verbatim: every weight N(0, 0.02), LayerNorm weight 1, all biases 0 (dense ReLU FFN, no column compaction)"
 
 
+PROF = {"frac": 1.0, "steps": []}      # share of the last timed region that carried the slot profiler's event pairs (timed_leg)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="skip the full-depth parity block (GPU bf16 / fp32 mode vs the oracle cycle of cpu_baseline)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs #3-#5 legs (LLaVA + FT_VL, BLIP-2 + MEND_VL, MiniGPT-4 + IKE_VL)")
     ap.add_argument("--config-cycles", type=str, default="32,64,16", help="cycles of the three configs legs (llava_ft, blip2_mend, minigpt4_ike)")
+    ap.add_argument("--profile-every", type=int, default=4, help="the slot profiler's event pairs bracket every N-th step of the timed region (1: every step)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the two stages of every batch back to back on one stream")
     ap.add_argument("--host-pixels", action="store_true",
                     help="measurement only (never `value`): the pre-processed pixel values stay in pinned HOST memory and cross PCIe inside the timed "
@@ -461,9 +465,9 @@ class Leg:
             return torch.from_numpy(proc(self._synth_image_u8(s, tag, size, self.args.seed)))
         return self._evqa_cycles(n, self.cfg["text_config"]["vocab_size"], self.args.seed + 7919 * self.rank, image_of)
 
-    def run(self, batches, pipelined):
+    def run(self, batches, pipelined, on_iter=None):
         outs, metas = [], []
-        for o, mt in self.be.run_batches(batches, pipelined=pipelined):
+        for o, mt in self.be.run_batches(batches, pipelined=pipelined, on_iter=on_iter):
             outs += o
             metas += mt
         return outs, metas
@@ -500,9 +504,23 @@ def timed_leg(leg, K, W, barrier, use_dist, rank, world, dev, scaling=None, tota
         leg.run(warm, not a.no_pipeline)
     leg.reset_stats()
     barrier()
-    lib.profile(0 if os.environ.get("DEVQA_BENCH_NOPROF") else 1)      # (DEVQA_BENCH_NOPROF=1: A/B of what the per-launch event pairs cost)
+    # The slot profiler (HIP event pairs around every instrumented launch, on its own stream) is what `roofline` is read from; the pairs cost 1.8 % of
+    # throughput when every step carries them (profiles/r03_summary.md U), so they bracket a SAMPLE of the timed region: every --profile-every-th
+    # iteration of the pipelined loop (one iteration = stage A of one batch + stage B of the previous one = one step's launches; all steps of the weak
+    # leg launch the same shapes).  PROF["frac"] = instrumented share of the region: gemm_roofline / side_kernels scale their per-step figures with it.
+    n_it = len(timed)
+    P = max(1, int(a.profile_every))
+    sample = set(i for i in range(n_it) if i % P == P // 2 and i + 1 < n_it) if (P > 1 and not a.no_pipeline and n_it >= 2) else set()
+    off = bool(os.environ.get("DEVQA_BENCH_NOPROF"))       # A/B of what the event pairs cost: nothing is instrumented
+    PROF["frac"], PROF["steps"] = (len(sample) / n_it, sorted(sample)) if sample else (1.0, list(range(n_it)))
+    lib.profile(1)            # new recording
+    if sample or off:
+        lib.profile(0)
+
+    def on_iter(i):
+        lib.profile(2 if i in sample else 0)
     t0 = time.time()
-    outs, metas = leg.run(timed, not a.no_pipeline)
+    outs, metas = leg.run(timed, not a.no_pipeline, on_iter if (sample and not off) else None)
     barrier()
     elapsed = time.time() - t0
     lib.profile(0)
@@ -532,6 +550,7 @@ def gemm_roofline(K_E_local, elapsed):
     names = ["gemm_bf16_tn_kernel<32,128,1,4>", "gemm_bf16_glds_kernel<64,128,2,2>", "gemm_bf16_glds_kernel<128,128,2,2>",
              "gemm_bf16_pp_kernel"]
     prof = [lib.profile_read(i) for i in range(4)]
+    K_E_local, elapsed = K_E_local * PROF["frac"], elapsed * PROF["frac"]       # the instrumented share of the region
     dom = max(range(4), key=lambda i: prof[i][0])
     g_ms, g_fl, g_n = (sum(p[j] for p in prof) for j in range(3))
     dms, dfl, dn = prof[dom]
@@ -545,12 +564,15 @@ def gemm_roofline(K_E_local, elapsed):
             "executed_tflops": round((dfl / 1e12) / (dms / 1e3), 1) if dms > 0 else 0.0,
             "all_gemm_executed_tflops": round((g_fl / 1e12) / (g_ms / 1e3), 1) if g_ms > 0 else 0.0,
             "gemm_time_frac_of_step": round((g_ms / 1e3) / elapsed, 3), "executed_tflop_per_cycle": round(exec_per_cycle, 3),
-            "a_min_tflop_per_cycle": A_MIN_TFLOP_PER_CYCLE}
+            "a_min_tflop_per_cycle": A_MIN_TFLOP_PER_CYCLE,
+            "instrumented_steps": list(PROF["steps"]), "instrumented_share_of_timed_region": round(PROF["frac"], 4)}
 
 
 def side_kernels(be, elapsed):
     """HIP-event figures of the other instrumented kernels over the same timed region."""
     from devqa_amd import lib
+    frac = PROF["frac"]
+    elapsed = elapsed * frac                                  # the instrumented share of the region
     ms, fl, n = lib.profile_read(lib.PROF_ATTENTION)
     att = {"kernel": "attention_mfma_kernel", "launches": int(n), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
            "tflops_as_launched": round(fl / 1e12 / (ms / 1e3), 1) if ms > 0 else 0.0, "time_frac_of_step": round(ms / 1e3 / elapsed, 3)}
@@ -558,7 +580,7 @@ def side_kernels(be, elapsed):
     ln = {"kernel": "layernorm_kernel", "launches": int(n), "gbps": round(by / 1e9 / (ms / 1e3), 1) if ms > 0 else 0.0,
           "time_frac_of_step": round(ms / 1e3 / elapsed, 3)}
     ms, _, n = lib.profile_read(lib.PROF_FT_ADAMW)
-    by = float(be.stats.get("ft_bytes", 0))
+    by = float(be.stats.get("ft_bytes", 0)) * frac            # (the counter runs over every step; the instrumented steps are a 1-in-N sample of equal batches)
     npad_mean = be.stats.get("npad_sum", 0) / max(be.stats.get("cycles", 1), 1)
     ft = {"bound": "hbm", "kernel": "ft_adamw_step_kernel", "launches": int(n), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
           "achieved": round(by / 1e9 / (ms / 1e3), 1) if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -247,7 +247,7 @@ class BatchedEditEval:
         """One batch, both stages back to back on the current stream."""
         return self._stage_b(self._stage_a(rds, eds))
 
-    def run_batches(self, batches, pipelined=True):
+    def run_batches(self, batches, pipelined=True, on_iter=None):
         """batches: list of (rds, eds).  Software pipeline: the host runs ONE BATCH AHEAD of the GPU and never waits inside the loop --
         stage A of batch i+1 (host bookkeeping, vision encoder, frozen decoder prefix: the MFMA-heavy part) is queued, then stage B of
         batch i (pre-edit tails, the FT_VL loop, post-edit tails: many small launches), whose results come back through pinned
@@ -265,9 +265,13 @@ class BatchedEditEval:
             if side is None:
                 side = self._side_stream = torch.cuda.Stream(device=self.eng.dev)
         outs = []
+        if on_iter is not None:         # measurement hook (bench.py): iteration i queues stage A of batch i + 1 and stage B of batch i = one step's kernels
+            on_iter(-1)
         ctx = self._stage_a(*batches[0])
         pending = None
         for i in range(len(batches)):
+            if on_iter is not None:
+                on_iter(i)
             nxt = self._stage_a(*batches[i + 1]) if i + 1 < len(batches) else None
             handle = self._stage_b(ctx, side, finish=False)
             if pending is not None:

@@ -45,8 +45,10 @@ extern "C" int devqa_profile(int enable) {
             g_slot.resize(PROF_MAX_PAIRS);
             g_work.resize(PROF_MAX_PAIRS);
         }
-        g_used = 0;
-        g_dropped = 0;
+        if (enable != 2) {      // 2 = resume after a pause: the records taken so far stay (bench.py instruments a sample of its timed steps)
+            g_used = 0;
+            g_dropped = 0;
+        }
     }
     g_on = enable != 0;
     return DEVQA_OK;

@@ -88,7 +88,8 @@ int devqa_gemm_set_mode(int mode);
  * of one slot and returns its summed kernel time (ms), summed work and launch count.  Slots: 0..3 GEMM tile variants (32x128,
  * 64x128, 128x128, 256x256 ping-pong; work = 2 M N K FLOPs), 4 attention_mfma (FLOPs as launched), 5 ft_adamw_step (bytes if every
  * edit updates: 24 E Dout Din), 6 cosine top-k call (corpus bytes 4 N D), 7 layernorm (bytes).  devqa_profile_gemm / _gemm_read are
- * the round-1 names for slots 0..3 (arrays of 4).  Not part of the data path. */
+ * the round-1 names for slots 0..3 (arrays of 4).  Not part of the data path.  devqa_profile(1) starts a new recording, (0) pauses / ends it,
+ * (2) resumes a paused one without dropping its records (bench.py brackets a SAMPLE of its timed steps: the event pairs cost ~2 % of throughput). */
 #define DEVQA_PROF_SLOT_GEMM0 0
 #define DEVQA_PROF_SLOT_ATTENTION 4
 #define DEVQA_PROF_SLOT_FT_ADAMW 5
