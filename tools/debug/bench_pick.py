@@ -1,3 +1,5 @@
+"""One-line digest of a bench.py JSON line read from stdin (value, ms/step, the GEMM roofline fields, the shares of attention / LayerNorm / FT sweep):
+  python bench.py ... | python tools/debug/bench_pick.py <label>   -- used for the A/B runs of profiles/r03_summary.md U."""
 import sys,json
 j=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1])
 r=j["roofline"]
