@@ -154,6 +154,85 @@ static void run_pp(const char* name, const short8_t* src, float* out, unsigned l
            flop / (ms / 10 * 1e-3) / 1e12, clk[clk.size() / 2], cyc[cyc.size() / 2]);
 }
 
+// F: B with the next k-step's fragments fetched (second register set) while the current k-step's 64 MFMAs issue: one wave per SIMD has no partner to hide its
+// LDS latency behind, so the fetch has to sit inside its own MFMA stream.  DMA: + the same 64 KB of LDS-DMA staging per K-tile and CU as E (16 pieces per wave).
+template <bool DMA>
+__global__ __launch_bounds__(256) void probe_4w(const short8_t* __restrict__ src, float* __restrict__ out, unsigned long long* stamps, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 131072 / 16; i += 256) reinterpret_cast<short8_t*>(smem)[i] = src[(blockIdx.x * 8192 + i) & 0xfffff];
+    __syncthreads();
+    float4_t acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    unsigned long long c0 = 0, r0 = 0;
+    if (tid == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned char* base = smem + wave * 16384 + lane * 16;
+    const char* gsrc = reinterpret_cast<const char*>(src) + (size_t)(blockIdx.x & 255) * 65536 + lane * 16;
+    short8_t a[2][8], b[2][8];
+    auto fetch = [&](int set, const unsigned char* p) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[set][i] = *reinterpret_cast<const short8_t*>(p + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[set][j] = *reinterpret_cast<const short8_t*>(p + (8 + j) * 1024);
+    };
+    fetch(0, base);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int cur = ks, nxt = ks ^ 1;
+            fetch(nxt, base + (((it + ks + 1) & 1) << 16));
+            if (DMA) {     // 8 of the wave's 16 pieces per K-tile in each k-step
+                unsigned char* d = smem + (((it + 1) & 1) << 16) + ks * 32768 + wave * 8192;
+                const char* g = gsrc + ks * 32768 + wave * 8192;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) __builtin_amdgcn_global_load_lds((gptr_t)(g + q * 1024), (lptr_t)(d + q * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[cur][j], a[cur][i], acc[i][j], 0, 0, 0);
+            if (DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+        stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - c0;
+        stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <bool DMA>
+static void run_4w(const char* name, const short8_t* src, float* out, unsigned long long* st, int iters) {
+    auto k = probe_4w<DMA>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 30; ++r) hipLaunchKernelGGL(k, dim3(256), dim3(256), 131072, nullptr, src, out, st, iters);
+    hipEventRecord(e0, nullptr);
+    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(k, dim3(256), dim3(256), 131072, nullptr, src, out, st, iters);
+    hipEventRecord(e1, nullptr);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(512);
+    hipMemcpy(h.data(), st, 512 * 8, hipMemcpyDeviceToHost);
+    std::vector<double> clk, cyc;
+    for (int b = 0; b < 256; ++b) if (h[b * 2 + 1]) { clk.push_back((double)h[b * 2] / (double)h[b * 2 + 1] * 0.1); cyc.push_back((double)h[b * 2] / iters); }
+    std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
+    const double flop = 256.0 * 4 * iters * 128.0 * (2.0 * 16 * 16 * 32);
+    printf("%-44s %8.2f ms per launch  %7.1f TFLOP/s  clock %.3f GHz  shader cycles per K-tile %.0f (MFMA issue floor 2048)\n", name, ms / 10,
+           flop / (ms / 10 * 1e-3) / 1e12, clk[clk.size() / 2], cyc[cyc.size() / 2]);
+}
+
 template <int NI, int NJ, int WAVES>
 static void run(const char* name, const short8_t* src, float* out, unsigned long long* st, int iters) {
     auto k = probe<NI, NJ, WAVES>;
@@ -190,6 +269,8 @@ int main() {
         run<8, 8, 4>("B: 4 waves, 128 x 128 wave tiles (256 acc regs)", src, out, st, iters / 1);
         run_pp<true>("C: A in the shipped phase structure (barriers)", src, out, st, iters);
         run_pp<true, true>("E: C + the LDS-DMA staging (L2 hits)", src, out, st, iters);
+        run_4w<false>("F: B with the next k-step prefetched", src, out, st, iters);
+        run_4w<true>("G: F + the LDS-DMA staging (L2 hits)", src, out, st, iters);
     }
     return 0;
 }
