@@ -133,6 +133,14 @@ def split_batches(n, E):
     return [n // nb + (1 if i < n % nb else 0) for i in range(nb)]
 
 
+def instrumented_iters(n_it, every, pipelined=True):
+    """Iterations of the pipelined batch loop whose launches carry the slot profiler's event pairs: every `every`-th one, never the last (it has no
+    stage A of a next batch, i.e. is not a whole step's launches).  Empty set = instrument everything (short runs, --profile-every 1, no pipeline)."""
+    if every <= 1 or not pipelined or n_it < 2:
+        return set()
+    return set(i for i in range(n_it) if i % every == every // 2 and i + 1 < n_it)
+
+
 def build_threads(world):
     """Host threads of the synthetic-weight generator: 8 ranks x 16 threads on a 64-core host would oversubscribe it 2x during the
     (untimed) model build; share the cores between the ranks of this node."""
@@ -510,7 +518,7 @@ def timed_leg(leg, K, W, barrier, use_dist, rank, world, dev, scaling=None, tota
     # leg launch the same shapes).  PROF["frac"] = instrumented share of the region: gemm_roofline / side_kernels scale their per-step figures with it.
     n_it = len(timed)
     P = max(1, int(a.profile_every))
-    sample = set(i for i in range(n_it) if i % P == P // 2 and i + 1 < n_it) if (P > 1 and not a.no_pipeline and n_it >= 2) else set()
+    sample = instrumented_iters(n_it, P, not a.no_pipeline)
     off = bool(os.environ.get("DEVQA_BENCH_NOPROF"))       # A/B of what the event pairs cost: nothing is instrumented
     PROF["frac"], PROF["steps"] = (len(sample) / n_it, sorted(sample)) if sample else (1.0, list(range(n_it)))
     lib.profile(1)            # new recording

@@ -146,7 +146,10 @@ def test_bench_strong_stream_is_rank_count_invariant(tmp_path):
     sub-batches, the single gather): rank-order concatenation of the gathered score rows == the rows of the 1-rank run of the same
     stream, bit for bit -- also for a stream length that does not divide by the rank count or the batch size."""
     import numpy as np
-    from bench import split_batches
+    from bench import instrumented_iters, split_batches
+    assert instrumented_iters(20, 4) == {2, 6, 10, 14, 18} and instrumented_iters(10, 4) == {2, 6} and instrumented_iters(8, 4) == {2, 6}
+    assert instrumented_iters(3, 4) == set() and instrumented_iters(2, 4) == set() and instrumented_iters(20, 1) == set()      # = every step instrumented
+    assert instrumented_iters(20, 4, pipelined=False) == set() and 19 not in instrumented_iters(20, 2) and instrumented_iters(7, 4) == {2}
     assert split_batches(125, 127) == [63, 62] and split_batches(1000, 127) == [125] * 8 and split_batches(1, 127) == [1]
     assert split_batches(0, 127) == [] and sum(split_batches(255, 127)) == 255 and max(split_batches(255, 127)) <= 127
     for total in (1000, 37):
